@@ -1,0 +1,159 @@
+/*
+ * st3r.h -- C ABI of libst3r_hip.so, the MI355X (gfx950) hot path behind the
+ * starster Python API.
+ *
+ * The reference (phuang1024/Starst3r v0.4.0) has NO plugin/FFI boundary of its own:
+ * its hot path is reached through Python calls into third-party packages
+ *   starster/gs.py:76-87          gsplat.rasterization(...)            -> st3r_gs_* below
+ *   starster/gs.py:126-136,153    compute_loss + loss.backward()       -> st3r_loss_l1_ssim, *_bwd
+ *   starster/gs.py:37,159-161     6x torch.optim.Adam.step             -> st3r_adam_step
+ *   starster/reconstruct.py:371-406  optimize_loop (alignment)         -> st3r_align_*
+ *   starster/reconstruct.py:97    forward_mast3r -> fast_reciprocal_NNs-> st3r_recip_nn
+ * so this header DEFINES the boundary a maintainer would bind with ctypes (see
+ * INTEGRATION.md).  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every pointer argument is a DEVICE pointer owned by the caller unless the name
+ *     ends in _host; the library never frees or retains caller memory past the call;
+ *   - scratch lives in a grow-only arena inside the ctx;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it unless
+ *     documented otherwise;
+ *   - every function returns 0 on success or a negative ST3R_ERR_* code; the message is
+ *     available from st3r_last_error() (thread local).  No C++ exception crosses the ABI;
+ *   - a ctx belongs to one (process, GPU) and is not thread safe.
+ *
+ * Layouts (floats unless noted)
+ *   means [N,3]  quats [N,4] (w,x,y,z)  scales [N,3] RAW  opacities [N] RAW
+ *   sh    [N,sh_stride]  with the degree<=1 coefficients in the first 12 floats of each
+ *         row ([4,3]); for the reference's shN tensor [N,24,3] sh_stride = 72
+ *   viewmats [C,4,4] world->camera row major, Ks [C,3,3], campos [C,3] = inverse(viewmats)[:, :3, 3]
+ *   splats [C*N,12]: x y opacity | conic a b c | r g b | depth | radius (int32 bits) | 0
+ *          pair id pid = cam*N + gaussian ("dense" ids; radius == 0 <=> culled)
+ *   v_splats [C*N,12]: v_x v_y v_opacity | v_conic a b c | v_r v_g v_b | 0 0 0
+ *   grads / adam m / adam v [23*N]: blocks means[3N] quats[4N] scales[3N] opacities[N] sh4[12N]
+ *   images [C,H,W,3], alpha [C,H,W], last_ids int32 [C,H,W]
+ */
+#ifndef ST3R_H
+#define ST3R_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST3R_VERSION 100 /* 0.1.0 */
+
+#define ST3R_OK 0
+#define ST3R_ERR_INVALID (-1)  /* bad argument */
+#define ST3R_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define ST3R_ERR_CAPACITY (-3) /* caller-supplied capacity too small */
+#define ST3R_ERR_NOMEM (-4)
+
+#define ST3R_SPLAT_STRIDE 12
+#define ST3R_GRAD_PER_GAUSSIAN 23
+
+typedef struct st3r_ctx st3r_ctx;
+
+int st3r_version(void);
+const char* st3r_last_error(void);
+int st3r_ctx_create(int device, st3r_ctx** out);
+int st3r_ctx_destroy(st3r_ctx* ctx);
+/* bytes currently held by the ctx arena (diagnostics) */
+int64_t st3r_ctx_arena_bytes(st3r_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------
+ * Path C -- 3DGS rasterization stages (replace gsplat.rasterization, starster/gs.py:76-87)
+ * ---------------------------------------------------------------------------------- */
+
+/* projection + degree-1 SH colour for every (camera, gaussian).  gsplat
+ * fully_fused_projection + spherical_harmonics + clamp_min(c+0.5,0).
+ * Also accumulates sum(sigmoid(opacities)) and sum(exp(scales)) into reg_sums[2]
+ * (double, device, may be NULL) for the regularisers of starster/gs.py:132-134. */
+int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,
+                       const float* scales, const float* opacities, const float* sh, int sh_stride,
+                       const float* viewmats, const float* Ks, const float* campos, int width, int height,
+                       int tile_size, float eps2d, float near_plane, float far_plane, float radius_clip,
+                       float* splats, int32_t* tiles_per_gauss, double* reg_sums);
+
+/* inclusive scan of tiles_per_gauss -> cum_tiles; total copied to *n_isects_host
+ * (this call synchronises the stream). gsplat isect_tiles pass 1 + torch.cumsum. */
+int st3r_gs_isect_scan(st3r_ctx* ctx, void* stream, int64_t n_pairs, const int32_t* tiles_per_gauss,
+                       int32_t* cum_tiles, int64_t* n_isects_host);
+
+/* gsplat isect_tiles pass 2: key = cam << (32+tile_bits) | tile << 32 | depth bits,
+ * value = dense pair id. */
+int st3r_gs_isect_emit(st3r_ctx* ctx, void* stream, int N, int C, const float* splats,
+                       const int32_t* cum_tiles, int tile_size, int tile_w, int tile_h, int64_t n_isects,
+                       int64_t* isect_ids, int32_t* flatten_ids);
+
+/* stable ascending sort of (key,value) on bits [0,end_bit).  cub DeviceRadixSort::SortPairs
+ * as used by gsplat.  Inputs may be clobbered. */
+int st3r_gs_sort(st3r_ctx* ctx, void* stream, int64_t n_isects, int end_bit, int64_t* isect_ids,
+                 int32_t* flatten_ids, int64_t* isect_ids_sorted, int32_t* flatten_ids_sorted);
+
+/* gsplat isect_offset_encode: offsets [C,tile_h,tile_w] */
+int st3r_gs_offsets(st3r_ctx* ctx, void* stream, int64_t n_isects, const int64_t* isect_ids_sorted, int C,
+                    int tile_w, int tile_h, int32_t* offsets);
+
+/* gsplat rasterize_to_pixels forward (no background, RGB) */
+int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width, int height, int tile_size, int tile_w,
+                      int tile_h, const float* splats, const int32_t* offsets, const int32_t* flatten_ids,
+                      int64_t n_isects, float* rgb, float* alpha, int32_t* last_ids);
+
+/* gsplat rasterize_to_pixels backward.  v_alpha may be NULL (== 0).  v_splats is
+ * zero-filled by this call (n_pairs = C*N records) and then accumulated into. */
+int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width, int height, int tile_size, int tile_w,
+                      int tile_h, const float* splats, const int32_t* offsets, const int32_t* flatten_ids,
+                      int64_t n_isects, const float* alpha, const int32_t* last_ids, const float* v_rgb,
+                      const float* v_alpha, int64_t n_pairs, float* v_splats);
+
+/* backward of st3r_gs_project_sh, summed over cameras, plus the regulariser gradients
+ *   reg_views * opac_fac * d mean|sigmoid(o)|   and   reg_views * scale_fac * d mean|exp(s)|
+ * (starster/gs.py:132-134, added once per view :150-152).  Writes grads [23*N]. */
+int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,
+                           const float* scales, const float* opacities, const float* sh, int sh_stride,
+                           const float* viewmats, const float* Ks, const float* campos, int width, int height,
+                           float eps2d, const float* splats, const float* v_splats, float reg_views,
+                           float opac_fac, float scale_fac, float* grads);
+
+/* L1 + SSIM of C views (starster/gs.py:126-130; torchmetrics SSIM data_range=1).
+ *   loss_c = w_l1 * mean|gt - r| + w_ssim * (1 - SSIM(gt, r))
+ * sums [C,2] (double, device): per view  sum|gt-r|  and  sum of the interior SSIM map
+ * (zeroed by this call).  v_render [C,H,W,3] = d(sum_c loss_c)/d render; may be NULL. */
+int st3r_loss_l1_ssim(st3r_ctx* ctx, void* stream, int C, int height, int width, const float* render,
+                      const float* gt, float w_l1, float w_ssim, double* sums, float* v_render);
+
+/* fused Adam over the 23 active scalars per gaussian (replaces the 6 torch.optim.Adam of
+ * starster/gs.py:37,159-161; sh0 and SH rows 4..23 never receive gradient and are
+ * left untouched, their Adam update is exactly 0).  `step` is 1-based. */
+int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
+                   float* opacities, float* sh, int sh_stride, const float* grads, float* m, float* v, double lr,
+                   double beta1, double beta2, double eps, int step);
+
+/* ------------------------------------------------------------------------------------
+ * Fused train step, first half: everything of one iteration of starster/gs.py:143-153
+ * (render all C local views -> loss -> backward) using ctx scratch only.
+ *   grads   [23*N]  written (not accumulated)
+ *   loss_out        device float; receives this rank's loss (sum over its views, regularisers
+ *                   added reg_views times)
+ *   stats_host[4]   optional host int64: n_visible_pairs (or -1), n_isects, arena bytes, 0
+ * The second half is an (optional) all-reduce of `grads` by the caller, then st3r_adam_step.
+ * ---------------------------------------------------------------------------------- */
+int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,
+                          const float* scales, const float* opacities, const float* sh, int sh_stride,
+                          const float* viewmats, const float* Ks, const float* campos, const float* gt_images,
+                          int width, int height, float ssim_fac, float opac_fac, float scale_fac, float* grads,
+                          float* loss_out, int64_t* stats_host);
+
+/* Inference render of C views into caller buffers using ctx scratch (starster/gs.py:47-88
+ * without `info`). */
+int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,
+                   const float* scales, const float* opacities, const float* sh, int sh_stride,
+                   const float* viewmats, const float* Ks, const float* campos, int width, int height,
+                   float* rgb, float* alpha, int64_t* stats_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST3R_H */

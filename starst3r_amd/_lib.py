@@ -1,0 +1,69 @@
+"""ctypes binding of libst3r_hip.so (include/st3r.h).
+
+There is NO fallback: if the shared library is missing or a call fails this module raises.
+The product path never routes through oracle/ or any CPU implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libst3r_hip.so")
+
+_lib = None
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/st3r.h
+SIGNATURES = {
+    "st3r_version": [],
+    "st3r_last_error": [],
+    "st3r_ctx_create": [i32, C.POINTER(vp)],
+    "st3r_ctx_destroy": [vp],
+    "st3r_ctx_arena_bytes": [vp],
+    "st3r_gs_project_sh": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32,
+                           vp, vp, vp],
+    "st3r_gs_isect_scan": [vp, vp, i64, vp, vp, C.POINTER(i64)],
+    "st3r_gs_isect_emit": [vp, vp, i32, i32, vp, vp, i32, i32, i32, i64, vp, vp],
+    "st3r_gs_sort": [vp, vp, i64, i32, vp, vp, vp, vp],
+    "st3r_gs_offsets": [vp, vp, i64, vp, i32, i32, i32, vp],
+    "st3r_gs_blend_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp],
+    "st3r_gs_blend_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp],
+    "st3r_gs_project_sh_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32,
+                               f32, vp],
+    "st3r_loss_l1_ssim": [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp],
+    "st3r_adam_step": [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, f64, f64, f64, f64, i32],
+    "st3r_gs_train_fwd_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp,
+                              vp, C.POINTER(i64)],
+    "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],
+}
+_RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_ctx_arena_bytes": i64}
+
+
+class St3rError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it is not built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise St3rError(
+                f"{LIB_PATH} is missing: build it with `python -m starst3r_amd.build` "
+                "(there is no CPU fallback for the hot path)")
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().st3r_last_error()
+        msg = msg.decode() if msg else ""
+        if rc == -1:
+            raise ValueError(f"st3r: invalid argument: {msg}")
+        raise St3rError(f"st3r error {rc}: {msg}")

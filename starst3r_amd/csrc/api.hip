@@ -1,0 +1,221 @@
+// C-ABI glue: context, scratch arena, error reporting and the fused train / render steps
+// that chain the stage kernels on one stream using only ctx scratch.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void st3r_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+ST3R_EXPORT int st3r_version(void) { return ST3R_VERSION; }
+ST3R_EXPORT const char* st3r_last_error(void) { return g_err; }
+
+ST3R_EXPORT int st3r_ctx_create(int device, st3r_ctx** out) {
+    ARG_CHECK(out);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    ARG_CHECK(device >= 0 && device < ndev);
+    HIP_TRY(hipSetDevice(device));
+    st3r_ctx* c = new (std::nothrow) st3r_ctx();
+    if (!c) { st3r_set_error("out of host memory"); return ST3R_ERR_NOMEM; }
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    hipError_t e = hipHostMalloc((void**)&c->pinned, 64 * sizeof(int64_t), hipHostMallocDefault);
+    if (e != hipSuccess) { delete c; st3r_set_error("hipHostMalloc: %s", hipGetErrorString(e)); return ST3R_ERR_HIP; }
+    *out = c;
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_ctx_destroy(st3r_ctx* ctx) {
+    if (!ctx) return ST3R_OK;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < SLOT_COUNT; ++i)
+        if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx;
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int64_t st3r_ctx_arena_bytes(st3r_ctx* ctx) {
+    if (!ctx) return 0;
+    int64_t t = 0;
+    for (int i = 0; i < SLOT_COUNT; ++i) t += (int64_t)ctx->slot_bytes[i];
+    return t;
+}
+
+int st3r_arena_get(st3r_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->slot_bytes[slot] < bytes) {
+        // grow with 25% headroom so slowly growing intersection counts do not reallocate every step
+        size_t want = bytes + bytes / 4;
+        want = (want + 255) & ~(size_t)255;
+        if (ctx->slot_ptr[slot]) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(ctx->slot_ptr[slot]));
+            ctx->slot_ptr[slot] = nullptr; ctx->slot_bytes[slot] = 0;
+        }
+        hipError_t e = hipMalloc(&ctx->slot_ptr[slot], want);
+        if (e != hipSuccess) {
+            st3r_set_error("arena slot %d: hipMalloc(%zu) failed: %s", slot, want, hipGetErrorString(e));
+            return ST3R_ERR_NOMEM;
+        }
+        ctx->slot_bytes[slot] = want;
+    }
+    *out = ctx->slot_ptr[slot];
+    return ST3R_OK;
+}
+
+// ---- internal stage launchers (other translation units) ----
+int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
+                         int64_t* n_isects_host);
+int st3r_isect_emit_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* cum, int tile_size,
+                         int tile_w, int tile_h, int64_t* isect_ids, int32_t* flatten_ids);
+int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t* keys_in, int32_t* vals_in,
+                   int64_t* keys_out, int32_t* vals_out);
+int st3r_isect_offsets_impl(hipStream_t s, int64_t n_isects, const int64_t* ids, int C, int tile_w, int tile_h,
+                            int32_t* offsets);
+int st3r_blend_fwd_impl(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
+                        const int32_t* offsets, const int32_t* flat, int64_t n_isects, float* rgb, float* alpha,
+                        int32_t* last_ids);
+int st3r_blend_bwd_impl(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
+                        const int32_t* offsets, const int32_t* flat, int64_t n_isects, const float* alpha,
+                        const int32_t* last_ids, const float* v_rgb, const float* v_alpha, int64_t n_pairs,
+                        float* v_splats);
+int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
+                   float w_l1, float w_ssim, double* sums, float* v_render);
+
+static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+
+#define GET(slot, type, count, var)                                                          \
+    type* var;                                                                               \
+    {                                                                                        \
+        void* _p;                                                                            \
+        int _rc = st3r_arena_get(ctx, slot, sizeof(type) * (size_t)(count), &_p);            \
+        if (_rc) return _rc;                                                                 \
+        var = (type*)_p;                                                                     \
+    }
+
+struct RasterOut {
+    float* splats; int32_t* offsets; int32_t* flat; int64_t n_isects; int tile_w, tile_h;
+};
+
+// project -> scan -> emit -> sort -> offsets, all in ctx scratch
+static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats,
+                           const float* scales, const float* opacities, const float* sh, int sh_stride,
+                           const float* viewmats, const float* Ks, const float* campos, int W, int H,
+                           double* reg_sums, RasterOut* o) {
+    const int tile = 16;
+    const int tile_w = (W + tile - 1) / tile, tile_h = (H + tile - 1) / tile;
+    const int64_t n_pairs = (int64_t)N * C;
+    GET(SLOT_SPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, splats);
+    GET(SLOT_TILES, int32_t, n_pairs, tiles);
+    GET(SLOT_CUM, int32_t, n_pairs, cum);
+    GET(SLOT_OFFSETS, int32_t, (int64_t)C * tile_w * tile_h, offsets);
+    int rc = st3r_gs_project_sh(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
+                                H, tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums);
+    if (rc) return rc;
+    int64_t n_isects = 0;
+    rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, &n_isects);
+    if (rc) return rc;
+    GET(SLOT_KEYS_A, int64_t, n_isects, keys_a);
+    GET(SLOT_KEYS_B, int64_t, n_isects, keys_b);
+    GET(SLOT_VALS_A, int32_t, n_isects, vals_a);
+    GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
+    if (n_isects > 0) {
+        rc = st3r_isect_emit_impl(s, N, C, splats, cum, tile, tile_w, tile_h, keys_a, vals_a);
+        if (rc) return rc;
+        const int end_bit = 32 + bit_length_u32((uint32_t)(tile_w * tile_h)) + bit_length_u32((uint32_t)C);
+        rc = st3r_sort_impl(ctx, s, n_isects, end_bit, keys_a, vals_a, keys_b, vals_b);
+        if (rc) return rc;
+    }
+    rc = st3r_isect_offsets_impl(s, n_isects, keys_b, C, tile_w, tile_h, offsets);
+    if (rc) return rc;
+    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->n_isects = n_isects;
+    o->tile_w = tile_w; o->tile_h = tile_h;
+    return ST3R_OK;
+}
+
+__global__ void k_finalize_loss(int C, const double* __restrict__ sums, const double* __restrict__ reg_sums,
+                                double inv_px, double inv_cnt, double w_l1, double w_ssim, double reg_views,
+                                double opac_k, double scale_k, float* __restrict__ loss_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double loss = 0;
+        for (int c = 0; c < C; ++c) loss += w_l1 * sums[2 * c] * inv_px + w_ssim * (1.0 - sums[2 * c + 1] * inv_cnt);
+        loss += reg_views * (opac_k * reg_sums[0] + scale_k * reg_sums[1]);
+        loss_out[0] = (float)loss;
+    }
+}
+
+ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means,
+                                      const float* quats, const float* scales, const float* opacities,
+                                      const float* sh, int sh_stride, const float* viewmats, const float* Ks,
+                                      const float* campos, const float* gt_images, int width, int height,
+                                      float ssim_fac, float opac_fac, float scale_fac, float* grads,
+                                      float* loss_out, int64_t* stats_host) {
+    ARG_CHECK(ctx && N > 0 && C > 0 && width > 0 && height > 0 && sh_stride >= 12);
+    ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && gt_images && grads && loss_out);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = width, H = height;
+    const int64_t n_pairs = (int64_t)N * C, n_px = (int64_t)C * H * W;
+    GET(SLOT_SMALL, double, 2 * (size_t)C + 8, small);
+    double* sums = small;              // [C,2]
+    double* reg_sums = small + 2 * C;  // [2]
+    HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 2, s));
+    RasterOut ro;
+    int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
+                             reg_sums, &ro);
+    if (rc) return rc;
+    GET(SLOT_RGB, float, n_px * 3, rgb);
+    GET(SLOT_ALPHA, float, n_px, alpha);
+    GET(SLOT_LAST, int32_t, n_px, last);
+    GET(SLOT_VRENDER, float, n_px * 3, v_rgb);
+    GET(SLOT_VSPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, v_splats);
+    rc = st3r_blend_fwd_impl(s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb, alpha,
+                             last);
+    if (rc) return rc;
+    rc = st3r_loss_impl(ctx, s, C, H, W, rgb, gt_images, 1.0f - ssim_fac, ssim_fac, sums, v_rgb);
+    if (rc) return rc;
+    rc = st3r_blend_bwd_impl(s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha, last,
+                             v_rgb, nullptr, n_pairs, v_splats);
+    if (rc) return rc;
+    rc = st3r_gs_project_sh_bwd(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
+                                H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads);
+    if (rc) return rc;
+    const int Hi = H - 10, Wi = W - 10;
+    const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
+    hipLaunchKernelGGL(k_finalize_loss, dim3(1), dim3(64), 0, s, C, sums, reg_sums, 1.0 / ((double)H * W * 3),
+                       cnt > 0 ? 1.0 / cnt : 0.0, (double)(1.0f - ssim_fac), (double)ssim_fac, (double)C,
+                       (double)opac_fac / N, (double)scale_fac / (3.0 * N), loss_out);
+    LAUNCH_CHECK();
+    if (stats_host) {
+        stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = 0;
+    }
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,
+                               const float* scales, const float* opacities, const float* sh, int sh_stride,
+                               const float* viewmats, const float* Ks, const float* campos, int width, int height,
+                               float* rgb, float* alpha, int64_t* stats_host) {
+    ARG_CHECK(ctx && N > 0 && C > 0 && width > 0 && height > 0 && sh_stride >= 12);
+    ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && rgb && alpha);
+    hipStream_t s = (hipStream_t)stream;
+    RasterOut ro;
+    int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width,
+                             height, nullptr, &ro);
+    if (rc) return rc;
+    GET(SLOT_LAST, int32_t, (int64_t)C * height * width, last);
+    rc = st3r_blend_fwd_impl(s, C, width, height, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects,
+                             rgb, alpha, last);
+    if (rc) return rc;
+    if (stats_host) {
+        stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = 0;
+    }
+    return ST3R_OK;
+}

@@ -1,0 +1,230 @@
+// K2/K3/K5: tile-intersection bookkeeping.
+//   scan    -- inclusive prefix sum of tiles_per_gauss (gsplat: torch.cumsum between the two
+//              isect_tiles passes), three-phase: per-block reduce, one-block scan of the
+//              block sums, per-block downsweep with wave64 prefix scans;
+//   emit    -- gsplat isect_tiles pass 2: one (key,value) per touched tile;
+//   offsets -- gsplat isect_offset_encode.
+// All integer work: results are bit-exact against oracle/gs_oracle.c.
+#include "common.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 16
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// block-wide inclusive scan of one int per thread (256 threads = 4 waves); returns inclusive value,
+// *total receives the block total
+__device__ __forceinline__ int block_incl_scan(int v, int* total) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = wave_incl_scan(v);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) base += (i < w) ? wsum[i] : 0;
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return inc + base;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int32_t* __restrict__ in, int64_t n,
+                                                              int32_t* __restrict__ block_sums) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += in[idx];
+    }
+    int total;
+    block_incl_scan(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of block_sums in place; grand total -> total_out[0]
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(int32_t* __restrict__ block_sums, int nblocks,
+                                                                 int32_t* __restrict__ total_out) {
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += SCAN_THREADS) {
+        int idx = base + threadIdx.x;
+        int v = idx < nblocks ? block_sums[idx] : 0;
+        int total;
+        int inc = block_incl_scan(v, &total);
+        if (idx < nblocks) block_sums[idx] = carry + inc - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) total_out[0] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* __restrict__ in, int64_t n,
+                                                            const int32_t* __restrict__ block_sums,
+                                                            int32_t* __restrict__ out) {
+    // thread t owns SCAN_ITEMS consecutive elements so the scan order is the array order
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        int64_t idx = base + i;
+        v[i] = idx < n ? in[idx] : 0;
+        s += v[i];
+    }
+    int total;
+    int inc = block_incl_scan(s, &total);
+    int run = block_sums[blockIdx.x] + inc - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        run += v[i];
+        int64_t idx = base + i;
+        if (idx < n) out[idx] = run;
+    }
+}
+
+// out = inclusive scan(in); the grand total is left in the SLOT_SCAN_TMP buffer at [nblocks]
+int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, int32_t* out, int64_t n,
+                            int32_t** total_dev) {
+    int nblocks = ceil_div(n, SCAN_TILE);
+    void* tmp;
+    int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, sizeof(int32_t) * (size_t)(nblocks + 4), &tmp);
+    if (rc) return rc;
+    int32_t* bs = (int32_t*)tmp;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, n, bs);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_THREADS), 0, s, bs, nblocks, bs + nblocks);
+    hipLaunchKernelGGL(k_scan_down, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, n, bs, out);
+    LAUNCH_CHECK();
+    if (total_dev) *total_dev = bs + nblocks;
+    return ST3R_OK;
+}
+
+int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
+                         int64_t* n_isects_host) {
+    if (n_pairs == 0) { if (n_isects_host) *n_isects_host = 0; return ST3R_OK; }
+    int32_t* total_dev = nullptr;
+    int rc = st3r_scan_inclusive_i32(ctx, s, tiles, cum, n_pairs, &total_dev);
+    if (rc) return rc;
+    if (n_isects_host) {
+        int32_t* pin = (int32_t*)ctx->pinned;
+        HIP_TRY(hipMemcpyAsync(pin, total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *n_isects_host = (int64_t)pin[0];
+    }
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_gs_isect_scan(st3r_ctx* ctx, void* stream, int64_t n_pairs, const int32_t* tiles_per_gauss,
+                                   int32_t* cum_tiles, int64_t* n_isects_host) {
+    ARG_CHECK(ctx && n_pairs >= 0 && tiles_per_gauss && cum_tiles && n_isects_host);
+    return st3r_isect_scan_impl(ctx, (hipStream_t)stream, n_pairs, tiles_per_gauss, cum_tiles, n_isects_host);
+}
+
+__device__ __forceinline__ int tile_clampi(float v, int hi) {
+    if (!(v > 0.0f)) return 0;
+    if (v >= (float)hi) return hi;
+    return (int)v;
+}
+
+__global__ __launch_bounds__(256) void k_isect_emit(int N, int64_t n_pairs, const float4* __restrict__ splats,
+                                                    const int32_t* __restrict__ cum, int tile_size, int tile_w,
+                                                    int tile_h, int tile_n_bits, int64_t* __restrict__ isect_ids,
+                                                    int32_t* __restrict__ flatten_ids) {
+    const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= n_pairs) return;
+    const int end = cum[pid];
+    const int start = pid == 0 ? 0 : cum[pid - 1];
+    if (end == start) return;
+    const float4 r0 = splats[pid * 3 + 0];
+    const float4 r2 = splats[pid * 3 + 2];
+    const float radius = (float)__float_as_int(r2.z);
+    const float tile_radius = radius / (float)tile_size;
+    const float tile_x = r0.x / (float)tile_size, tile_y = r0.y / (float)tile_size;
+    const int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
+    const int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
+    const int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
+    const int y1 = tile_clampi(ceilf(tile_y + tile_radius), tile_h);
+    const int64_t cid = pid / N;
+    const int64_t cid_enc = cid << (32 + tile_n_bits);
+    const int64_t depth_enc = (int64_t)(uint32_t)__float_as_int(r2.y);
+    int cur = start;
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            const int64_t tile_id = (int64_t)ty * tile_w + tx;
+            isect_ids[cur] = cid_enc | (tile_id << 32) | depth_enc;
+            flatten_ids[cur] = (int32_t)pid;
+            ++cur;
+        }
+}
+
+static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+
+int st3r_isect_emit_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* cum, int tile_size,
+                         int tile_w, int tile_h, int64_t* isect_ids, int32_t* flatten_ids) {
+    int64_t n_pairs = (int64_t)N * C;
+    if (n_pairs == 0) return ST3R_OK;
+    int tile_n_bits = bit_length_u32((uint32_t)(tile_w * tile_h));
+    hipLaunchKernelGGL(k_isect_emit, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs, (const float4*)splats,
+                       cum, tile_size, tile_w, tile_h, tile_n_bits, isect_ids, flatten_ids);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_gs_isect_emit(st3r_ctx* ctx, void* stream, int N, int C, const float* splats,
+                                   const int32_t* cum_tiles, int tile_size, int tile_w, int tile_h,
+                                   int64_t n_isects, int64_t* isect_ids, int32_t* flatten_ids) {
+    ARG_CHECK(ctx && N >= 0 && C > 0 && splats && cum_tiles && tile_size > 0 && tile_w > 0 && tile_h > 0);
+    if (n_isects == 0) return ST3R_OK;
+    ARG_CHECK(isect_ids && flatten_ids);
+    return st3r_isect_emit_impl((hipStream_t)stream, N, C, splats, cum_tiles, tile_size, tile_w, tile_h, isect_ids,
+                                flatten_ids);
+}
+
+__global__ __launch_bounds__(256) void k_isect_offsets(int64_t n_isects, const int64_t* __restrict__ ids, int C,
+                                                       int n_tiles, int tile_n_bits,
+                                                       int32_t* __restrict__ offsets) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_isects) return;
+    const int64_t hi = ids[idx] >> 32;
+    const int64_t id_curr = (hi >> tile_n_bits) * n_tiles + (hi & (((int64_t)1 << tile_n_bits) - 1));
+    if (idx == 0) {
+        for (int64_t i = 0; i <= id_curr; ++i) offsets[i] = 0;
+    } else {
+        const int64_t hp = ids[idx - 1] >> 32;
+        const int64_t id_prev = (hp >> tile_n_bits) * n_tiles + (hp & (((int64_t)1 << tile_n_bits) - 1));
+        if (id_prev != id_curr)
+            for (int64_t i = id_prev + 1; i <= id_curr; ++i) offsets[i] = (int32_t)idx;
+    }
+    if (idx == n_isects - 1) {
+        const int64_t total = (int64_t)C * n_tiles;
+        for (int64_t i = id_curr + 1; i < total; ++i) offsets[i] = (int32_t)n_isects;
+    }
+}
+
+int st3r_isect_offsets_impl(hipStream_t s, int64_t n_isects, const int64_t* ids, int C, int tile_w, int tile_h,
+                            int32_t* offsets) {
+    int n_tiles = tile_w * tile_h;
+    if (n_isects == 0) {
+        HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)C * n_tiles, s));
+        return ST3R_OK;
+    }
+    int tile_n_bits = bit_length_u32((uint32_t)n_tiles);
+    hipLaunchKernelGGL(k_isect_offsets, dim3(ceil_div(n_isects, 256)), dim3(256), 0, s, n_isects, ids, C, n_tiles,
+                       tile_n_bits, offsets);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_gs_offsets(st3r_ctx* ctx, void* stream, int64_t n_isects, const int64_t* isect_ids_sorted,
+                                int C, int tile_w, int tile_h, int32_t* offsets) {
+    ARG_CHECK(ctx && n_isects >= 0 && C > 0 && tile_w > 0 && tile_h > 0 && offsets);
+    ARG_CHECK(n_isects == 0 || isect_ids_sorted);
+    return st3r_isect_offsets_impl((hipStream_t)stream, n_isects, isect_ids_sorted, C, tile_w, tile_h, offsets);
+}

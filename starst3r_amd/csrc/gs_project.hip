@@ -1,0 +1,216 @@
+// K1: projection + degree-1 SH colour + tile count, one thread per Gaussian looping over
+// the cameras in registers (each Gaussian's 23 parameter floats are read from HBM once,
+// its world covariance is built once and reused for every view).
+//
+// Replaces gsplat fully_fused_projection (packed) + spherical_harmonics + isect_tiles
+// pass 1 as reached from starster/gs.py:76-87.
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off: radii, tile rectangles and depth keys are
+// integer outputs that must be bit-exact against oracle/gs_oracle.c, so every float
+// operation below is a single IEEE binary32 op in a fixed order (sums of three products
+// left to right; 1/x and sqrt correctly rounded -- hipcc's default for HIP).
+#include "common.h"
+
+#define CAM_STRIDE 32
+// per-camera block in LDS: [0..11] view matrix rows 0..2 (R|t), 12 fx, 13 fy, 14 cx, 15 cy,
+// 16 lim_x_pos, 17 lim_x_neg, 18 lim_y_pos, 19 lim_y_neg, 20..22 camera position
+
+__device__ __forceinline__ float dot3f(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return (a0 * b0 + a1 * b1) + a2 * b2;
+}
+
+__device__ __forceinline__ int tile_clampi(float v, int hi) {
+    if (!(v > 0.0f)) return 0;
+    if (v >= (float)hi) return hi;
+    return (int)v;
+}
+
+#define SH_C0 0.2820947917738781f
+#define SH_C1 0.48860251190292f
+
+__global__ __launch_bounds__(256) void k_project_sh_fwd(
+    int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ sh,
+    int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
+    const float* __restrict__ campos, int W, int H, int tile_size, int tile_w, int tile_h, float eps2d,
+    float near_plane, float far_plane, float radius_clip, float4* __restrict__ splats,
+    int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_sums) {
+    extern __shared__ float cam[];
+    __shared__ float red[8];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float* o = cam + c * CAM_STRIDE;
+        const float* V = viewmats + 16 * c;
+        for (int k = 0; k < 12; ++k) o[k] = V[k];
+        const float* K = Ks + 9 * c;
+        float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+        o[12] = fx; o[13] = fy; o[14] = cx; o[15] = cy;
+        float tan_fovx = 0.5f * (float)W / fx;
+        float tan_fovy = 0.5f * (float)H / fy;
+        o[16] = ((float)W - cx) / fx + 0.3f * tan_fovx;
+        o[17] = cx / fx + 0.3f * tan_fovx;
+        o[18] = ((float)H - cy) / fy + 0.3f * tan_fovy;
+        o[19] = cy / fy + 0.3f * tan_fovy;
+        o[20] = campos[3 * c]; o[21] = campos[3 * c + 1]; o[22] = campos[3 * c + 2];
+    }
+    __syncthreads();
+
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = g < N;
+    float mx = 0, my = 0, mz = 0, opac = 0;
+    float cov0 = 0, cov1 = 0, cov2 = 0, cov3 = 0, cov4 = 0, cov5 = 0;
+    float k[12];
+    float reg_o = 0.f, reg_s = 0.f;
+    if (active) {
+        mx = means[3 * g]; my = means[3 * g + 1]; mz = means[3 * g + 2];
+        opac = opacities[g];
+        float qw = quats[4 * g], qx = quats[4 * g + 1], qy = quats[4 * g + 2], qz = quats[4 * g + 3];
+        float s0 = scales[3 * g], s1 = scales[3 * g + 1], s2 = scales[3 * g + 2];
+        const float* kp = sh + (int64_t)g * sh_stride;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) k[i] = kp[i];
+        float n2 = ((qw * qw + qx * qx) + qy * qy) + qz * qz;
+        float inv = 1.0f / sqrtf(n2);
+        qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+        float x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
+        float xy = qx * qy, xz = qx * qz, yz = qy * qz;
+        float wx = qw * qx, wy = qw * qy, wz = qw * qz;
+        float m0 = (1.0f - 2.0f * (y2 + z2)) * s0, m1 = (2.0f * (xy - wz)) * s1, m2 = (2.0f * (xz + wy)) * s2;
+        float m3 = (2.0f * (xy + wz)) * s0, m4 = (1.0f - 2.0f * (x2 + z2)) * s1, m5 = (2.0f * (yz - wx)) * s2;
+        float m6 = (2.0f * (xz - wy)) * s0, m7 = (2.0f * (yz + wx)) * s1, m8 = (1.0f - 2.0f * (x2 + y2)) * s2;
+        cov0 = dot3f(m0, m1, m2, m0, m1, m2);
+        cov1 = dot3f(m0, m1, m2, m3, m4, m5);
+        cov2 = dot3f(m0, m1, m2, m6, m7, m8);
+        cov3 = dot3f(m3, m4, m5, m3, m4, m5);
+        cov4 = dot3f(m3, m4, m5, m6, m7, m8);
+        cov5 = dot3f(m6, m7, m8, m6, m7, m8);
+        if (reg_sums) {
+            reg_o = 1.0f / (1.0f + __expf(-opac));
+            reg_s = (__expf(s0) + __expf(s1)) + __expf(s2);
+        }
+    }
+    if (reg_sums) {  // block reduction of the two regulariser sums -> one double atomic each
+        for (int off = 32; off > 0; off >>= 1) {
+            reg_o += __shfl_down(reg_o, off);
+            reg_s += __shfl_down(reg_s, off);
+        }
+        int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[w] = reg_o; red[4 + w] = reg_s; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&reg_sums[0], (double)((red[0] + red[1]) + (red[2] + red[3])));
+            atomicAdd(&reg_sums[1], (double)((red[4] + red[5]) + (red[6] + red[7])));
+        }
+    }
+    if (!active) return;
+
+    for (int c = 0; c < C; ++c) {
+        const float* o = cam + c * CAM_STRIDE;
+        const float R00 = o[0], R01 = o[1], R02 = o[2], t0 = o[3];
+        const float R10 = o[4], R11 = o[5], R12 = o[6], t1 = o[7];
+        const float R20 = o[8], R21 = o[9], R22 = o[10], t2 = o[11];
+        const int64_t pid = (int64_t)c * N + g;
+        float x = dot3f(R00, R01, R02, mx, my, mz) + t0;
+        float y = dot3f(R10, R11, R12, mx, my, mz) + t1;
+        float z = dot3f(R20, R21, R22, mx, my, mz) + t2;
+        bool valid = !(z < near_plane || z > far_plane);
+        float m2x = 0, m2y = 0, ca = 0, cb = 0, cc = 0, radius = 0;
+        if (valid) {
+            // T = R * cov ; covc = T * R^T (upper)
+            float T0 = dot3f(R00, R01, R02, cov0, cov1, cov2), T1 = dot3f(R00, R01, R02, cov1, cov3, cov4),
+                  T2 = dot3f(R00, R01, R02, cov2, cov4, cov5);
+            float T3 = dot3f(R10, R11, R12, cov0, cov1, cov2), T4 = dot3f(R10, R11, R12, cov1, cov3, cov4),
+                  T5 = dot3f(R10, R11, R12, cov2, cov4, cov5);
+            float T6 = dot3f(R20, R21, R22, cov0, cov1, cov2), T7 = dot3f(R20, R21, R22, cov1, cov3, cov4),
+                  T8 = dot3f(R20, R21, R22, cov2, cov4, cov5);
+            float c0 = dot3f(T0, T1, T2, R00, R01, R02);
+            float c1 = dot3f(T0, T1, T2, R10, R11, R12);
+            float c2 = dot3f(T0, T1, T2, R20, R21, R22);
+            float c3 = dot3f(T3, T4, T5, R10, R11, R12);
+            float c4 = dot3f(T3, T4, T5, R20, R21, R22);
+            float c5 = dot3f(T6, T7, T8, R20, R21, R22);
+            const float fx = o[12], fy = o[13], cx = o[14], cy = o[15];
+            float rz = 1.0f / z;
+            float rz2 = rz * rz;
+            float xr = x * rz, yr = y * rz;
+            float tx = z * fminf(o[16], fmaxf(-o[17], xr));
+            float ty = z * fminf(o[18], fmaxf(-o[19], yr));
+            float a = fx * rz, cj = -(fx * tx) * rz2;
+            float b = fy * rz, d = -(fy * ty) * rz2;
+            float t0x = a * c0 + cj * c2;
+            float t0y = a * c1 + cj * c4;
+            float t0z = a * c2 + cj * c5;
+            float t1y = b * c3 + d * c4;
+            float t1z = b * c4 + d * c5;
+            float c00 = t0x * a + t0z * cj;
+            float c01 = t0y * b + t0z * d;
+            float c11 = t1y * b + t1z * d;
+            m2x = (fx * x) * rz + cx;
+            m2y = (fy * y) * rz + cy;
+            c00 += eps2d; c11 += eps2d;
+            float det = c00 * c11 - c01 * c01;
+            if (det <= 0.0f) valid = false;
+            else {
+                float inv_det = 1.0f / det;
+                ca = c11 * inv_det; cb = -c01 * inv_det; cc = c00 * inv_det;
+                float bb = 0.5f * (c00 + c11);
+                float v1 = bb + sqrtf(fmaxf(0.1f, bb * bb - det));
+                radius = ceilf(3.0f * sqrtf(v1));
+                if (radius <= radius_clip) valid = false;
+                else if (m2x + radius <= 0.0f || m2x - radius >= (float)W || m2y + radius <= 0.0f ||
+                         m2y - radius >= (float)H)
+                    valid = false;
+            }
+        }
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        int ntiles = 0;
+        if (valid) {
+            // SH colour (degree 1) + clamp_min(c + 0.5, 0)
+            float dx = mx - o[20], dy = my - o[21], dz = mz - o[22];
+            float inorm = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+            dx *= inorm; dy *= inorm; dz *= inorm;
+            float col[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float r = SH_C0 * k[ch];
+                r = r + SH_C1 * ((-dy * k[3 + ch] + dz * k[6 + ch]) - dx * k[9 + ch]);
+                r = r + 0.5f;
+                col[ch] = r < 0.0f ? 0.0f : r;
+            }
+            // tile rectangle (isect_tiles pass 1)
+            float tile_radius = radius / (float)tile_size;
+            float tile_x = m2x / (float)tile_size, tile_y = m2y / (float)tile_size;
+            int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
+            int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
+            int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
+            int y1 = tile_clampi(ceilf(tile_y + tile_radius), tile_h);
+            ntiles = (y1 - y0) * (x1 - x0);
+            r0 = make_float4(m2x, m2y, opac, ca);
+            r1 = make_float4(cb, cc, col[0], col[1]);
+            r2 = make_float4(col[2], z, __int_as_float((int)radius), 0.0f);
+        }
+        splats[pid * 3 + 0] = r0;
+        splats[pid * 3 + 1] = r1;
+        splats[pid * 3 + 2] = r2;
+        tiles_per_gauss[pid] = ntiles;
+    }
+}
+
+ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, const float* means,
+                                   const float* quats, const float* scales, const float* opacities,
+                                   const float* sh, int sh_stride, const float* viewmats, const float* Ks,
+                                   const float* campos, int width, int height, int tile_size, float eps2d,
+                                   float near_plane, float far_plane, float radius_clip, float* splats,
+                                   int32_t* tiles_per_gauss, double* reg_sums) {
+    ARG_CHECK(ctx && N >= 0 && C > 0 && C <= 1024 && sh_stride >= 12 && width > 0 && height > 0 && tile_size > 0);
+    ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
+    if (N == 0) return ST3R_OK;
+    int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ceil_div(N, 256)), block(256);
+    size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
+    hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
+                       viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
+                       radius_clip, (float4*)splats, tiles_per_gauss, reg_sums);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}

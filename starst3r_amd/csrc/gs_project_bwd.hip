@@ -1,0 +1,253 @@
+// K1-bwd: backward of projection + SH colour, one thread per Gaussian looping over the
+// cameras.  The per-camera gradients of the world mean and world covariance are summed in
+// registers, the quaternion/scale VJP runs once per Gaussian, and the 23 gradients are
+// written exactly once -- no atomics, no read-modify-write of the gradient buffer.
+//
+// Replaces gsplat fully_fused_projection_packed_bwd + spherical_harmonics bwd (autograd
+// through starster/gs.py:76-87 from loss.backward(), starster/gs.py:153) and folds in the
+// gradients of the two regularisers of starster/gs.py:132-134.
+#include "common.h"
+
+#define CAM_STRIDE 32
+#define SH_C0 0.2820947917738781f
+#define SH_C1 0.48860251190292f
+
+__global__ __launch_bounds__(256) void k_project_sh_bwd(
+    int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ sh,
+    int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
+    const float* __restrict__ campos, int W, int H, float eps2d, const float4* __restrict__ splats,
+    const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads) {
+    extern __shared__ float cam[];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float* o = cam + c * CAM_STRIDE;
+        const float* V = viewmats + 16 * c;
+        for (int k = 0; k < 12; ++k) o[k] = V[k];
+        const float* K = Ks + 9 * c;
+        float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+        o[12] = fx; o[13] = fy; o[14] = cx; o[15] = cy;
+        float tan_fovx = 0.5f * (float)W / fx;
+        float tan_fovy = 0.5f * (float)H / fy;
+        o[16] = ((float)W - cx) / fx + 0.3f * tan_fovx;
+        o[17] = cx / fx + 0.3f * tan_fovx;
+        o[18] = ((float)H - cy) / fy + 0.3f * tan_fovy;
+        o[19] = cy / fy + 0.3f * tan_fovy;
+        o[20] = campos[3 * c]; o[21] = campos[3 * c + 1]; o[22] = campos[3 * c + 2];
+    }
+    __syncthreads();
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+
+    const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+    const float opac = opacities[g];
+    float qw = quats[4 * g], qx = quats[4 * g + 1], qy = quats[4 * g + 2], qz = quats[4 * g + 3];
+    const float s0 = scales[3 * g], s1 = scales[3 * g + 1], s2 = scales[3 * g + 2];
+    float k[12];
+    const float* kp = sh + (int64_t)g * sh_stride;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) k[i] = kp[i];
+    const float inv_norm = 1.0f / sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+    qw *= inv_norm; qx *= inv_norm; qy *= inv_norm; qz *= inv_norm;
+    float Rq[9];
+    {
+        float x2 = qx * qx, y2 = qy * qy, z2 = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz;
+        float wx = qw * qx, wy = qw * qy, wz = qw * qz;
+        Rq[0] = 1.0f - 2.0f * (y2 + z2); Rq[1] = 2.0f * (xy - wz); Rq[2] = 2.0f * (xz + wy);
+        Rq[3] = 2.0f * (xy + wz); Rq[4] = 1.0f - 2.0f * (x2 + z2); Rq[5] = 2.0f * (yz - wx);
+        Rq[6] = 2.0f * (xz - wy); Rq[7] = 2.0f * (yz + wx); Rq[8] = 1.0f - 2.0f * (x2 + y2);
+    }
+    const float sc[3] = {s0, s1, s2};
+    float M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[i * 3 + j] = Rq[i * 3 + j] * sc[j];
+    float cov[6];
+    cov[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    cov[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    cov[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    cov[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    cov[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    cov[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+
+    float v_mean[3] = {0, 0, 0};
+    float vSw[6] = {0, 0, 0, 0, 0, 0};  // symmetric world-covariance gradient: 00 01 02 11 12 22
+    float v_k[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v_k[i] = 0.f;
+    float v_opac = 0.f;
+
+    for (int c = 0; c < C; ++c) {
+        const int64_t pid = (int64_t)c * N + g;
+        const float4 r2 = splats[pid * 3 + 2];
+        if (__float_as_int(r2.z) <= 0) continue;  // culled pair
+        const float4 r0 = splats[pid * 3 + 0];
+        const float4 r1 = splats[pid * 3 + 1];
+        const float4 g0 = v_splats[pid * 3 + 0];
+        const float4 g1 = v_splats[pid * 3 + 1];
+        const float4 g2 = v_splats[pid * 3 + 2];
+        const float* o = cam + c * CAM_STRIDE;
+        const float R[9] = {o[0], o[1], o[2], o[4], o[5], o[6], o[8], o[9], o[10]};
+        v_opac += g0.z;
+        // ---- SH backward ----
+        {
+            float dx = mx - o[20], dy = my - o[21], dz = mz - o[22];
+            float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+            float inrm = 1.0f / nrm;
+            float ux = dx * inrm, uy = dy * inrm, uz = dz * inrm;
+            const float vcol[3] = {g2.x, g2.y, g2.z};
+            const float colf[3] = {r1.z, r1.w, r2.x};
+            float vdx = 0.f, vdy = 0.f, vdz = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                // clamp_min(c+0.5, 0) passes gradient where the pre-clamp value is >= 0;
+                // a clamped colour is stored as exactly 0 and a positive value is not clamped
+                float pre = SH_C0 * k[ch] + SH_C1 * ((-uy * k[3 + ch] + uz * k[6 + ch]) - ux * k[9 + ch]) + 0.5f;
+                float vc = (colf[ch] > 0.0f || pre >= 0.0f) ? vcol[ch] : 0.0f;
+                v_k[ch] += SH_C0 * vc;
+                v_k[3 + ch] += -SH_C1 * uy * vc;
+                v_k[6 + ch] += SH_C1 * uz * vc;
+                v_k[9 + ch] += -SH_C1 * ux * vc;
+                vdx += -SH_C1 * k[9 + ch] * vc;
+                vdy += -SH_C1 * k[3 + ch] * vc;
+                vdz += SH_C1 * k[6 + ch] * vc;
+            }
+            float dotp = vdx * ux + vdy * uy + vdz * uz;
+            v_mean[0] += (vdx - dotp * ux) * inrm;
+            v_mean[1] += (vdy - dotp * uy) * inrm;
+            v_mean[2] += (vdz - dotp * uz) * inrm;
+        }
+        // ---- projection backward ----
+        const float x = R[0] * mx + R[1] * my + R[2] * mz + o[3];
+        const float y = R[3] * mx + R[4] * my + R[5] * mz + o[7];
+        const float z = R[6] * mx + R[7] * my + R[8] * mz + o[11];
+        // camera covariance S = R cov R^T (symmetric, 6 unique)
+        float T[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T[i * 3 + 0] = R[i * 3] * cov[0] + R[i * 3 + 1] * cov[1] + R[i * 3 + 2] * cov[2];
+            T[i * 3 + 1] = R[i * 3] * cov[1] + R[i * 3 + 1] * cov[3] + R[i * 3 + 2] * cov[4];
+            T[i * 3 + 2] = R[i * 3] * cov[2] + R[i * 3 + 1] * cov[4] + R[i * 3 + 2] * cov[5];
+        }
+        const float S00 = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
+        const float S01 = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
+        const float S02 = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+        const float S11 = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
+        const float S12 = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+        const float S22 = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+        const float fx = o[12], fy = o[13];
+        const float rz = 1.0f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+        const float xr = x * rz, yr = y * rz;
+        const bool x_in = (xr <= o[16]) && (xr >= -o[17]);
+        const bool y_in = (yr <= o[18]) && (yr >= -o[19]);
+        const float tx = z * fminf(o[16], fmaxf(-o[17], xr));
+        const float ty = z * fminf(o[18], fmaxf(-o[19], yr));
+        const float a = fx * rz, cj = -fx * tx * rz2, b = fy * rz, d = -fy * ty * rz2;
+        // conic -> cov2d
+        const float A = r0.w, B = r1.x, Cc = r1.y;
+        const float vA = g0.w, vB = 0.5f * g1.x, vC = g1.y;
+        const float X00 = A * vA + B * vB, X01 = A * vB + B * vC;
+        const float X10 = B * vA + Cc * vB, X11 = B * vB + Cc * vC;
+        const float G00 = -(X00 * A + X01 * B);
+        const float G01 = -0.5f * ((X00 * B + X01 * Cc) + (X10 * A + X11 * B));
+        const float G11 = -(X10 * B + X11 * Cc);
+        // GJ = G * J, J = [[a,0,cj],[0,b,d]]
+        const float GJ00 = G00 * a, GJ01 = G01 * b, GJ02 = G00 * cj + G01 * d;
+        const float GJ10 = G01 * a, GJ11 = G11 * b, GJ12 = G01 * cj + G11 * d;
+        // v_S = J^T G J
+        const float vS00 = a * GJ00, vS01 = a * GJ01, vS02 = a * GJ02;
+        const float vS11 = b * GJ11, vS12 = b * GJ12, vS22 = cj * GJ02 + d * GJ12;
+        // v_J = 2 G J S
+        const float vJ00 = 2.0f * (GJ00 * S00 + GJ01 * S01 + GJ02 * S02);
+        const float vJ02 = 2.0f * (GJ00 * S02 + GJ01 * S12 + GJ02 * S22);
+        const float vJ11 = 2.0f * (GJ10 * S01 + GJ11 * S11 + GJ12 * S12);
+        const float vJ12 = 2.0f * (GJ10 * S02 + GJ11 * S12 + GJ12 * S22);
+        const float vm2x = g0.x, vm2y = g0.y;
+        float vpx = fx * rz * vm2x;
+        float vpy = fy * rz * vm2y;
+        float vpz = -(fx * x * vm2x + fy * y * vm2y) * rz2;
+        vpz += -fx * rz2 * vJ00 - fy * rz2 * vJ11;
+        if (x_in) { vpx += -fx * rz2 * vJ02; vpz += 2.0f * fx * x * rz3 * vJ02; }
+        else { vpz += fx * tx * rz3 * vJ02; }
+        if (y_in) { vpy += -fy * rz2 * vJ12; vpz += 2.0f * fy * y * rz3 * vJ12; }
+        else { vpz += fy * ty * rz3 * vJ12; }
+        v_mean[0] += R[0] * vpx + R[3] * vpy + R[6] * vpz;
+        v_mean[1] += R[1] * vpx + R[4] * vpy + R[7] * vpz;
+        v_mean[2] += R[2] * vpx + R[5] * vpy + R[8] * vpz;
+        // v_Sw += R^T vS R   (U = vS * R, then R^T * U; keep the 6 unique entries)
+        float U[9];
+        const float vSm[9] = {vS00, vS01, vS02, vS01, vS11, vS12, vS02, vS12, vS22};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                U[i * 3 + j] = vSm[i * 3] * R[j] + vSm[i * 3 + 1] * R[3 + j] + vSm[i * 3 + 2] * R[6 + j];
+        vSw[0] += R[0] * U[0] + R[3] * U[3] + R[6] * U[6];
+        vSw[1] += R[0] * U[1] + R[3] * U[4] + R[6] * U[7];
+        vSw[2] += R[0] * U[2] + R[3] * U[5] + R[6] * U[8];
+        vSw[3] += R[1] * U[1] + R[4] * U[4] + R[7] * U[7];
+        vSw[4] += R[1] * U[2] + R[4] * U[5] + R[7] * U[8];
+        vSw[5] += R[2] * U[2] + R[5] * U[5] + R[8] * U[8];
+    }
+
+    // ---- covariance -> (quat, scale), once per Gaussian ----
+    // S_w = M M^T, M = Rq diag(s):  v_M = 2 vSw M
+    const float W9[9] = {vSw[0], vSw[1], vSw[2], vSw[1], vSw[3], vSw[4], vSw[2], vSw[4], vSw[5]};
+    float vM[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            vM[r * 3 + s] = 2.0f * (W9[r * 3] * M[s] + W9[r * 3 + 1] * M[3 + s] + W9[r * 3 + 2] * M[6 + s]);
+    float v_scale[3], vR[9];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        v_scale[s] = Rq[s] * vM[s] + Rq[3 + s] * vM[3 + s] + Rq[6 + s] * vM[6 + s];
+        vR[s] = vM[s] * sc[s]; vR[3 + s] = vM[3 + s] * sc[s]; vR[6 + s] = vM[6 + s] * sc[s];
+    }
+    // vR[i*3+j] = d/dRq[i][j]
+    float vq0 = 2.0f * (qx * (vR[7] - vR[5]) + qy * (vR[2] - vR[6]) + qz * (vR[3] - vR[1]));
+    float vq1 = 2.0f * (-2.0f * qx * (vR[4] + vR[8]) + qy * (vR[3] + vR[1]) + qz * (vR[6] + vR[2]) + qw * (vR[7] - vR[5]));
+    float vq2 = 2.0f * (qx * (vR[3] + vR[1]) - 2.0f * qy * (vR[0] + vR[8]) + qz * (vR[7] + vR[5]) + qw * (vR[2] - vR[6]));
+    float vq3 = 2.0f * (qx * (vR[6] + vR[2]) + qy * (vR[7] + vR[5]) - 2.0f * qz * (vR[0] + vR[4]) + qw * (vR[3] - vR[1]));
+    const float dq = vq0 * qw + vq1 * qx + vq2 * qy + vq3 * qz;
+    vq0 = (vq0 - dq * qw) * inv_norm; vq1 = (vq1 - dq * qx) * inv_norm;
+    vq2 = (vq2 - dq * qy) * inv_norm; vq3 = (vq3 - dq * qz) * inv_norm;
+
+    // ---- regularisers: k_o * d sigmoid(o), k_s * d exp(s) ----
+    const float sg = 1.0f / (1.0f + __expf(-opac));
+    v_opac += reg_o_k * sg * (1.0f - sg);
+    v_scale[0] += reg_s_k * __expf(s0);
+    v_scale[1] += reg_s_k * __expf(s1);
+    v_scale[2] += reg_s_k * __expf(s2);
+
+    const int64_t Nl = N;
+    float* gm = grads; float* gq = grads + 3 * Nl; float* gs = grads + 7 * Nl;
+    float* go = grads + 10 * Nl; float* gsh = grads + 11 * Nl;
+    gm[3 * g] = v_mean[0]; gm[3 * g + 1] = v_mean[1]; gm[3 * g + 2] = v_mean[2];
+    gq[4 * g] = vq0; gq[4 * g + 1] = vq1; gq[4 * g + 2] = vq2; gq[4 * g + 3] = vq3;
+    gs[3 * g] = v_scale[0]; gs[3 * g + 1] = v_scale[1]; gs[3 * g + 2] = v_scale[2];
+    go[g] = v_opac;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gsh[(int64_t)g * 12 + i] = v_k[i];
+}
+
+ST3R_EXPORT int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means,
+                                       const float* quats, const float* scales, const float* opacities,
+                                       const float* sh, int sh_stride, const float* viewmats, const float* Ks,
+                                       const float* campos, int width, int height, float eps2d,
+                                       const float* splats, const float* v_splats, float reg_views,
+                                       float opac_fac, float scale_fac, float* grads) {
+    ARG_CHECK(ctx && N >= 0 && C > 0 && C <= 1024 && sh_stride >= 12);
+    ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && v_splats && grads);
+    if (N == 0) return ST3R_OK;
+    hipStream_t s = (hipStream_t)stream;
+    float reg_o_k = reg_views * opac_fac / (float)N;
+    float reg_s_k = reg_views * scale_fac / (3.0f * (float)N);
+    size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
+    hipLaunchKernelGGL(k_project_sh_bwd, dim3(ceil_div(N, 256)), dim3(256), shmem, s, N, C, means, quats, scales,
+                       opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d, (const float4*)splats,
+                       (const float4*)v_splats, reg_o_k, reg_s_k, grads);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}

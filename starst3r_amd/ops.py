@@ -1,0 +1,245 @@
+"""torch-tensor front-end of the C ABI (include/st3r.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function below hands
+raw device pointers to libst3r_hip.so.  All tensors must live on the context's GPU.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+SPLAT = 12
+TILE = 16
+
+
+class Context:
+    """One st3r_ctx per (process, GPU): owns the grow-only scratch arena."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.St3rError(f"the st3r hot path needs a GPU device, got {device!r} (no CPU fallback)")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self._h = C.c_void_p()
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib().st3r_ctx_create(idx, C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def arena_bytes(self):
+        return int(_lib.lib().st3r_ctx_arena_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.lib().st3r_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def get_context(device):
+    d = torch.device(device)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    if idx not in _contexts:
+        _contexts[idx] = Context(torch.device("cuda", idx))
+    return _contexts[idx]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError(f"expected contiguous cuda {dtype} tensor, got {t.dtype} contiguous={t.is_contiguous()} "
+                         f"device={t.device}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _f(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def tile_grid(W, H):
+    return math.ceil(W / TILE), math.ceil(H / TILE)
+
+
+def camera_positions(viewmats):
+    """inverse(viewmats)[:, :3, 3] (gsplat: camtoworlds = torch.inverse(viewmats))."""
+    return torch.inverse(viewmats)[:, :3, 3].contiguous()
+
+
+def sh_stride_of(sh):
+    return int(sh.numel() // sh.shape[0])
+
+
+def project_sh(ctx, means, quats, scales, opacities, sh, viewmats, Ks, campos, W, H, reg_sums=None,
+               eps2d=0.3, near=0.01, far=1e10, radius_clip=0.0):
+    N, Cn = means.shape[0], viewmats.shape[0]
+    splats = torch.empty((Cn * N, SPLAT), dtype=torch.float32, device=means.device)
+    tiles = torch.empty((Cn * N,), dtype=torch.int32, device=means.device)
+    _lib.check(_lib.lib().st3r_gs_project_sh(
+        ctx.handle, _stream(), N, Cn, _p(means), _p(quats), _p(scales), _p(opacities), _p(sh), sh_stride_of(sh),
+        _p(viewmats), _p(Ks), _p(campos), W, H, TILE, eps2d, near, far, radius_clip, _p(splats),
+        _p(tiles, torch.int32), _p(reg_sums, torch.float64)))
+    return splats, tiles
+
+
+def isect(ctx, splats, tiles, N, Cn, W, H):
+    tw, th = tile_grid(W, H)
+    cum = torch.empty_like(tiles)
+    n = C.c_int64(0)
+    _lib.check(_lib.lib().st3r_gs_isect_scan(ctx.handle, _stream(), N * Cn, _p(tiles, torch.int32),
+                                             _p(cum, torch.int32), C.byref(n)))
+    n = n.value
+    ids = torch.empty((n,), dtype=torch.int64, device=splats.device)
+    flat = torch.empty((n,), dtype=torch.int32, device=splats.device)
+    _lib.check(_lib.lib().st3r_gs_isect_emit(ctx.handle, _stream(), N, Cn, _p(splats), _p(cum, torch.int32), TILE, tw,
+                                             th, n, _p(ids, torch.int64), _p(flat, torch.int32)))
+    return cum, ids, flat
+
+
+def sort_pairs(ctx, ids, flat, end_bit):
+    ids_in, flat_in = ids.clone(), flat.clone()
+    ids_out, flat_out = torch.empty_like(ids), torch.empty_like(flat)
+    _lib.check(_lib.lib().st3r_gs_sort(ctx.handle, _stream(), ids.numel(), end_bit, _p(ids_in, torch.int64),
+                                       _p(flat_in, torch.int32), _p(ids_out, torch.int64),
+                                       _p(flat_out, torch.int32)))
+    return ids_out, flat_out
+
+
+def offsets(ctx, ids_sorted, Cn, W, H):
+    tw, th = tile_grid(W, H)
+    off = torch.empty((Cn, th, tw), dtype=torch.int32, device=ids_sorted.device)
+    _lib.check(_lib.lib().st3r_gs_offsets(ctx.handle, _stream(), ids_sorted.numel(), _p(ids_sorted, torch.int64), Cn,
+                                          tw, th, _p(off, torch.int32)))
+    return off
+
+
+def blend_fwd(ctx, splats, off, flat, Cn, W, H):
+    tw, th = tile_grid(W, H)
+    dev = splats.device
+    rgb = torch.empty((Cn, H, W, 3), dtype=torch.float32, device=dev)
+    alpha = torch.empty((Cn, H, W, 1), dtype=torch.float32, device=dev)
+    last = torch.empty((Cn, H, W), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().st3r_gs_blend_fwd(ctx.handle, _stream(), Cn, W, H, TILE, tw, th, _p(splats),
+                                            _p(off, torch.int32), _p(flat, torch.int32), flat.numel(), _p(rgb),
+                                            _p(alpha), _p(last, torch.int32)))
+    return rgb, alpha, last
+
+
+def blend_bwd(ctx, splats, off, flat, alpha, last, v_rgb, v_alpha, Cn, W, H):
+    tw, th = tile_grid(W, H)
+    v_splats = torch.empty_like(splats)
+    _lib.check(_lib.lib().st3r_gs_blend_bwd(ctx.handle, _stream(), Cn, W, H, TILE, tw, th, _p(splats),
+                                            _p(off, torch.int32), _p(flat, torch.int32), flat.numel(), _p(alpha),
+                                            _p(last, torch.int32), _p(v_rgb), _p(v_alpha), splats.shape[0],
+                                            _p(v_splats)))
+    return v_splats
+
+
+def project_sh_bwd(ctx, means, quats, scales, opacities, sh, viewmats, Ks, campos, W, H, splats, v_splats,
+                   reg_views=0.0, opac_fac=0.0, scale_fac=0.0, eps2d=0.3):
+    N, Cn = means.shape[0], viewmats.shape[0]
+    grads = torch.empty((23 * N,), dtype=torch.float32, device=means.device)
+    _lib.check(_lib.lib().st3r_gs_project_sh_bwd(
+        ctx.handle, _stream(), N, Cn, _p(means), _p(quats), _p(scales), _p(opacities), _p(sh), sh_stride_of(sh),
+        _p(viewmats), _p(Ks), _p(campos), W, H, eps2d, _p(splats), _p(v_splats), reg_views, opac_fac, scale_fac,
+        _p(grads)))
+    return grads
+
+
+def split_grads(grads, N):
+    """views into the block layout means[3N] quats[4N] scales[3N] opacities[N] sh4[12N]"""
+    return dict(means=grads[0:3 * N].view(N, 3), quats=grads[3 * N:7 * N].view(N, 4),
+                scales=grads[7 * N:10 * N].view(N, 3), opacities=grads[10 * N:11 * N],
+                sh=grads[11 * N:23 * N].view(N, 4, 3))
+
+
+def loss_l1_ssim(ctx, render, gt, w_l1, w_ssim, want_grad=True):
+    Cn, H, W = render.shape[0], render.shape[1], render.shape[2]
+    sums = torch.empty((Cn, 2), dtype=torch.float64, device=render.device)
+    v = torch.empty_like(render) if want_grad else None
+    _lib.check(_lib.lib().st3r_loss_l1_ssim(ctx.handle, _stream(), Cn, H, W, _p(render), _p(gt), w_l1, w_ssim,
+                                            _p(sums, torch.float64), _p(v)))
+    return sums, v
+
+
+def adam_step(ctx, params, grads, m, v, lr, b1, b2, eps, step):
+    """params: dict with means, quats, scales, opacities, shN (updated in place)."""
+    N = params["means"].shape[0]
+    sh = params["shN"]
+    _lib.check(_lib.lib().st3r_adam_step(ctx.handle, _stream(), N, _p(params["means"]), _p(params["quats"]),
+                                         _p(params["scales"]), _p(params["opacities"]), _p(sh), sh_stride_of(sh),
+                                         _p(grads), _p(m), _p(v), lr, b1, b2, eps, step))
+
+
+def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fac, scale_fac, grads, loss_out):
+    N, Cn = params["means"].shape[0], viewmats.shape[0]
+    sh = params["shN"]
+    stats = (C.c_int64 * 4)()
+    _lib.check(_lib.lib().st3r_gs_train_fwd_bwd(
+        ctx.handle, _stream(), N, Cn, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
+        _p(params["opacities"]), _p(sh), sh_stride_of(sh), _p(viewmats), _p(Ks), _p(campos), _p(gt), W, H, ssim_fac,
+        opac_fac, scale_fac, _p(grads), _p(loss_out), stats))
+    return dict(n_isects=int(stats[1]), arena_bytes=int(stats[2]))
+
+
+def render(ctx, params, viewmats, Ks, campos, W, H):
+    N, Cn = params["means"].shape[0], viewmats.shape[0]
+    sh = params["shN"]
+    dev = params["means"].device
+    rgb = torch.empty((Cn, H, W, 3), dtype=torch.float32, device=dev)
+    alpha = torch.empty((Cn, H, W, 1), dtype=torch.float32, device=dev)
+    stats = (C.c_int64 * 4)()
+    _lib.check(_lib.lib().st3r_gs_render(
+        ctx.handle, _stream(), N, Cn, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
+        _p(params["opacities"]), _p(sh), sh_stride_of(sh), _p(viewmats), _p(Ks), _p(campos), W, H, _p(rgb), _p(alpha),
+        stats))
+    return rgb, alpha, dict(n_isects=int(stats[1]))
+
+
+def rasterization(ctx, means, quats, scales, opacities, colors, viewmats, Ks, width, height, want_info=True):
+    """Stage-by-stage rasterization with caller-owned outputs and the gsplat-style `info` dict
+    (packed arrays, reference call: starster/gs.py:76-87).  Used by Scene.render_3dgs and tests."""
+    N, Cn = means.shape[0], viewmats.shape[0]
+    W, H = width, height
+    campos = camera_positions(viewmats)
+    splats, tiles = project_sh(ctx, means, quats, scales, opacities, colors, viewmats, Ks, campos, W, H)
+    cum, ids, flat = isect(ctx, splats, tiles, N, Cn, W, H)
+    tw, th = tile_grid(W, H)
+    end_bit = 32 + (tw * th).bit_length() + Cn.bit_length()
+    ids_s, flat_s = sort_pairs(ctx, ids, flat, end_bit)
+    off = offsets(ctx, ids_s, Cn, W, H)
+    rgb, alpha, last = blend_fwd(ctx, splats, off, flat_s, Cn, W, H)
+    info = None
+    if want_info:
+        radii_dense = splats[:, 10].view(torch.int32)
+        vis = radii_dense > 0
+        pid = torch.nonzero(vis).reshape(-1)
+        packed_of_dense = torch.cumsum(vis.to(torch.int64), 0) - 1
+        sp = splats[pid]
+        info = dict(
+            camera_ids=torch.div(pid, N, rounding_mode="floor").to(torch.int32), gaussian_ids=(pid % N).to(torch.int32),
+            radii=radii_dense[pid], means2d=sp[:, 0:2], depths=sp[:, 9], conics=sp[:, 3:6], opacities=sp[:, 2],
+            colors=sp[:, 6:9], tile_width=tw, tile_height=th, tiles_per_gauss=tiles[pid], isect_ids=ids_s,
+            flatten_ids=packed_of_dense[flat_s.long()].to(torch.int32), isect_offsets=off, width=W, height=H,
+            tile_size=TILE, n_cameras=Cn,
+            # dense-id extras used by the backward / tests
+            _splats=splats, _flatten_ids_dense=flat_s, _last_ids=last, _isect_ids_unsorted=ids,
+            _flatten_ids_dense_unsorted=flat, _packed_of_dense=packed_of_dense, _campos=campos)
+    return rgb, alpha, info
