@@ -51,6 +51,11 @@ def lib():
             raise St3rError(
                 f"{LIB_PATH} is missing: build it with `python -m starst3r_amd.build` "
                 "(there is no CPU fallback for the hot path)")
+        # torch bundles its own HIP runtime; it must be the one already resident when our library's
+        # libamdhip64 dependency is resolved, otherwise two runtimes end up in one process
+        import torch  # noqa: F401
+        if torch.cuda.is_available():
+            torch.cuda.init()
         L = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
             float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
             float inrm = 1.0f / nrm;
             float ux = dx * inrm, uy = dy * inrm, uz = dz * inrm;
-            const float vcol[3] = {g2.x, g2.y, g2.z};
+            const float vcol[3] = {g1.z, g1.w, g2.x};
             const float colf[3] = {r1.z, r1.w, r2.x};
             float vdx = 0.f, vdy = 0.f, vdz = 0.f;
 #pragma unroll
