@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Headline benchmark: 3DGS train iters/sec @ 1M Gaussians, 8 x 1080p views (BASELINE.json).
+
+One "step" = one iteration of the reference loop starster/gs.py:143-161: render every view,
+L1+SSIM loss (+ regularisers), backward, Adam.  Workload = SYNTH-1M of SURVEY.md 8(d)
+(BASELINE.json configs[2]); synthetic data, random-init parameters.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the 8 views are sharded 8/N per rank (strong scaling of the named config), Gaussians
+and Adam state are replicated, one RCCL sum-all-reduce of the [23*N] gradient buffer per step.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     -- dominant kernel: algorithmic bytes per launch / mean launch time, the launch
+                  time measured with HIP events on the launch stream inside the timed region
+  cpu_baseline -- the C oracle (oracle/gs_oracle.c, a "port") timed on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X datasheet HBM3E peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-div", type=int, default=2,
+                    help="CPU baseline sample: 1 view at (W/div)x(H/div), N/div^2 gaussians, same density")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, V, I, P, Ct, keybits):
+    """algorithmic HBM bytes per iteration, per stage (C local views)."""
+    passes = math.ceil(keybits / 8)
+    return {
+        "project": 92 * N + 44 * V,
+        "scan": 8 * V,
+        "emit": 8 * V + 12 * I,
+        "sort": 24 * passes * I,
+        "offsets": 8 * I + 4 * Ct,
+        "blend_fwd": 40 * I + 20 * P,
+        "loss": 36 * P,
+        "blend_bwd": 112 * I + 20 * P,
+        "project_bwd": 80 * V + 92 * N,
+        "adam": 644 * N,
+    }
+
+
+def make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device):
+    """GT = render of the jittered scene, clipped to [0,1]; produced on device."""
+    from starst3r_amd import synth
+    gt_g = synth.perturb_for_gt(g_np)
+    P = {k: torch.tensor(v, device=device) for k, v in gt_g.items()}
+    campos = ops.camera_positions(w2c)
+    rgb, _, _ = ops.render(ctx, P, w2c, Ks, campos, W, H)
+    return rgb.clamp_(0, 1).contiguous()
+
+
+def cpu_baseline(args):
+    """Time the C oracle (single thread) on a bounded sample and extrapolate to the metric's unit.
+    Sample: 1 view at (W/d)x(H/d) with N/d^2 Gaussians whose scales are multiplied by ... nothing:
+    the scene extent and camera are unchanged, focal scales with the image, so the per-pixel list
+    length drops by d^2 too; the extrapolation is therefore reported as measured-sample only."""
+    from oracle import build as ob
+    ob.build()
+    from oracle import gs_oracle as go
+    from starst3r_amd import synth
+    d = args.cpu_sample_div
+    W, H, N = args.width // d, args.height // d, args.gaussians // (d * d)
+    g, w2c, Ks = synth.make_scene(N, 1, W, H)
+    gt_g = synth.perturb_for_gt(g)
+    gt_img, _, _ = go.rasterization(gt_g["means"], gt_g["quats"], gt_g["scales"], gt_g["opacities"], gt_g["shN"], w2c,
+                                    Ks, W, H)
+    gt_img = np.clip(gt_img, 0, 1)
+    t0 = time.perf_counter()
+    rgb, alpha, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H)
+    _, _, v_rgb = go.l1_ssim(rgb[0], gt_img[0], 0.8, 0.2)
+    grads = go.rasterization_backward(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H,
+                                      meta, alpha, v_rgb[None])
+    p = g["means"].reshape(-1).copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    for _ in range(23 // 3 + 1):  # Adam over ~23 scalars per gaussian
+        go.adam(p, grads["means"].astype(np.float32).reshape(-1), m, v, 1e-3, 0.9, 0.999, 1e-8, 1)
+    t = time.perf_counter() - t0
+    # one full iteration = views x d^2 (pixels) samples of this size; d^2 more gaussians per pixel list too
+    scale = args.views * d * d
+    return {
+        "value": 1.0 / (t * scale), "unit": "iters/sec", "cores": 1, "kind": "port",
+        "sample": f"oracle/gs_oracle.c, 1 thread: 1 view {W}x{H}, {N} gaussians, fwd+loss+bwd+Adam took {t:.2f}s; "
+                  f"value = 1/(t*{scale}) i.e. scaled by views*{d * d} pixel area only (optimistic for the CPU: "
+                  f"the full scene also has {d * d}x more gaussians per pixel list)",
+        "sample_seconds": t,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from starst3r_amd import ops, synth
+    ctx = ops.get_context(device)
+
+    N, W, H = args.gaussians, args.width, args.height
+    assert args.views % world == 0, "views must divide evenly over the GPUs"
+    g_np, w2c_np, Ks_np = synth.make_scene(N, args.views, W, H)
+    views = list(range(rank, args.views, world))  # this rank's views
+    C_local = len(views)
+    P = {k: torch.tensor(v, device=device) for k, v in g_np.items()}
+    w2c = torch.tensor(w2c_np[views], device=device)
+    Ks = torch.tensor(Ks_np[views], device=device)
+    campos = ops.camera_positions(w2c)
+    gt = make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device)
+
+    grads = torch.empty(23 * N, device=device)
+    m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+    total = args.warmup + args.steps
+    losses = torch.zeros(total, device=device)
+    stats = {}
+
+    def step(it):
+        st = ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1])
+        if world > 1:
+            dist.all_reduce(grads)          # RCCL sum over ranks (views are sharded, loss is a sum over views)
+        ops.adam_step(ctx, P, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1)
+        return st
+
+    for it in range(args.warmup):
+        stats = step(it)
+    ops.set_profiling(ctx, True)
+    ops.stage_ms(ctx)  # reset
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.warmup, total):
+        stats = step(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stage = ops.stage_ms(ctx)
+    ops.set_profiling(ctx, False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        lt = losses.clone(); dist.all_reduce(lt); losses = lt
+    L = losses.cpu().numpy()
+
+    if rank == 0:
+        V, I = stats["n_visible"], stats["n_isects"]
+        P_px = C_local * H * W
+        tw, th = ops.tile_grid(W, H)
+        keybits = 32 + (tw * th).bit_length() + C_local.bit_length()
+        ab = algorithmic_bytes(N, V, I, P_px, C_local * tw * th, keybits)
+        per_stage = {k: (ms / max(n, 1)) for k, (ms, n) in stage.items()}
+        dom = max(per_stage, key=per_stage.get)
+        dom_ms = per_stage[dom]
+        achieved = ab[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        ms_per_step = dt / args.steps * 1e3
+        iter_bytes = sum(ab.values())
+        out = {
+            "metric": "3DGS train iters/sec @ 1M Gaussians, 8x1080p views",
+            "value": args.steps / dt, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"SYNTH-1M (BASELINE.json configs[2]): {N} gaussians, {args.views} views {W}x{H}, "
+                            f"3DGS train only; views sharded {C_local}/GPU, gaussians replicated",
+                "gaussians": N, "views": args.views, "width": W, "height": H, "views_per_gpu": C_local,
+                "parallelism": f"view-dp{world}", "n_visible_pairs": V, "n_isects": I, "sort_key_bits": keybits,
+                "mean_tiles_per_visible_gaussian": (I / V) if V else 0.0,
+                "mean_gaussians_per_tile": I / (C_local * tw * th),
+                "loss_first": float(L[0]), "loss_last": float(L[-1]),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": ab[dom], "launch_ms": dom_ms,
+                "whole_iter": {"algorithmic_bytes": iter_bytes,
+                               "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9,
+                               "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "stage_ms": per_stage,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

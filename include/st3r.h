@@ -62,14 +62,25 @@ int st3r_ctx_destroy(st3r_ctx* ctx);
 /* bytes currently held by the ctx arena (diagnostics) */
 int64_t st3r_ctx_arena_bytes(st3r_ctx* ctx);
 
+/* Per-stage timing with HIP events recorded on the caller's stream around every stage of the
+ * fused steps (no host synchronisation while enabled).  st3r_ctx_get_stage_ms synchronises
+ * the device, writes the accumulated milliseconds and sample counts of the ST3R_NUM_STAGES
+ * stages and resets them.  Stage order: project, scan, emit, sort, offsets, blend_fwd, loss,
+ * blend_bwd, project_bwd, adam (names from st3r_stage_name). */
+#define ST3R_NUM_STAGES 10
+int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
+int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* counts_out);
+const char* st3r_stage_name(int stage);
+
 /* ------------------------------------------------------------------------------------
  * Path C -- 3DGS rasterization stages (replace gsplat.rasterization, starster/gs.py:76-87)
  * ---------------------------------------------------------------------------------- */
 
 /* projection + degree-1 SH colour for every (camera, gaussian).  gsplat
  * fully_fused_projection + spherical_harmonics + clamp_min(c+0.5,0).
- * Also accumulates sum(sigmoid(opacities)) and sum(exp(scales)) into reg_sums[2]
- * (double, device, may be NULL) for the regularisers of starster/gs.py:132-134. */
+ * Also accumulates sum(sigmoid(opacities)), sum(exp(scales)) (the regularisers of
+ * starster/gs.py:132-134) and the number of visible pairs into reg_sums[3]
+ * (double, device, NOT zeroed here, may be NULL). */
 int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,
                        const float* scales, const float* opacities, const float* sh, int sh_stride,
                        const float* viewmats, const float* Ks, const float* campos, int width, int height,
@@ -137,7 +148,7 @@ int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quat
  *   grads   [23*N]  written (not accumulated)
  *   loss_out        device float; receives this rank's loss (sum over its views, regularisers
  *                   added reg_views times)
- *   stats_host[4]   optional host int64: n_visible_pairs (or -1), n_isects, arena bytes, 0
+ *   stats_host[4]   optional host int64: n_visible_pairs, n_isects, arena bytes, 0
  * The second half is an (optional) all-reduce of `grads` by the caller, then st3r_adam_step.
  * ---------------------------------------------------------------------------------- */
 int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,

@@ -20,6 +20,9 @@ SIGNATURES = {
     "st3r_ctx_create": [i32, C.POINTER(vp)],
     "st3r_ctx_destroy": [vp],
     "st3r_ctx_arena_bytes": [vp],
+    "st3r_ctx_set_profiling": [vp, i32],
+    "st3r_ctx_get_stage_ms": [vp, C.POINTER(f64), C.POINTER(i64)],
+    "st3r_stage_name": [i32],
     "st3r_gs_project_sh": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32,
                            vp, vp, vp],
     "st3r_gs_isect_scan": [vp, vp, i64, vp, vp, C.POINTER(i64)],
@@ -36,7 +39,7 @@ SIGNATURES = {
                               vp, C.POINTER(i64)],
     "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],
 }
-_RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_ctx_arena_bytes": i64}
+_RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_stage_name": C.c_char_p, "st3r_ctx_arena_bytes": i64}
 
 
 class St3rError(RuntimeError):

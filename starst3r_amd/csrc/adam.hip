@@ -63,6 +63,9 @@ ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means,
                                double lr, double beta1, double beta2, double eps, int step) {
     ARG_CHECK(ctx && N >= 0 && step >= 1 && sh_stride >= 12);
     ARG_CHECK(means && quats && scales && opacities && sh && grads && m && v);
-    return st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr,
-                          beta1, beta2, eps, step);
+    st3r_prof_begin(ctx, (hipStream_t)stream, STG_ADAM);
+    int rc = st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr,
+                            beta1, beta2, eps, step);
+    st3r_prof_end(ctx, (hipStream_t)stream, STG_ADAM);
+    return rc;
 }

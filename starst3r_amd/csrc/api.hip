@@ -38,6 +38,10 @@ ST3R_EXPORT int st3r_ctx_destroy(st3r_ctx* ctx) {
     for (int i = 0; i < SLOT_COUNT; ++i)
         if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->prof_ev[0][0][0])
+        for (int r = 0; r < PROF_RING; ++r)
+            for (int st = 0; st < STG_COUNT; ++st)
+                for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ctx->prof_ev[r][st][k]);
     delete ctx;
     return ST3R_OK;
 }
@@ -68,6 +72,66 @@ int st3r_arena_get(st3r_ctx* ctx, int slot, size_t bytes, void** out) {
         ctx->slot_bytes[slot] = want;
     }
     *out = ctx->slot_ptr[slot];
+    return ST3R_OK;
+}
+
+// ---- per-stage event timing ----
+static const char* k_stage_names[STG_COUNT] = {"project", "scan", "emit", "sort", "offsets", "blend_fwd", "loss",
+                                               "blend_bwd", "project_bwd", "adam"};
+
+ST3R_EXPORT const char* st3r_stage_name(int stage) {
+    return (stage >= 0 && stage < STG_COUNT) ? k_stage_names[stage] : "";
+}
+
+static void prof_harvest_slot(st3r_ctx* ctx, int slot) {
+    for (int st = 0; st < STG_COUNT; ++st) {
+        if (!ctx->prof_used[slot][st]) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(ctx->prof_ev[slot][st][1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, ctx->prof_ev[slot][st][0], ctx->prof_ev[slot][st][1]) == hipSuccess) {
+            ctx->prof_ms[st] += ms; ctx->prof_n[st] += 1;
+        }
+        ctx->prof_used[slot][st] = 0;
+    }
+}
+
+void st3r_prof_begin(st3r_ctx* ctx, hipStream_t s, int stage) {
+    if (!ctx->prof_enabled) return;
+    (void)hipEventRecord(ctx->prof_ev[ctx->prof_slot][stage][0], s);
+}
+
+void st3r_prof_end(st3r_ctx* ctx, hipStream_t s, int stage) {
+    if (!ctx->prof_enabled) return;
+    (void)hipEventRecord(ctx->prof_ev[ctx->prof_slot][stage][1], s);
+    ctx->prof_used[ctx->prof_slot][stage] = 1;
+}
+
+void st3r_prof_next_step(st3r_ctx* ctx) {
+    if (!ctx->prof_enabled) return;
+    ctx->prof_slot = (ctx->prof_slot + 1) % PROF_RING;
+    prof_harvest_slot(ctx, ctx->prof_slot);  // events from PROF_RING steps ago: long finished
+}
+
+ST3R_EXPORT int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable) {
+    ARG_CHECK(ctx);
+    if (enable && !ctx->prof_ev[0][0][0]) {
+        for (int r = 0; r < PROF_RING; ++r)
+            for (int st = 0; st < STG_COUNT; ++st)
+                for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreate(&ctx->prof_ev[r][st][k]));
+    }
+    ctx->prof_enabled = enable ? 1 : 0;
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* counts_out) {
+    ARG_CHECK(ctx && ms_out && counts_out);
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->prof_ev[0][0][0])
+        for (int r = 0; r < PROF_RING; ++r) prof_harvest_slot(ctx, r);
+    for (int st = 0; st < STG_COUNT; ++st) {
+        ms_out[st] = ctx->prof_ms[st]; counts_out[st] = ctx->prof_n[st];
+        ctx->prof_ms[st] = 0; ctx->prof_n[st] = 0;
+    }
     return ST3R_OK;
 }
 
@@ -102,7 +166,7 @@ static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } r
     }
 
 struct RasterOut {
-    float* splats; int32_t* offsets; int32_t* flat; int64_t n_isects; int tile_w, tile_h;
+    float* splats; int32_t* offsets; int32_t* flat; int64_t n_isects, n_visible; int tile_w, tile_h;
 };
 
 // project -> scan -> emit -> sort -> offsets, all in ctx scratch
@@ -117,24 +181,42 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_TILES, int32_t, n_pairs, tiles);
     GET(SLOT_CUM, int32_t, n_pairs, cum);
     GET(SLOT_OFFSETS, int32_t, (int64_t)C * tile_w * tile_h, offsets);
+    st3r_prof_begin(ctx, s, STG_PROJECT);
     int rc = st3r_gs_project_sh(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
                                 H, tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums);
+    st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     int64_t n_isects = 0;
-    rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, &n_isects);
+    st3r_prof_begin(ctx, s, STG_SCAN);
+    rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, nullptr);
+    st3r_prof_end(ctx, s, STG_SCAN);
     if (rc) return rc;
+    {   // read back the intersection count (and the visible-pair count) -- the one host sync per step
+        int32_t* total_dev = (int32_t*)ctx->slot_ptr[SLOT_SCAN_TMP] + ceil_div(n_pairs, 4096);
+        HIP_TRY(hipMemcpyAsync(ctx->pinned, total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (reg_sums) HIP_TRY(hipMemcpyAsync(ctx->pinned + 1, reg_sums + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        n_isects = (int64_t)((int32_t*)ctx->pinned)[0];
+        o->n_visible = reg_sums ? (int64_t)((double*)ctx->pinned)[1] : -1;
+    }
     GET(SLOT_KEYS_A, int64_t, n_isects, keys_a);
     GET(SLOT_KEYS_B, int64_t, n_isects, keys_b);
     GET(SLOT_VALS_A, int32_t, n_isects, vals_a);
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
     if (n_isects > 0) {
+        st3r_prof_begin(ctx, s, STG_EMIT);
         rc = st3r_isect_emit_impl(s, N, C, splats, cum, tile, tile_w, tile_h, keys_a, vals_a);
+        st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
         const int end_bit = 32 + bit_length_u32((uint32_t)(tile_w * tile_h)) + bit_length_u32((uint32_t)C);
+        st3r_prof_begin(ctx, s, STG_SORT);
         rc = st3r_sort_impl(ctx, s, n_isects, end_bit, keys_a, vals_a, keys_b, vals_b);
+        st3r_prof_end(ctx, s, STG_SORT);
         if (rc) return rc;
     }
+    st3r_prof_begin(ctx, s, STG_OFFSETS);
     rc = st3r_isect_offsets_impl(s, n_isects, keys_b, C, tile_w, tile_h, offsets);
+    st3r_prof_end(ctx, s, STG_OFFSETS);
     if (rc) return rc;
     o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->n_isects = n_isects;
     o->tile_w = tile_w; o->tile_h = tile_h;
@@ -165,8 +247,9 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     const int64_t n_pairs = (int64_t)N * C, n_px = (int64_t)C * H * W;
     GET(SLOT_SMALL, double, 2 * (size_t)C + 8, small);
     double* sums = small;              // [C,2]
-    double* reg_sums = small + 2 * C;  // [2]
-    HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 2, s));
+    double* reg_sums = small + 2 * C;  // [3]
+    HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 3, s));
+    st3r_prof_next_step(ctx);
     RasterOut ro;
     int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
                              reg_sums, &ro);
@@ -176,16 +259,24 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     GET(SLOT_LAST, int32_t, n_px, last);
     GET(SLOT_VRENDER, float, n_px * 3, v_rgb);
     GET(SLOT_VSPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, v_splats);
+    st3r_prof_begin(ctx, s, STG_BLEND_FWD);
     rc = st3r_blend_fwd_impl(s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb, alpha,
                              last);
+    st3r_prof_end(ctx, s, STG_BLEND_FWD);
     if (rc) return rc;
+    st3r_prof_begin(ctx, s, STG_LOSS);
     rc = st3r_loss_impl(ctx, s, C, H, W, rgb, gt_images, 1.0f - ssim_fac, ssim_fac, sums, v_rgb);
+    st3r_prof_end(ctx, s, STG_LOSS);
     if (rc) return rc;
+    st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha, last,
                              v_rgb, nullptr, n_pairs, v_splats);
+    st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
+    st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
     rc = st3r_gs_project_sh_bwd(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
                                 H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads);
+    st3r_prof_end(ctx, s, STG_PROJECT_BWD);
     if (rc) return rc;
     const int Hi = H - 10, Wi = W - 10;
     const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
@@ -194,7 +285,8 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
                        (double)opac_fac / N, (double)scale_fac / (3.0 * N), loss_out);
     LAUNCH_CHECK();
     if (stats_host) {
-        stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = 0;
+        stats_host[0] = ro.n_visible; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx);
+        stats_host[3] = 0;
     }
     return ST3R_OK;
 }

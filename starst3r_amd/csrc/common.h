@@ -52,12 +52,39 @@ enum ArenaSlot {
     SLOT_COUNT
 };
 
+// Stage ids for the optional per-stage HIP-event timing (st3r_ctx_set_profiling).
+enum Stage {
+    STG_PROJECT = 0,
+    STG_SCAN,
+    STG_EMIT,
+    STG_SORT,
+    STG_OFFSETS,
+    STG_BLEND_FWD,
+    STG_LOSS,
+    STG_BLEND_BWD,
+    STG_PROJECT_BWD,
+    STG_ADAM,
+    STG_COUNT
+};
+#define PROF_RING 64
+
 struct st3r_ctx {
     int device;
     void* slot_ptr[SLOT_COUNT];
     size_t slot_bytes[SLOT_COUNT];
     int64_t* pinned;  // small pinned host buffer for read-backs
+    // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
+    int prof_enabled;
+    hipEvent_t prof_ev[PROF_RING][STG_COUNT][2];
+    unsigned char prof_used[PROF_RING][STG_COUNT];
+    int prof_slot;          // ring slot of the step being recorded
+    double prof_ms[STG_COUNT];
+    int64_t prof_n[STG_COUNT];
 };
+
+void st3r_prof_begin(st3r_ctx* ctx, hipStream_t s, int stage);
+void st3r_prof_end(st3r_ctx* ctx, hipStream_t s, int stage);
+void st3r_prof_next_step(st3r_ctx* ctx);
 
 // returns a device pointer with at least `bytes` capacity for `slot` (contents undefined after growth)
 int st3r_arena_get(st3r_ctx* ctx, int slot, size_t bytes, void** out);

@@ -101,9 +101,8 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
             atomicAdd(&reg_sums[1], (double)((red[4] + red[5]) + (red[6] + red[7])));
         }
     }
-    if (!active) return;
-
-    for (int c = 0; c < C; ++c) {
+    int n_vis = 0;
+    for (int c = 0; active && c < C; ++c) {
         const float* o = cam + c * CAM_STRIDE;
         const float R00 = o[0], R01 = o[1], R02 = o[2], t0 = o[3];
         const float R10 = o[4], R11 = o[5], R12 = o[6], t1 = o[7];
@@ -192,6 +191,11 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         splats[pid * 3 + 1] = r1;
         splats[pid * 3 + 2] = r2;
         tiles_per_gauss[pid] = ntiles;
+        n_vis += valid ? 1 : 0;
+    }
+    if (reg_sums) {  // number of visible (camera, gaussian) pairs -> reg_sums[2]
+        for (int off = 32; off > 0; off >>= 1) n_vis += __shfl_down(n_vis, off);
+        if ((threadIdx.x & 63) == 0 && n_vis) atomicAdd(&reg_sums[2], (double)n_vis);
     }
 }
 

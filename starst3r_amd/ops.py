@@ -196,7 +196,19 @@ def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fa
         ctx.handle, _stream(), N, Cn, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
         _p(params["opacities"]), _p(sh), sh_stride_of(sh), _p(viewmats), _p(Ks), _p(campos), _p(gt), W, H, ssim_fac,
         opac_fac, scale_fac, _p(grads), _p(loss_out), stats))
-    return dict(n_isects=int(stats[1]), arena_bytes=int(stats[2]))
+    return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]))
+
+
+def set_profiling(ctx, enable):
+    _lib.check(_lib.lib().st3r_ctx_set_profiling(ctx.handle, 1 if enable else 0))
+
+
+def stage_ms(ctx):
+    """-> {stage: (total_ms, samples)} accumulated since the last call (synchronises the device)."""
+    n = 10
+    ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
+    _lib.check(_lib.lib().st3r_ctx_get_stage_ms(ctx.handle, ms, cnt))
+    return {_lib.lib().st3r_stage_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
 
 def render(ctx, params, viewmats, Ks, campos, W, H):
