@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libst3r_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-munsafe-fp-atomics",
-          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-DNDEBUG"]
+          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-DNDEBUG"] + os.environ.get("ST3R_DEFS", "").split()
 PER_FILE = {
     "gs_project.hip": ["-ffp-contract=off"],
     "gs_isect.hip": ["-ffp-contract=off"],

@@ -144,13 +144,13 @@ int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t
                    int64_t* keys_out, int32_t* vals_out);
 int st3r_isect_offsets_impl(hipStream_t s, int64_t n_isects, const int64_t* ids, int C, int tile_w, int tile_h,
                             int32_t* offsets);
-int st3r_blend_fwd_impl(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
-                        const int32_t* offsets, const int32_t* flat, int64_t n_isects, float* rgb, float* alpha,
-                        int32_t* last_ids);
-int st3r_blend_bwd_impl(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
-                        const int32_t* offsets, const int32_t* flat, int64_t n_isects, const float* alpha,
-                        const int32_t* last_ids, const float* v_rgb, const float* v_alpha, int64_t n_pairs,
-                        float* v_splats);
+int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
+                        const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
+                        float* rgb, float* alpha, int32_t* last_ids, bool for_backward);
+int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
+                        const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
+                        const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
+                        int64_t n_pairs, float* v_splats);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -260,8 +260,8 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     GET(SLOT_VRENDER, float, n_px * 3, v_rgb);
     GET(SLOT_VSPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, v_splats);
     st3r_prof_begin(ctx, s, STG_BLEND_FWD);
-    rc = st3r_blend_fwd_impl(s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb, alpha,
-                             last);
+    rc = st3r_blend_fwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb,
+                             alpha, last, true);
     st3r_prof_end(ctx, s, STG_BLEND_FWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_LOSS);
@@ -269,8 +269,8 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     st3r_prof_end(ctx, s, STG_LOSS);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
-    rc = st3r_blend_bwd_impl(s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha, last,
-                             v_rgb, nullptr, n_pairs, v_splats);
+    rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
+                             last, v_rgb, nullptr, n_pairs, v_splats);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
@@ -303,8 +303,8 @@ ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const 
                              height, nullptr, &ro);
     if (rc) return rc;
     GET(SLOT_LAST, int32_t, (int64_t)C * height * width, last);
-    rc = st3r_blend_fwd_impl(s, C, width, height, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects,
-                             rgb, alpha, last);
+    rc = st3r_blend_fwd_impl(ctx, s, C, width, height, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat,
+                             ro.n_isects, rgb, alpha, last, false);
     if (rc) return rc;
     if (stats_host) {
         stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = 0;

@@ -49,6 +49,8 @@ enum ArenaSlot {
     SLOT_SORT_TMP,
     SLOT_SCAN_TMP,
     SLOT_SMALL,
+    SLOT_CMASK,
+    SLOT_TILE_NB,
     SLOT_COUNT
 };
 

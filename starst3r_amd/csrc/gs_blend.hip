@@ -2,16 +2,42 @@
 // Replaces gsplat rasterize_to_pixels fwd/bwd (starster/gs.py:76 and the autograd pass of
 // starster/gs.py:153).
 //
-// One workgroup = one 16x16 tile = 4 wave64; wave w owns the 8x8 quadrant (w&1, w>>1) so a
-// wave covers a compact pixel block (better chance that a whole wave is skipped or finishes
-// early than with 16x4 strips).  The tile's depth-sorted Gaussian list is staged through
-// LDS in batches of 256 splat records (one record per thread, 3 x 16-byte loads), and every
-// lane then reads the same LDS address (broadcast, conflict free).
-// Workgroups are remapped so that each XCD (private 4 MiB L2) walks a contiguous range of
-// (camera, tile) ids: with 8 views on 8 XCDs every XCD owns one camera's splat array.
+// Mapping.  One workgroup = one 16x16 tile = 4 wave64; wave w owns the 8x8 quadrant
+// (w&1, w>>1).  Workgroups are remapped so that each XCD (private 4 MiB L2) walks a
+// contiguous range of (camera, tile) ids: with 8 views on 8 XCDs every XCD owns one
+// camera's splat array.
+//
+// Staging + wavefront compaction.  The tile's depth-sorted list is staged through LDS in
+// batches of 256 splat records (one record per thread, 3 x 16-byte loads).  The staging
+// thread also tests the record's exact influence box -- the bounding box of the ellipse
+// {alpha >= 1/255}, slightly inflated -- against the four quadrants; four wave ballots per
+// 64 records give every wave a 256-bit "relevant" mask, and the wave then walks only the set
+// bits with scalar bit-scan instructions.  Records that cannot reach a quadrant cost that
+// wave nothing (in the reference they fail the alpha test on all 64 pixels).
+//
+// Forward -> backward hand-off.  While blending, each wave records which staged records
+// actually contributed to at least one of its pixels (one bit per record per wave, ~20 MB at
+// 1M Gaussians / 8x1080p) and the number of batches the tile consumed.  The backward pass
+// walks exactly those bits back to front: no alpha test for non-contributors, no work behind
+// a wave's last contribution.
+//
+// Backward reduction.  The 9 per-pixel partial gradients are summed over the wave's 64 pixels
+// with a halving butterfly: v_permlane32_swap and v_permlane16_swap pair registers so that each
+// step halves the live values (5 + 3 swap/add pairs), then 4 DPP row steps on 3 registers --
+// 28 instructions instead of 9 full 64-lane reductions.  The four waves' partial sums meet in
+// LDS (ds_add_f32), and one thread per record flushes them to HBM with float atomics.
+//
+// Arithmetic note.  sigma is evaluated as P = dx*(qa*dx + qb*dy) + qc*dy*dy with
+// (qa,qb,qc) = -log2(e) * (a/2, b, c/2) folded at staging time, so exp(-sigma) = exp2(P) is
+// one v_exp_f32.  Forward and backward use the identical expression, hence identical
+// include/skip decisions.
 #include "common.h"
 
 #define BLK 256
+#ifndef ST3R_EXP
+#define ST3R_EXP 0  // timing experiments only (1: no HBM flush, 2: +no LDS atomics, 3: +no reduction)
+#endif
+#define LOG2E 1.4426950408889634f
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
     const int q = total >> 3, r = total & 7;
@@ -19,76 +45,160 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-__device__ __forceinline__ void tile_pixel(int tid, int& lx, int& ly) {
-    const int w = tid >> 6, lane = tid & 63;
-    lx = ((w & 1) << 3) + (lane & 7);
-    ly = ((w >> 1) << 3) + (lane >> 3);
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
 }
+
+struct TileGeom {
+    int lb, cam, i, j, start, end, tx0, ty0;
+    bool inside;
+    float px, py;
+};
+
+__device__ __forceinline__ TileGeom tile_geom(int C, int W, int H, int tile_w, int tile_h,
+                                              const int32_t* __restrict__ offsets, int n_isects) {
+    TileGeom g;
+    const int n_tiles = tile_w * tile_h, total = C * n_tiles;
+    g.lb = xcd_remap(blockIdx.x, total);
+    g.cam = g.lb / n_tiles;
+    const int tile = g.lb - g.cam * n_tiles;
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    g.tx0 = tx * 16; g.ty0 = ty * 16;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    g.j = g.tx0 + ((w & 1) << 3) + (lane & 7);
+    g.i = g.ty0 + ((w >> 1) << 3) + (lane >> 3);
+    g.inside = (g.i < H) && (g.j < W);
+    g.px = (float)g.j + 0.5f; g.py = (float)g.i + 0.5f;
+    g.start = offsets[g.lb];
+    g.end = (g.lb == total - 1) ? n_isects : offsets[g.lb + 1];
+    return g;
+}
+
+// Stage record `id` into LDS slot t (q-form) and return the 4-bit quadrant relevance.
+__device__ __forceinline__ int stage_record(const float4* __restrict__ splats, int64_t id, int t, int tx0, int ty0,
+                                            float4* sA, float4* sB, float* sC) {
+    const float4 a = splats[id * 3 + 0];   // x y opacity conic.a
+    const float4 b = splats[id * 3 + 1];   // conic.b conic.c r g
+    const float4 c = splats[id * 3 + 2];   // b depth radius 0
+    sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
+    sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
+    sC[t] = c.x;
+    // influence box of {opacity*exp(-sigma) >= 1/255}: |dx| <= sqrt(2 tau cov_xx), tau = ln(255 o)
+    const float o255 = 255.0f * a.z;
+    if (!(o255 > 1.0f)) return 0;
+    const float tau = __logf(o255) * 1.0002f + 1e-4f;
+    const float det = a.w * b.y - b.x * b.x;
+    const float inv = 1.0f / det;
+    const float ex = sqrtf(2.0f * tau * b.y * inv) + 0.02f;
+    const float ey = sqrtf(2.0f * tau * a.w * inv) + 0.02f;
+    // pixel centres of quadrant (qx,qy): tx0 + 8qx + [0.5, 7.5]
+    const float rx = a.x - ((float)tx0 + 0.5f), ry = a.y - ((float)ty0 + 0.5f);
+    const bool x0 = (rx + ex >= 0.0f) && (rx - ex <= 7.0f);
+    const bool x1 = (rx + ex >= 8.0f) && (rx - ex <= 15.0f);
+    const bool y0 = (ry + ey >= 0.0f) && (ry - ey <= 7.0f);
+    const bool y1 = (ry + ey >= 8.0f) && (ry - ey <= 15.0f);
+    return (int)(x0 && y0) | ((int)(x1 && y0) << 1) | ((int)(x0 && y1) << 2) | ((int)(x1 && y1) << 3);
+}
+
+// word index of the first 64-record chunk of tile lb in the contribution-mask arrays
+// (a tile of `len` records uses 4*ceil(len/256) <= floor(len/64) + 4 words, hence the 4*lb slack)
+__device__ __forceinline__ int64_t mask_base(int lb, int start) { return (int64_t)(start >> 6) + 4 * (int64_t)lb; }
 
 __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
                                                    const int32_t* __restrict__ offsets,
                                                    const int32_t* __restrict__ flat, int n_isects,
                                                    float* __restrict__ out_rgb, float* __restrict__ out_alpha,
-                                                   int32_t* __restrict__ last_ids) {
-    __shared__ float4 sA[BLK];  // x y opacity conic.a
-    __shared__ float4 sB[BLK];  // conic.b conic.c r g
+                                                   int32_t* __restrict__ last_ids,
+                                                   uint64_t* __restrict__ cmask, int64_t cmask_words,
+                                                   int32_t* __restrict__ tile_nb) {
+    __shared__ float4 sA[BLK];  // x y opacity qa
+    __shared__ float4 sB[BLK];  // qb qc r g
     __shared__ float sC[BLK];   // b
-    const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-    const int lb = xcd_remap(blockIdx.x, total);
-    const int cam = lb / n_tiles, tile = lb - cam * n_tiles;
-    const int ty = tile / tile_w, tx = tile - ty * tile_w;
-    int lx, ly;
-    tile_pixel(threadIdx.x, lx, ly);
-    const int i = ty * 16 + ly, j = tx * 16 + lx;
-    const bool inside = (i < H) && (j < W);
-    bool done = !inside;
-    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-    const int start = offsets[lb];
-    const int end = (lb == total - 1) ? n_isects : offsets[lb + 1];
-    float T = 1.0f, r = 0.f, g = 0.f, b = 0.f;
+    __shared__ uint64_t sMask[4][4];  // [quadrant][64-record chunk]
+    const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    bool done = !g.inside;
+    float T = 1.0f, r = 0.f, gg = 0.f, b = 0.f;
     int cur = 0;
-    for (int bs = start; bs < end; bs += BLK) {
+    int nb = 0;
+    const int64_t mbase = mask_base(g.lb, g.start);
+    for (int bs = g.start; bs < g.end; bs += BLK, ++nb) {
         if (__syncthreads_and(done)) break;
         const int idx = bs + threadIdx.x;
-        if (idx < end) {
-            const int64_t id = flat[idx];
-            const float4 a = splats[id * 3 + 0];
-            const float4 bq = splats[id * 3 + 1];
-            const float4 c = splats[id * 3 + 2];
-            sA[threadIdx.x] = a; sB[threadIdx.x] = bq; sC[threadIdx.x] = c.x;
-        }
+        int rel = 0;
+        if (idx < g.end) rel = stage_record(splats, flat[idx], threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
+        const uint64_t m0 = __ballot(rel & 1), m1 = __ballot(rel & 2), m2 = __ballot(rel & 4), m3 = __ballot(rel & 8);
+        if (lane == 0) { sMask[0][w] = m0; sMask[1][w] = m1; sMask[2][w] = m2; sMask[3][w] = m3; }
         __syncthreads();
-        const int bsz = min(BLK, end - bs);
-        for (int t = 0; t < bsz && !done; ++t) {
-            const float4 a = sA[t];
-            const float4 bq = sB[t];
-            const float dx = a.x - px, dy = a.y - py;
-            const float sigma = 0.5f * (a.w * dx * dx + bq.y * dy * dy) + bq.x * dx * dy;
-            const float alpha = fminf(0.999f, a.z * __expf(-sigma));
-            if (sigma < 0.f || alpha < 1.f / 255.f) continue;
-            const float nT = T * (1.0f - alpha);
-            if (nT <= 1e-4f) { done = true; break; }
-            const float vis = alpha * T;
-            r += bq.z * vis; g += bq.w * vis; b += sC[t] * vis;
-            cur = bs + t;
-            T = nT;
+#pragma unroll 1
+        for (int jj = 0; jj < 4; ++jj) {
+            uint64_t m = uniform_u64(sMask[w][jj]);
+            uint64_t contributed = 0;
+            if (__all(done)) m = 0;
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int t = jj * 64 + bit;
+                const float4 a = sA[t];
+                const float4 q = sB[t];
+                const float dx = a.x - g.px, dy = a.y - g.py;
+                const float P = dx * (a.w * dx + q.x * dy) + q.y * dy * dy;
+                const float alpha = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
+                const bool valid = !done && !(P > 0.f) && !(alpha < 1.f / 255.f);
+                if (!__any(valid)) continue;
+                const float nT = T * (1.0f - alpha);
+                const bool stop = valid && (nT <= 1e-4f);
+                const bool take = valid && !stop;
+                done = done || stop;
+                if (take) {
+                    const float vis = alpha * T;
+                    r += q.z * vis; gg += q.w * vis; b += sC[t] * vis;
+                    cur = bs + t;
+                    T = nT;
+                }
+                if (__any(take)) contributed |= (1ull << bit);
+            }
+            if (cmask && lane == 0) cmask[(int64_t)w * cmask_words + mbase + nb * 4 + jj] = contributed;
         }
     }
-    if (inside) {
-        const int64_t p = ((int64_t)cam * H + i) * W + j;
-        out_rgb[3 * p] = r; out_rgb[3 * p + 1] = g; out_rgb[3 * p + 2] = b;
+    if (g.inside) {
+        const int64_t p = ((int64_t)g.cam * H + g.i) * W + g.j;
+        out_rgb[3 * p] = r; out_rgb[3 * p + 1] = gg; out_rgb[3 * p + 2] = b;
         out_alpha[p] = 1.0f - T;
         last_ids[p] = cur;
     }
+    if (tile_nb && threadIdx.x == 0) tile_nb[g.lb] = nb;
 }
 
-int st3r_blend_fwd_impl(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
-                        const int32_t* offsets, const int32_t* flat, int64_t n_isects, float* rgb, float* alpha,
-                        int32_t* last_ids) {
+// scratch for the forward->backward hand-off lives in the ctx
+static int hand_off_buffers(st3r_ctx* ctx, int C, int tile_w, int tile_h, int64_t n_isects, uint64_t** cmask,
+                            int64_t* words, int32_t** tile_nb) {
+    const int64_t total = (int64_t)C * tile_w * tile_h;
+    *words = (n_isects >> 6) + 4 * total + 8;
+    void* p;
+    int rc = st3r_arena_get(ctx, SLOT_CMASK, sizeof(uint64_t) * 4 * (size_t)*words, &p);
+    if (rc) return rc;
+    *cmask = (uint64_t*)p;
+    rc = st3r_arena_get(ctx, SLOT_TILE_NB, sizeof(int32_t) * (size_t)total, &p);
+    if (rc) return rc;
+    *tile_nb = (int32_t*)p;
+    return ST3R_OK;
+}
+
+int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
+                        const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
+                        float* rgb, float* alpha, int32_t* last_ids, bool for_backward) {
     const int total = C * tile_w * tile_h;
+    uint64_t* cmask = nullptr; int64_t words = 0; int32_t* tile_nb = nullptr;
+    if (for_backward) {
+        int rc = hand_off_buffers(ctx, C, tile_w, tile_h, n_isects, &cmask, &words, &tile_nb);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_blend_fwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, (int)n_isects, rgb, alpha, last_ids);
+                       offsets, flat, (int)n_isects, rgb, alpha, last_ids, cmask, words, tile_nb);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -101,8 +211,8 @@ ST3R_EXPORT int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width,
     ARG_CHECK(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16);
     ARG_CHECK(splats && offsets && rgb && alpha && last_ids && n_isects >= 0 && n_isects < 2147483647LL);
     ARG_CHECK(n_isects == 0 || flatten_ids);
-    return st3r_blend_fwd_impl((hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets, flatten_ids,
-                               n_isects, rgb, alpha, last_ids);
+    return st3r_blend_fwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
+                               flatten_ids, n_isects, rgb, alpha, last_ids, true);
 }
 
 // ------------------------------------------------------------------------------------
@@ -113,17 +223,27 @@ __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
-// sum over the 64 lanes of a wave; result valid in every lane
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+// (a, b) -> a + b after exchanging halves: lanes 0-31 end up with sum_{l, l+32} a, lanes 32-63 with that of b.
+// Inline asm on purpose: with hipcc 7.2 the second element returned by
+// __builtin_amdgcn_permlane32_swap / permlane16_swap came back equal to the first (measured, see
+// tools/probe/swap_probe.hip); the instruction itself behaves as documented.  "s_nop 1" = the two
+// wait states a VALU-written operand needs before v_permlane*_swap reads it.
+__device__ __forceinline__ float fold32(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// rows (16 lanes) 0,2 end up with a summed over the row pair (0,1)/(2,3); rows 1,3 with b
+__device__ __forceinline__ float fold16(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// every lane of a 16-lane row receives the row sum
+__device__ __forceinline__ float row_allsum(float v) {
+    v += dpp_f<0x128>(v);  // row_ror:8
+    v += dpp_f<0x124>(v);  // row_ror:4
     v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);  // row_half_mirror
-    v += dpp_f<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row sum
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (r0 + r1) + (r2 + r3);
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    return v;
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
@@ -142,28 +262,22 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const int32_t* __restrict__ last_ids,
                                                    const float* __restrict__ v_rgb,
                                                    const float* __restrict__ v_alpha,
+                                                   const uint64_t* __restrict__ cmask, int64_t cmask_words,
+                                                   const int32_t* __restrict__ tile_nb,
                                                    float* __restrict__ v_splats) {
     __shared__ float4 sA[BLK];
     __shared__ float4 sB[BLK];
     __shared__ float sC[BLK];
     __shared__ int sId[BLK];
-    __shared__ float sAcc[BLK * ACC_STRIDE];  // per-batch, per-Gaussian partial sums of the 4 waves
-    const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-    const int lb = xcd_remap(blockIdx.x, total);
-    const int cam = lb / n_tiles, tile = lb - cam * n_tiles;
-    const int ty = tile / tile_w, tx = tile - ty * tile_w;
-    int lx, ly;
-    tile_pixel(threadIdx.x, lx, ly);
-    const int i = ty * 16 + ly, j = tx * 16 + lx;
-    const bool inside = (i < H) && (j < W);
-    const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-    const int start = offsets[lb];
-    const int end = (lb == total - 1) ? n_isects : offsets[lb + 1];
-    if (end <= start) return;
-    const int64_t p = ((int64_t)cam * H + i) * W + j;
+    __shared__ float sAcc[BLK * ACC_STRIDE];  // per-batch, per-record partial sums of the 4 waves
+    const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
+    const int nb = tile_nb[g.lb];
+    if (nb == 0) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t p = ((int64_t)g.cam * H + g.i) * W + g.j;
     float T_final = 1.0f, vr = 0.f, vg = 0.f, vb = 0.f, va = 0.f;
     int bin_final = -1;
-    if (inside) {
+    if (g.inside) {
         T_final = 1.0f - out_alpha[p];
         vr = v_rgb[3 * p]; vg = v_rgb[3 * p + 1]; vb = v_rgb[3 * p + 2];
         if (v_alpha) va = v_alpha[p];
@@ -171,71 +285,94 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     }
     float T = T_final;
     float bufr = 0.f, bufg = 0.f, bufb = 0.f;
-    const int wave_bin_final = wave_max_i(bin_final);
-    const int lane = threadIdx.x & 63;
+    const int64_t mbase = mask_base(g.lb, g.start);
+    const uint64_t* wmask = cmask + (int64_t)w * cmask_words + mbase;
+    // row (16 lanes) r of the folded registers holds: k0 -> slot {0,2,1,3}[r], k1 -> {4,6,5,7}[r], k2 -> 8 (row 0)
+    const int row = lane >> 4;
+    const int slot0 = ((row & 1) << 1) | (row >> 1);
+    const bool row_leader = (lane & 15) == 0;
 
-    // batches walk the tile list back to front; batch_end is the last index of the batch
-    for (int batch_end = end - 1; batch_end >= start; batch_end -= BLK) {
+    for (int bt = nb - 1; bt >= 0; --bt) {
+        const int bs = g.start + bt * BLK;
+        const int bsz = min(BLK, g.end - bs);
         __syncthreads();
-        const int bsz = min(BLK, batch_end + 1 - start);
-        const int idx = batch_end - threadIdx.x;
-        if (idx >= start) {
-            const int64_t id = flat[idx];
-            const float4 a = splats[id * 3 + 0];
-            const float4 bq = splats[id * 3 + 1];
-            const float4 c = splats[id * 3 + 2];
-            sA[threadIdx.x] = a; sB[threadIdx.x] = bq; sC[threadIdx.x] = c.x; sId[threadIdx.x] = (int)id;
+        if ((int)threadIdx.x < bsz) {
+            const int64_t id = flat[bs + threadIdx.x];
+            (void)stage_record(splats, id, threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
+            sId[threadIdx.x] = (int)id;
         }
 #pragma unroll
         for (int k = 0; k < ACC_STRIDE; ++k) sAcc[threadIdx.x * ACC_STRIDE + k] = 0.f;
         __syncthreads();
-        // t = 0 is the furthest-back Gaussian of the batch (sorted index batch_end - t)
-        for (int t = max(0, batch_end - wave_bin_final); t < bsz; ++t) {
-            const float4 a = sA[t];
-            const float4 bq = sB[t];
-            const float cb_ = sC[t];
-            bool valid = inside && (batch_end - t <= bin_final);
-            const float dx = a.x - px, dy = a.y - py;
-            const float sigma = 0.5f * (a.w * dx * dx + bq.y * dy * dy) + bq.x * dx * dy;
-            const float vis = __expf(-sigma);
-            const float alpha = fminf(0.999f, a.z * vis);
-            if (sigma < 0.f || alpha < 1.f / 255.f) valid = false;
-            if (!__any(valid)) continue;
-            float g_x = 0.f, g_y = 0.f, g_o = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
-            if (valid) {
-                const float ra = 1.0f / (1.0f - alpha);
-                T *= ra;
-                const float fac = alpha * T;
-                g_r = fac * vr; g_g = fac * vg; g_b = fac * vb;
-                float v_al = (bq.z * T - bufr * ra) * vr + (bq.w * T - bufg * ra) * vg + (cb_ * T - bufb * ra) * vb;
-                v_al += T_final * ra * va;
-                if (a.z * vis <= 0.999f) {
-                    const float v_sigma = -a.z * vis * v_al;
-                    g_ca = 0.5f * v_sigma * dx * dx;
-                    g_cb = v_sigma * dx * dy;
-                    g_cc = 0.5f * v_sigma * dy * dy;
-                    g_x = v_sigma * (a.w * dx + bq.x * dy);
-                    g_y = v_sigma * (bq.x * dx + bq.y * dy);
-                    g_o = vis * v_al;
+#pragma unroll 1
+        for (int jj = 3; jj >= 0; --jj) {
+            uint64_t m = uniform_u64(wmask[bt * 4 + jj]);
+            while (m) {
+                const int bit = 63 - __builtin_clzll(m);
+                m &= ~(1ull << bit);
+                const int t = jj * 64 + bit;
+                const float4 a = sA[t];
+                const float4 q = sB[t];
+                const float cb_ = sC[t];
+                const float dx = a.x - g.px, dy = a.y - g.py;
+                const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
+                const float P = dx * lx + q.y * dy * dy;
+                const float vis = __builtin_amdgcn_exp2f(P);
+                const float ov = a.z * vis;
+                const float alpha = fminf(0.999f, ov);
+                const bool valid = g.inside && (bs + t <= bin_final) && !(P > 0.f) && !(alpha < 1.f / 255.f);
+                float g_x = 0.f, g_y = 0.f, g_o = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
+                if (valid) {
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T *= ra;
+                    const float fac = alpha * T;
+                    g_r = fac * vr; g_g = fac * vg; g_b = fac * vb;
+                    float v_al = (q.z * T - bufr * ra) * vr + (q.w * T - bufg * ra) * vg + (cb_ * T - bufb * ra) * vb;
+                    v_al += T_final * ra * va;
+                    if (ov <= 0.999f) {
+                        const float v_sigma = -ov * v_al;
+                        g_ca = 0.5f * v_sigma * dx * dx;
+                        g_cb = v_sigma * dx * dy;
+                        g_cc = 0.5f * v_sigma * dy * dy;
+                        // d sigma/d mean = (a dx + b dy, b dx + c dy) with a = -2 qa/log2e, b = -qb/log2e, c = -2 qc/log2e
+                        const float wv = v_sigma * (-1.0f / LOG2E);
+                        g_x = wv * (lx + a.w * dx);
+                        g_y = wv * (q.x * dx + 2.0f * q.y * dy);
+                        g_o = vis * v_al;
+                    }
+                    bufr += q.z * fac; bufg += q.w * fac; bufb += cb_ * fac;
                 }
-                bufr += bq.z * fac; bufg += bq.w * fac; bufb += cb_ * fac;
-            }
-            g_x = wave_sum(g_x); g_y = wave_sum(g_y); g_o = wave_sum(g_o);
-            g_ca = wave_sum(g_ca); g_cb = wave_sum(g_cb); g_cc = wave_sum(g_cc);
-            g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
-            if (lane == 0) {
-                float* acc = sAcc + t * ACC_STRIDE;
-                atomicAdd(acc + 0, g_x); atomicAdd(acc + 1, g_y); atomicAdd(acc + 2, g_o);
-                atomicAdd(acc + 3, g_ca); atomicAdd(acc + 4, g_cb); atomicAdd(acc + 5, g_cc);
-                atomicAdd(acc + 6, g_r); atomicAdd(acc + 7, g_g); atomicAdd(acc + 8, g_b);
+#if ST3R_EXP >= 3
+                asm volatile("" ::"v"(g_x), "v"(g_y), "v"(g_o), "v"(g_ca), "v"(g_cb), "v"(g_cc), "v"(g_r), "v"(g_g), "v"(g_b));
+                continue;
+#endif
+                // 9 values x 64 lanes -> halving butterfly
+                const float h0 = fold32(g_x, g_y), h1 = fold32(g_o, g_ca), h2 = fold32(g_cb, g_cc);
+                const float h3 = fold32(g_r, g_g), h4 = fold32(g_b, 0.f);
+                float k0 = fold16(h0, h1), k1 = fold16(h2, h3), k2 = fold16(h4, 0.f);
+                k0 = row_allsum(k0); k1 = row_allsum(k1); k2 = row_allsum(k2);
+#if ST3R_EXP >= 2
+                asm volatile("" ::"v"(k0), "v"(k1), "v"(k2));
+                continue;
+#endif
+                if (row_leader) {
+                    float* acc = sAcc + t * ACC_STRIDE;
+                    atomicAdd(acc + slot0, k0);
+                    atomicAdd(acc + 4 + slot0, k1);
+                    if (lane == 0) atomicAdd(acc + 8, k2);
+                }
             }
         }
         __syncthreads();
-        if (threadIdx.x < bsz) {
+        if ((int)threadIdx.x < bsz) {
             const float* acc = sAcc + threadIdx.x * ACC_STRIDE;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < ACC_STRIDE; ++k) any |= (acc[k] != 0.f);
+#if ST3R_EXP >= 1
+            asm volatile("" ::"v"(any));
+            any = false;
+#endif
             if (any) {
                 float* dst = v_splats + (int64_t)sId[threadIdx.x] * ST3R_SPLAT_STRIDE;
 #pragma unroll
@@ -245,15 +382,18 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     }
 }
 
-int st3r_blend_bwd_impl(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
-                        const int32_t* offsets, const int32_t* flat, int64_t n_isects, const float* alpha,
-                        const int32_t* last_ids, const float* v_rgb, const float* v_alpha, int64_t n_pairs,
-                        float* v_splats) {
+int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
+                        const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
+                        const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
+                        int64_t n_pairs, float* v_splats) {
     HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
     if (n_isects == 0) return ST3R_OK;
+    uint64_t* cmask; int64_t words; int32_t* tile_nb;
+    int rc = hand_off_buffers(ctx, C, tile_w, tile_h, n_isects, &cmask, &words, &tile_nb);
+    if (rc) return rc;
     const int total = C * tile_w * tile_h;
     hipLaunchKernelGGL(k_blend_bwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, v_splats);
+                       offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask, words, tile_nb, v_splats);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -267,6 +407,6 @@ ST3R_EXPORT int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width,
     ARG_CHECK(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16);
     ARG_CHECK(splats && offsets && alpha && last_ids && v_rgb && v_splats && n_pairs >= 0);
     ARG_CHECK(n_isects >= 0 && n_isects < 2147483647LL && (n_isects == 0 || flatten_ids));
-    return st3r_blend_bwd_impl((hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets, flatten_ids,
-                               n_isects, alpha, last_ids, v_rgb, v_alpha, n_pairs, v_splats);
+    return st3r_blend_bwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
+                               flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, n_pairs, v_splats);
 }
