@@ -112,12 +112,16 @@ int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width, int height,
                       int tile_h, const float* splats, const int32_t* offsets, const int32_t* flatten_ids,
                       int64_t n_isects, float* rgb, float* alpha, int32_t* last_ids);
 
-/* gsplat rasterize_to_pixels backward.  v_alpha may be NULL (== 0).  v_splats is
- * zero-filled by this call (n_pairs = C*N records) and then accumulated into. */
+/* gsplat rasterize_to_pixels backward.  v_alpha may be NULL (== 0).  Must follow
+ * st3r_gs_blend_fwd of the same arguments on the same ctx (the forward leaves per-wave
+ * contribution bitmasks in ctx scratch).  Gradients are accumulated without HBM atomics:
+ * each (record, tile) pair owns a slot in ctx scratch, and v_splats[pid] (n_pairs = C*N
+ * records, fully written) is the in-order sum of the pair's slots.  cum_tiles is the
+ * inclusive scan from st3r_gs_isect_scan. */
 int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width, int height, int tile_size, int tile_w,
                       int tile_h, const float* splats, const int32_t* offsets, const int32_t* flatten_ids,
                       int64_t n_isects, const float* alpha, const int32_t* last_ids, const float* v_rgb,
-                      const float* v_alpha, int64_t n_pairs, float* v_splats);
+                      const float* v_alpha, const int32_t* cum_tiles, int64_t n_pairs, float* v_splats);
 
 /* backward of st3r_gs_project_sh, summed over cameras, plus the regulariser gradients
  *   reg_views * opac_fac * d mean|sigmoid(o)|   and   reg_views * scale_fac * d mean|exp(s)|

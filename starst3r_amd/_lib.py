@@ -30,7 +30,7 @@ SIGNATURES = {
     "st3r_gs_sort": [vp, vp, i64, i32, vp, vp, vp, vp],
     "st3r_gs_offsets": [vp, vp, i64, vp, i32, i32, i32, vp],
     "st3r_gs_blend_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp],
-    "st3r_gs_blend_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp],
+    "st3r_gs_blend_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp],
     "st3r_gs_project_sh_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32,
                                f32, vp],
     "st3r_loss_l1_ssim": [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp],

@@ -54,6 +54,12 @@ ST3R_EXPORT int64_t st3r_ctx_arena_bytes(st3r_ctx* ctx) {
 }
 
 int st3r_arena_get(st3r_ctx* ctx, int slot, size_t bytes, void** out) {
+    int grown;
+    return st3r_arena_get2(ctx, slot, bytes, out, &grown);
+}
+
+int st3r_arena_get2(st3r_ctx* ctx, int slot, size_t bytes, void** out, int* grown) {
+    *grown = 0;
     if (bytes == 0) bytes = 16;
     if (ctx->slot_bytes[slot] < bytes) {
         // grow with 25% headroom so slowly growing intersection counts do not reallocate every step
@@ -70,6 +76,7 @@ int st3r_arena_get(st3r_ctx* ctx, int slot, size_t bytes, void** out) {
             return ST3R_ERR_NOMEM;
         }
         ctx->slot_bytes[slot] = want;
+        *grown = 1;
     }
     *out = ctx->slot_ptr[slot];
     return ST3R_OK;
@@ -150,7 +157,7 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        int64_t n_pairs, float* v_splats);
+                        const int32_t* cum, int64_t n_pairs, float* v_splats);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -166,7 +173,7 @@ static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } r
     }
 
 struct RasterOut {
-    float* splats; int32_t* offsets; int32_t* flat; int64_t n_isects, n_visible; int tile_w, tile_h;
+    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; int64_t n_isects, n_visible; int tile_w, tile_h;
 };
 
 // project -> scan -> emit -> sort -> offsets, all in ctx scratch
@@ -218,7 +225,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     rc = st3r_isect_offsets_impl(s, n_isects, keys_b, C, tile_w, tile_h, offsets);
     st3r_prof_end(ctx, s, STG_OFFSETS);
     if (rc) return rc;
-    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->n_isects = n_isects;
+    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->n_isects = n_isects;
     o->tile_w = tile_w; o->tile_h = tile_h;
     return ST3R_OK;
 }
@@ -270,7 +277,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, n_pairs, v_splats);
+                             last, v_rgb, nullptr, ro.cum, n_pairs, v_splats);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);

@@ -51,6 +51,7 @@ enum ArenaSlot {
     SLOT_SMALL,
     SLOT_CMASK,
     SLOT_TILE_NB,
+    SLOT_VTILE,
     SLOT_COUNT
 };
 
@@ -76,6 +77,7 @@ struct st3r_ctx {
     size_t slot_bytes[SLOT_COUNT];
     int64_t* pinned;  // small pinned host buffer for read-backs
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
+    int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     int prof_enabled;
     hipEvent_t prof_ev[PROF_RING][STG_COUNT][2];
     unsigned char prof_used[PROF_RING][STG_COUNT];
@@ -90,6 +92,8 @@ void st3r_prof_next_step(st3r_ctx* ctx);
 
 // returns a device pointer with at least `bytes` capacity for `slot` (contents undefined after growth)
 int st3r_arena_get(st3r_ctx* ctx, int slot, size_t bytes, void** out);
+// same, *grown = 1 when the slot was (re)allocated by this call
+int st3r_arena_get2(st3r_ctx* ctx, int slot, size_t bytes, void** out, int* grown);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

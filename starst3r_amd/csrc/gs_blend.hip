@@ -253,6 +253,13 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 #define ACC_STRIDE 9
+#define VT_STRIDE 10  // per-(record, tile) slot: 9 partial gradients + stamp
+
+__device__ __forceinline__ int tile_clampi(float v, int hi) {
+    if (!(v > 0.0f)) return 0;
+    if (v >= (float)hi) return hi;
+    return (int)v;
+}
 
 __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
@@ -264,11 +271,11 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const float* __restrict__ v_alpha,
                                                    const uint64_t* __restrict__ cmask, int64_t cmask_words,
                                                    const int32_t* __restrict__ tile_nb,
-                                                   float* __restrict__ v_splats) {
+                                                   const int32_t* __restrict__ cum, int tile_size_unused,
+                                                   float* __restrict__ vtile, int stamp) {
     __shared__ float4 sA[BLK];
     __shared__ float4 sB[BLK];
     __shared__ float sC[BLK];
-    __shared__ int sId[BLK];
     __shared__ float sAcc[BLK * ACC_STRIDE];  // per-batch, per-record partial sums of the 4 waves
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
     const int nb = tile_nb[g.lb];
@@ -296,10 +303,10 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         const int bs = g.start + bt * BLK;
         const int bsz = min(BLK, g.end - bs);
         __syncthreads();
+        int64_t my_id = 0;
         if ((int)threadIdx.x < bsz) {
-            const int64_t id = flat[bs + threadIdx.x];
-            (void)stage_record(splats, id, threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
-            sId[threadIdx.x] = (int)id;
+            my_id = flat[bs + threadIdx.x];
+            (void)stage_record(splats, my_id, threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
         }
 #pragma unroll
         for (int k = 0; k < ACC_STRIDE; ++k) sAcc[threadIdx.x * ACC_STRIDE + k] = 0.f;
@@ -374,26 +381,75 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             any = false;
 #endif
             if (any) {
-                float* dst = v_splats + (int64_t)sId[threadIdx.x] * ST3R_SPLAT_STRIDE;
+                // slot of this (record, tile) pair in emission order: u = cum_excl[pid] + index of this
+                // tile inside the record's tile rectangle (same float ops as k_isect_emit => same ints)
+                const float4 a = sA[threadIdx.x];
+                const float radius = (float)__float_as_int(splats[my_id * 3 + 2].z);
+                const float tile_radius = radius / 16.0f, tile_x = a.x / 16.0f, tile_y = a.y / 16.0f;
+                const int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
+                const int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
+                const int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
+                const int cum_excl = my_id == 0 ? 0 : cum[my_id - 1];
+                const int64_t u = (int64_t)cum_excl + ((g.ty0 >> 4) - y0) * (x1 - x0) + ((g.tx0 >> 4) - x0);
+                float* dst = vtile + u * VT_STRIDE;
 #pragma unroll
-                for (int k = 0; k < ACC_STRIDE; ++k) atomicAdd(dst + k, acc[k]);
+                for (int k = 0; k < ACC_STRIDE; ++k) dst[k] = acc[k];
+                dst[ACC_STRIDE] = __int_as_float(stamp);
             }
         }
     }
 }
 
+// v_splats[pid] = sum over the pair's tiles of the slots stamped by this backward call, in slot order
+// (deterministic given the slots).  One thread per (camera, gaussian) pair.
+__global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int32_t* __restrict__ cum,
+                                                      const float* __restrict__ vtile, int stamp,
+                                                      float4* __restrict__ v_splats) {
+    const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= n_pairs) return;
+    const int end = cum[pid];
+    const int start = pid == 0 ? 0 : cum[pid - 1];
+    float acc[ACC_STRIDE];
+#pragma unroll
+    for (int k = 0; k < ACC_STRIDE; ++k) acc[k] = 0.f;
+    for (int u = start; u < end; ++u) {
+        const float* src = vtile + (int64_t)u * VT_STRIDE;
+        if (__float_as_int(src[ACC_STRIDE]) == stamp) {
+#pragma unroll
+            for (int k = 0; k < ACC_STRIDE; ++k) acc[k] += src[k];
+        }
+    }
+    v_splats[pid * 3 + 0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    v_splats[pid * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    v_splats[pid * 3 + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+}
+
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        int64_t n_pairs, float* v_splats) {
-    HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
-    if (n_isects == 0) return ST3R_OK;
+                        const int32_t* cum, int64_t n_pairs, float* v_splats) {
+    if (n_isects == 0) {
+        HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
+        return ST3R_OK;
+    }
     uint64_t* cmask; int64_t words; int32_t* tile_nb;
     int rc = hand_off_buffers(ctx, C, tile_w, tile_h, n_isects, &cmask, &words, &tile_nb);
     if (rc) return rc;
+    // per-(record, tile) partial gradients: 9 floats + a stamp; a slot counts only if its stamp equals this
+    // call's, so the buffer is never cleared (it is zeroed once when it is (re)allocated)
+    void* p; int grown = 0;
+    rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * VT_STRIDE * (size_t)n_isects, &p, &grown);
+    if (rc) return rc;
+    if (grown) HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VTILE], s));
+    float* vtile = (float*)p;
+    const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
     hipLaunchKernelGGL(k_blend_bwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask, words, tile_nb, v_splats);
+                       offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask, words, tile_nb, cum, 16,
+                       vtile, stamp);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp,
+                       (float4*)v_splats);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -402,11 +458,11 @@ ST3R_EXPORT int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width,
                                   int tile_w, int tile_h, const float* splats, const int32_t* offsets,
                                   const int32_t* flatten_ids, int64_t n_isects, const float* alpha,
                                   const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                                  int64_t n_pairs, float* v_splats) {
+                                  const int32_t* cum_tiles, int64_t n_pairs, float* v_splats) {
     ARG_CHECK(ctx && C > 0 && width > 0 && height > 0 && tile_size == 16);
     ARG_CHECK(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16);
-    ARG_CHECK(splats && offsets && alpha && last_ids && v_rgb && v_splats && n_pairs >= 0);
+    ARG_CHECK(splats && offsets && alpha && last_ids && v_rgb && v_splats && cum_tiles && n_pairs >= 0);
     ARG_CHECK(n_isects >= 0 && n_isects < 2147483647LL && (n_isects == 0 || flatten_ids));
     return st3r_blend_bwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
-                               flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, n_pairs, v_splats);
+                               flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, cum_tiles, n_pairs, v_splats);
 }

@@ -3,18 +3,26 @@
 // (data_range=1: 11x11 gaussian window sigma 1.5, k1=.01, k2=.03, mean over the interior
 // (H-10)x(W-10)) and their autograd, starster/gs.py:126-130,153.
 //
-// Two LDS-tiled separable passes over 32x32 pixel tiles (halo 5):
-//   k_ssim_fwd: x,y tile -> 5 windowed moments -> SSIM map; accumulates sum|x-y| and the
-//               SSIM sum; writes the three per-pixel derivative maps D = (dS/dmu_x,
-//               dS/dE[x^2], dS/dE[xy]) of the interior (zero elsewhere), 9 floats/pixel;
+// Row-streaming separable convolution.  A workgroup owns a strip 64 pixels wide (x3 interleaved
+// channels = 192 threads, one per (column, channel)) and walks down 64+10 image rows.  Each
+// row segment is staged once in LDS (coalesced: interleaved channels make the segment one
+// contiguous run), the 11-tap horizontal pass reads it from LDS, and the vertical pass never
+// touches LDS: every thread keeps the last 11 horizontal results in a register ring (the row
+// loop is unrolled by 11 so ring slots are compile-time indices).
+//   k_ssim_fwd: x,y -> 5 windowed moments -> SSIM map; accumulates sum|x-y| and the SSIM sum;
+//               writes the per-pixel derivative maps D = (dS/dmu_x, dS/dE[x^2], dS/dE[xy]) of the
+//               interior (zero elsewhere), 9 floats/pixel;
 //   k_ssim_bwd: v_x = k_l1*sign(x-y) + k_ss*( G*D0 + 2x G*D1 + y G*D2 )   (G symmetric).
 // The window never touches padding for interior outputs, so reflect-padding is not needed.
 #include "common.h"
 
-#define TS 32          // output tile
+#define LW 64                 // strip width in pixels
+#define LT (LW * 3)           // threads per workgroup: one per (column, channel)
+#define LH 64                 // output rows per workgroup
 #define HALO 5
-#define TIN (TS + 2 * HALO)  // 42
 #define KS 11
+#define SEG ((LW + 2 * HALO) * 3)   // floats per staged row segment of an image (222)
+#define SEGD ((LW + 2 * HALO) * 9)  // floats per staged row segment of D (666)
 
 struct Win { float w[KS]; };
 
@@ -26,160 +34,221 @@ static Win make_window() {
     return w;
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
+__device__ __forceinline__ float block_sum_192(float v, float* red) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
-    float t = (red[0] + red[1]) + (red[2] + red[3]);
+    const float t = (red[0] + red[1]) + red[2];
     __syncthreads();
     return t;
 }
 
-__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, const float* __restrict__ render,
-                                                  const float* __restrict__ gt, Win win,
-                                                  double* __restrict__ sums, float* __restrict__ D) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sx = smem;                       // [TIN][TIN*3]
-    float* sy = sx + TIN * TIN * 3;         // [TIN][TIN*3]
-    float* hp = sy + TIN * TIN * 3;         // [5][TIN][TS]
+__global__ __launch_bounds__(LT) void k_ssim_fwd(int H, int W, const float* __restrict__ render,
+                                                 const float* __restrict__ gt, Win win,
+                                                 double* __restrict__ sums, float* __restrict__ D) {
+    __shared__ float sx[2][SEG];
+    __shared__ float sy[2][SEG];
     __shared__ float red[4];
     const int cam = blockIdx.z;
-    const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+    const int j0 = blockIdx.x * LW, i0 = blockIdx.y * LH;
+    const int t = threadIdx.x;
+    const int col = t / 3, ch = t - col * 3;
+    const int j = j0 + col;
     const float* xr = render + (int64_t)cam * H * W * 3;
     const float* yr = gt + (int64_t)cam * H * W * 3;
-    for (int e = threadIdx.x; e < TIN * TIN * 3; e += 256) {
-        const int row = e / (TIN * 3), rem = e - row * (TIN * 3);
-        const int col = rem / 3;
-        const int i = i0 - HALO + row, j = j0 - HALO + col;
-        float vx = 0.f, vy = 0.f;
-        if (i >= 0 && i < H && j >= 0 && j < W) {
-            const int64_t q = ((int64_t)i * W + j) * 3 + (rem - col * 3);
-            vx = xr[q]; vy = yr[q];
-        }
-        sx[e] = vx; sy[e] = vy;
-    }
-    __syncthreads();
-    // L1 partial over the centre 32x32 of the tile (pixels outside the image hold 0,0)
-    float l1 = 0.f;
-    for (int e = threadIdx.x; e < TS * TS * 3; e += 256) {
-        const int row = e / (TS * 3), rem = e - row * (TS * 3);
-        const int a = (row + HALO) * (TIN * 3) + HALO * 3 + rem;
-        l1 += fabsf(sy[a] - sx[a]);
-    }
-    float ssim_acc = 0.f;
     const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
-    for (int ch = 0; ch < 3; ++ch) {
-        // horizontal pass: [TIN rows][TS cols]
-        for (int e = threadIdx.x; e < TIN * TS; e += 256) {
-            const int row = e / TS, col = e - row * TS;
-            const float* px = sx + row * (TIN * 3) + col * 3 + ch;
-            const float* py = sy + row * (TIN * 3) + col * 3 + ch;
-            float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    const int nrows = min(LH, H - i0) + 2 * HALO;  // input rows i0-5 .. i0+rows+4
+
+    // Input row r (image row i0 - HALO + r) travels HBM -> registers (prefetch, issued two rows
+    // ahead of its use so the load latency hides behind a whole row of arithmetic) -> LDS (commit).
+    constexpr int NPF = (SEG + LT - 1) / LT;
+    float pfx[NPF], pfy[NPF];
+    auto prefetch = [&](int r) {
+        const int i = i0 - HALO + r;
+        const bool row_ok = (r < nrows) && (i >= 0) && (i < H);
 #pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                const float x = px[k * 3], y = py[k * 3], w = win.w[k];
-                const float wx = w * x, wy = w * y;
-                s0 += wx; s1 += wy; s2 += wx * x; s3 += wy * y; s4 += wx * y;
+        for (int n = 0; n < NPF; ++n) {
+            const int e = t + n * LT;
+            const int jj = j0 - HALO + e / 3;
+            float vx = 0.f, vy = 0.f;
+            if (row_ok && e < SEG && jj >= 0 && jj < W) {
+                const int64_t q = ((int64_t)i * W + j0 - HALO) * 3 + e;
+                vx = xr[q]; vy = yr[q];
             }
-            hp[0 * TIN * TS + e] = s0; hp[1 * TIN * TS + e] = s1; hp[2 * TIN * TS + e] = s2;
-            hp[3 * TIN * TS + e] = s3; hp[4 * TIN * TS + e] = s4;
+            pfx[n] = vx; pfy[n] = vy;
         }
-        __syncthreads();
-        // vertical pass + SSIM
-        for (int e = threadIdx.x; e < TS * TS; e += 256) {
-            const int row = e / TS, col = e - row * TS;
-            const int i = i0 + row, j = j0 + col;
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-            const bool interior = (i >= HALO) && (i < H - HALO) && (j >= HALO) && (j < W - HALO);
-            if (interior) {
-                float mx = 0, my = 0, exx = 0, eyy = 0, exy = 0;
+    };
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int n = 0; n < NPF; ++n) {
+            const int e = t + n * LT;
+            if (e < SEG) { sx[b][e] = pfx[n]; sy[b][e] = pfy[n]; }
+        }
+    };
+
+    float ring[KS][5];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int m = 0; m < 5; ++m) ring[s][m] = 0.f;
+    float l1 = 0.f, ssim_acc = 0.f;
+
+    prefetch(0);
+    commit(0);
+    prefetch(1);
+    __syncthreads();
+    for (int rb = 0; rb < nrows; rb += KS) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int r = rb + s;
+            if (r < nrows) {
+                const int b = r & 1;
+                commit(b ^ 1);     // row r+1 (prefetched one iteration ago)
+                prefetch(r + 2);
+                // horizontal pass of input row r for this (column, channel)
+                const float* px = &sx[b][col * 3 + ch];
+                const float* py = &sy[b][col * 3 + ch];
+                float h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
-                    const int a = (row + k) * TS + col;
-                    const float w = win.w[k];
-                    mx += w * hp[0 * TIN * TS + a]; my += w * hp[1 * TIN * TS + a];
-                    exx += w * hp[2 * TIN * TS + a]; eyy += w * hp[3 * TIN * TS + a];
-                    exy += w * hp[4 * TIN * TS + a];
+                    const float x = px[k * 3], y = py[k * 3], w = win.w[k];
+                    const float wx = w * x, wy = w * y;
+                    h0 += wx; h1 += wy; h2 += wx * x; h3 += wy * y; h4 += wx * y;
                 }
-                const float sxx = exx - mx * mx, syy = eyy - my * my, sxy = exy - mx * my;
-                const float n1 = 2.f * mx * my + c1, n2 = 2.f * sxy + c2;
-                const float dd1 = mx * mx + my * my + c1, dd2 = sxx + syy + c2;
-                const float inv = 1.0f / (dd1 * dd2);
-                const float ssim = n1 * n2 * inv;
-                ssim_acc += ssim;
-                const float dn1 = n2 * inv, dn2 = n1 * inv;
-                const float g1 = -ssim / dd1, g2 = -ssim / dd2;
-                d0 = 2.f * my * (dn1 - dn2) + 2.f * mx * (g1 - g2);  // dS/dmu_x
-                d1 = g2;                                             // dS/dE[x^2]
-                d2 = 2.f * dn2;                                      // dS/dE[xy]
-            }
-            if (D && i < H && j < W) {
-                float* dst = D + ((((int64_t)cam * H + i) * W + j) * 3 + ch) * 3;
-                dst[0] = d0; dst[1] = d1; dst[2] = d2;
+                ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2; ring[s][3] = h3; ring[s][4] = h4;
+                const int i = i0 - HALO + r;  // image row just staged
+                if (i >= i0 && i < i0 + LH && i < H && j < W) l1 += fabsf(py[HALO * 3] - px[HALO * 3]);
+                if (r >= 2 * HALO) {
+                    const int io = i0 + r - 2 * HALO;  // output row
+                    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                    const bool interior = (io >= HALO) && (io < H - HALO) && (j >= HALO) && (j < W - HALO);
+                    if (interior) {
+                        float mx = 0, my = 0, exx = 0, eyy = 0, exy = 0;
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            const int slot = (s + 1 + k) % KS;  // input row r-10+k
+                            const float w = win.w[k];
+                            mx += w * ring[slot][0]; my += w * ring[slot][1]; exx += w * ring[slot][2];
+                            eyy += w * ring[slot][3]; exy += w * ring[slot][4];
+                        }
+                        const float sxx = exx - mx * mx, syy = eyy - my * my, sxy = exy - mx * my;
+                        const float n1 = 2.f * mx * my + c1, n2 = 2.f * sxy + c2;
+                        const float dd1 = mx * mx + my * my + c1, dd2 = sxx + syy + c2;
+                        const float inv = 1.0f / (dd1 * dd2);
+                        const float ssim = n1 * n2 * inv;
+                        ssim_acc += ssim;
+                        const float dn1 = n2 * inv, dn2 = n1 * inv;
+                        const float g1 = -ssim / dd1, g2 = -ssim / dd2;
+                        d0 = 2.f * my * (dn1 - dn2) + 2.f * mx * (g1 - g2);  // dS/dmu_x
+                        d1 = g2;                                             // dS/dE[x^2]
+                        d2 = 2.f * dn2;                                      // dS/dE[xy]
+                    }
+                    if (D && io < H && j < W) {
+                        float* dst = D + ((((int64_t)cam * H + io) * W + j) * 3 + ch) * 3;
+                        dst[0] = d0; dst[1] = d1; dst[2] = d2;
+                    }
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
-    const float tl1 = block_sum_256(l1, red);
-    const float tss = block_sum_256(ssim_acc, red);
+    const float tl1 = block_sum_192(l1, red);
+    const float tss = block_sum_192(ssim_acc, red);
     if (threadIdx.x == 0) {
         atomicAdd(&sums[2 * cam + 0], (double)tl1);
         atomicAdd(&sums[2 * cam + 1], (double)tss);
     }
 }
 
-__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, const float* __restrict__ render,
-                                                  const float* __restrict__ gt, const float* __restrict__ D,
-                                                  Win win, float k_l1, float k_ss,
-                                                  float* __restrict__ v_render) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sd = smem;                   // [TIN][TIN*9]
-    float* hp = sd + TIN * TIN * 9;     // [3][TIN][TS]
+__global__ __launch_bounds__(LT) void k_ssim_bwd(int H, int W, const float* __restrict__ render,
+                                                 const float* __restrict__ gt, const float* __restrict__ D,
+                                                 Win win, float k_l1, float k_ss,
+                                                 float* __restrict__ v_render) {
+    __shared__ float sd[2][SEGD];
     const int cam = blockIdx.z;
-    const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+    const int j0 = blockIdx.x * LW, i0 = blockIdx.y * LH;
+    const int t = threadIdx.x;
+    const int col = t / 3, ch = t - col * 3;
+    const int j = j0 + col;
     const float* Dc = D + (int64_t)cam * H * W * 9;
-    for (int e = threadIdx.x; e < TIN * TIN * 9; e += 256) {
-        const int row = e / (TIN * 9), rem = e - row * (TIN * 9);
-        const int col = rem / 9;
-        const int i = i0 - HALO + row, j = j0 - HALO + col;
-        float v = 0.f;
-        if (i >= 0 && i < H && j >= 0 && j < W) v = Dc[((int64_t)i * W + j) * 9 + (rem - col * 9)];
-        sd[e] = v;
-    }
-    __syncthreads();
-    for (int ch = 0; ch < 3; ++ch) {
-        for (int e = threadIdx.x; e < TIN * TS; e += 256) {
-            const int row = e / TS, col = e - row * TS;
-            const float* pd = sd + row * (TIN * 9) + col * 9 + ch * 3;
-            float s0 = 0, s1 = 0, s2 = 0;
+    const int nrows = min(LH, H - i0) + 2 * HALO;
+
+    constexpr int NPF = (SEGD + LT - 1) / LT;
+    float pf[NPF];
+    auto prefetch = [&](int r) {
+        const int i = i0 - HALO + r;
+        const bool row_ok = (r < nrows) && (i >= 0) && (i < H);
 #pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                const float w = win.w[k];
-                s0 += w * pd[k * 9]; s1 += w * pd[k * 9 + 1]; s2 += w * pd[k * 9 + 2];
-            }
-            hp[0 * TIN * TS + e] = s0; hp[1 * TIN * TS + e] = s1; hp[2 * TIN * TS + e] = s2;
+        for (int n = 0; n < NPF; ++n) {
+            const int e = t + n * LT;
+            const int jj = j0 - HALO + e / 9;
+            float v = 0.f;
+            if (row_ok && e < SEGD && jj >= 0 && jj < W) v = Dc[((int64_t)i * W + j0 - HALO) * 9 + e];
+            pf[n] = v;
         }
-        __syncthreads();
-        for (int e = threadIdx.x; e < TS * TS; e += 256) {
-            const int row = e / TS, col = e - row * TS;
-            const int i = i0 + row, j = j0 + col;
-            if (i < H && j < W) {
-                float a0 = 0, a1 = 0, a2 = 0;
+    };
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int n = 0; n < NPF; ++n) {
+            const int e = t + n * LT;
+            if (e < SEGD) sd[b][e] = pf[n];
+        }
+    };
+
+    float ring[KS][3];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
+
+    float xn = 0.f, yn = 0.f;
+    prefetch(0);
+    commit(0);
+    prefetch(1);
+    __syncthreads();
+    for (int rb = 0; rb < nrows; rb += KS) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int r = rb + s;
+            if (r < nrows) {
+                const int b = r & 1;
+                commit(b ^ 1);
+                prefetch(r + 2);
+                // x, y of the output pixel of this iteration were requested one iteration ago
+                const float x = xn, y = yn;
+                {
+                    const int ion = i0 + r + 1 - 2 * HALO;  // next iteration's output row
+                    if (ion >= i0 && ion < H && j < W) {
+                        const int64_t qn = (((int64_t)cam * H + ion) * W + j) * 3 + ch;
+                        xn = render[qn]; yn = gt[qn];
+                    }
+                }
+                const float* pd = &sd[b][col * 9 + ch * 3];
+                float h0 = 0, h1 = 0, h2 = 0;
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
-                    const int a = (row + k) * TS + col;
                     const float w = win.w[k];
-                    a0 += w * hp[0 * TIN * TS + a]; a1 += w * hp[1 * TIN * TS + a]; a2 += w * hp[2 * TIN * TS + a];
+                    h0 += w * pd[k * 9]; h1 += w * pd[k * 9 + 1]; h2 += w * pd[k * 9 + 2];
                 }
-                const int64_t q = (((int64_t)cam * H + i) * W + j) * 3 + ch;
-                const float x = render[q], y = gt[q];
-                const float sgn = (x > y) ? 1.0f : ((x < y) ? -1.0f : 0.0f);
-                v_render[q] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
+                ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2;
+                if (r >= 2 * HALO) {
+                    const int io = i0 + r - 2 * HALO;
+                    if (io < H && j < W) {
+                        float a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            const int slot = (s + 1 + k) % KS;
+                            const float w = win.w[k];
+                            a0 += w * ring[slot][0]; a1 += w * ring[slot][1]; a2 += w * ring[slot][2];
+                        }
+                        const int64_t q = (((int64_t)cam * H + io) * W + j) * 3 + ch;
+                        const float sgn = (x > y) ? 1.0f : ((x < y) ? -1.0f : 0.0f);
+                        v_render[q] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
+                    }
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
 }
 
@@ -194,23 +263,15 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
         if (rc) return rc;
         D = (float*)p;
     }
-    dim3 grid(ceil_div(W, TS), ceil_div(H, TS), C);
-    const size_t sh_f = sizeof(float) * (2 * TIN * TIN * 3 + 5 * TIN * TS);
-    const size_t sh_b = sizeof(float) * (TIN * TIN * 9 + 3 * TIN * TS);
-    static bool attr_set = false;
-    if (!attr_set) {  // both kernels need more than the default 64 KiB of dynamic LDS
-        HIP_TRY(hipFuncSetAttribute((const void*)k_ssim_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_b));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_ssim_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_f));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), sh_f, s, H, W, render, gt, win, sums, D);
+    dim3 grid(ceil_div(W, LW), ceil_div(H, LH), C);
+    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(LT), 0, s, H, W, render, gt, win, sums, D);
     LAUNCH_CHECK();
     if (v_render) {
         const int Hi = H - 2 * HALO, Wi = W - 2 * HALO;
         const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
         const float k_l1 = (float)((double)w_l1 / ((double)H * W * 3));
         const float k_ss = cnt > 0 ? (float)(-(double)w_ssim / cnt) : 0.f;
-        hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), sh_b, s, H, W, render, gt, D, win, k_l1, k_ss, v_render);
+        hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(LT), 0, s, H, W, render, gt, D, win, k_l1, k_ss, v_render);
         LAUNCH_CHECK();
     }
     return ST3R_OK;

@@ -142,13 +142,13 @@ def blend_fwd(ctx, splats, off, flat, Cn, W, H):
     return rgb, alpha, last
 
 
-def blend_bwd(ctx, splats, off, flat, alpha, last, v_rgb, v_alpha, Cn, W, H):
+def blend_bwd(ctx, splats, off, flat, alpha, last, v_rgb, v_alpha, cum, Cn, W, H):
     tw, th = tile_grid(W, H)
     v_splats = torch.empty_like(splats)
     _lib.check(_lib.lib().st3r_gs_blend_bwd(ctx.handle, _stream(), Cn, W, H, TILE, tw, th, _p(splats),
                                             _p(off, torch.int32), _p(flat, torch.int32), flat.numel(), _p(alpha),
-                                            _p(last, torch.int32), _p(v_rgb), _p(v_alpha), splats.shape[0],
-                                            _p(v_splats)))
+                                            _p(last, torch.int32), _p(v_rgb), _p(v_alpha), _p(cum, torch.int32),
+                                            splats.shape[0], _p(v_splats)))
     return v_splats
 
 
@@ -253,5 +253,5 @@ def rasterization(ctx, means, quats, scales, opacities, colors, viewmats, Ks, wi
             tile_size=TILE, n_cameras=Cn,
             # dense-id extras used by the backward / tests
             _splats=splats, _flatten_ids_dense=flat_s, _last_ids=last, _isect_ids_unsorted=ids,
-            _flatten_ids_dense_unsorted=flat, _packed_of_dense=packed_of_dense, _campos=campos)
+            _flatten_ids_dense_unsorted=flat, _packed_of_dense=packed_of_dense, _campos=campos, _cum_tiles=cum)
     return rgb, alpha, info

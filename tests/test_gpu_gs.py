@@ -103,7 +103,7 @@ def test_backward_vs_oracle(ctx, name):
     P, rgb, alpha, info = run_hip(ctx, g, w2c, Ks, W, H)
     Cn, N = w2c.shape[0], g["means"].shape[0]
     v_splats = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
-                             info["_last_ids"], dev(v_rgb), dev(v_alpha), Cn, W, H)
+                             info["_last_ids"], dev(v_rgb), dev(v_alpha), info["_cum_tiles"], Cn, W, H)
     torch.cuda.synchronize()
     # per-pair gradients: compare in packed order
     pid = (info["camera_ids"].long() * N + info["gaussian_ids"].long())
@@ -135,9 +135,9 @@ def test_backward_deterministic_enough(ctx):
     v_rgb = torch.randn_like(rgb)
     Cn = w2c.shape[0]
     a = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
-                      info["_last_ids"], v_rgb, None, Cn, W, H)
+                      info["_last_ids"], v_rgb, None, info["_cum_tiles"], Cn, W, H)
     b = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
-                      info["_last_ids"], v_rgb, None, Cn, W, H)
+                      info["_last_ids"], v_rgb, None, info["_cum_tiles"], Cn, W, H)
     torch.cuda.synchronize()
     scale = a.abs().max()
     assert float((a - b).abs().max() / scale) < 1e-5

@@ -14,7 +14,7 @@ v_alpha=rng.standard_normal(alpha_o.shape).astype(np.float32)
 gg=go.rasterization_backward(g["means"],g["quats"],g["scales"],g["opacities"],g["shN"],w2c,Ks,W,H,meta,alpha_o,v_rgb,v_alpha)
 P={k:dev(v) for k,v in g.items()}
 rgb,alpha,info=ops.rasterization(ctx,P["means"],P["quats"],P["scales"],P["opacities"],P["shN"],dev(w2c),dev(Ks),W,H)
-vs=ops.blend_bwd(ctx,info["_splats"],info["isect_offsets"],info["_flatten_ids_dense"],alpha,info["_last_ids"],dev(v_rgb),dev(v_alpha),V,W,H)
+vs=ops.blend_bwd(ctx,info["_splats"],info["isect_offsets"],info["_flatten_ids_dense"],alpha,info["_last_ids"],dev(v_rgb),dev(v_alpha),info["_cum_tiles"],V,W,H)
 torch.cuda.synchronize()
 pid=(info["camera_ids"].long()*N+info["gaussian_ids"].long())
 vs=vs[pid].cpu().numpy()
