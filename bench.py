@@ -52,11 +52,14 @@ def parse():
 def algorithmic_bytes(N, V, I, P, Ct, keybits):
     """algorithmic HBM bytes per iteration, per stage (C local views)."""
     passes = math.ceil(keybits / 8)
+    sort_total = 24 * passes * I     # SURVEY 8(d): LSD radix over the 64-bit key, 8-bit digits
+    sort_depth = 24 * 5 * V          # level 1 of the two-level sort: (camera | depth) keys, 5 passes
     return {
         "project": 92 * N + 44 * V,
         "scan": 8 * V,
         "emit": 8 * V + 12 * I,
-        "sort": 24 * passes * I,
+        "sort_depth": sort_depth,
+        "sort": sort_total - sort_depth,
         "offsets": 8 * I + 4 * Ct,
         "blend_fwd": 40 * I + 20 * P,
         "loss": 36 * P,

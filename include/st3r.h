@@ -62,12 +62,17 @@ int st3r_ctx_destroy(st3r_ctx* ctx);
 /* bytes currently held by the ctx arena (diagnostics) */
 int64_t st3r_ctx_arena_bytes(st3r_ctx* ctx);
 
+/* Test hook: copy `bytes` of a scratch buffer left by the last fused step (st3r_gs_train_fwd_bwd /
+ * st3r_gs_render) into caller memory `dst` (device).  which: 0 sorted pair ids int32 [n_isects],
+ * 1 tile offsets int32 [C*tiles], 2 splat records float [C*N*12], 3 inclusive tile scan int32 [C*N]. */
+int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t bytes);
+
 /* Per-stage timing with HIP events recorded on the caller's stream around every stage of the
  * fused steps (no host synchronisation while enabled).  st3r_ctx_get_stage_ms synchronises
  * the device, writes the accumulated milliseconds and sample counts of the ST3R_NUM_STAGES
  * stages and resets them.  Stage order: project, scan, emit, sort, offsets, blend_fwd, loss,
- * blend_bwd, project_bwd, adam (names from st3r_stage_name). */
-#define ST3R_NUM_STAGES 10
+ * blend_bwd, project_bwd, adam, sort_depth (names from st3r_stage_name). */
+#define ST3R_NUM_STAGES 11
 int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
 int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* counts_out);
 const char* st3r_stage_name(int stage);

@@ -82,9 +82,21 @@ int st3r_arena_get2(st3r_ctx* ctx, int slot, size_t bytes, void** out, int* grow
     return ST3R_OK;
 }
 
+// Debug/test hook: device pointer and capacity of a scratch buffer of the last fused step.
+// which: 0 = sorted pair ids ("flatten ids", int32 [n_isects]), 1 = tile offsets (int32 [C*tiles]),
+//        2 = splat records (float [C*N*12]), 3 = inclusive tile scan in pair-id order (int32 [C*N])
+ST3R_EXPORT int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t bytes) {
+    ARG_CHECK(ctx && dst && bytes >= 0 && which >= 0 && which <= 3);
+    static const int slots[4] = {SLOT_VALS_B, SLOT_OFFSETS, SLOT_SPLATS, SLOT_CUM};
+    ARG_CHECK((size_t)bytes <= ctx->slot_bytes[slots[which]]);
+    HIP_TRY(hipMemcpyAsync(dst, ctx->slot_ptr[slots[which]], (size_t)bytes, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return ST3R_OK;
+}
+
 // ---- per-stage event timing ----
 static const char* k_stage_names[STG_COUNT] = {"project", "scan", "emit", "sort", "offsets", "blend_fwd", "loss",
-                                               "blend_bwd", "project_bwd", "adam"};
+                                               "blend_bwd", "project_bwd", "adam", "sort_depth"};
 
 ST3R_EXPORT const char* st3r_stage_name(int stage) {
     return (stage >= 0 && stage < STG_COUNT) ? k_stage_names[stage] : "";
@@ -151,6 +163,22 @@ int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t
                    int64_t* keys_out, int32_t* vals_out);
 int st3r_isect_offsets_impl(hipStream_t s, int64_t n_isects, const int64_t* ids, int C, int tile_w, int tile_h,
                             int32_t* offsets);
+int st3r_project_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
+                      const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
+                      const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
+                      float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
+                      uint64_t* depth_keys, int32_t* depth_vals);
+int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
+                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out);
+int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
+                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h,
+                                uint32_t* tile_keys, int32_t* vals);
+int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
+                              int32_t* offsets);
+int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint64_t* keys_in, int32_t* vals_in,
+                         uint64_t* keys_out, int32_t* vals_out);
+int st3r_sort_tile_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
+                        uint32_t* keys_out, int32_t* vals_out);
 int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         float* rgb, float* alpha, int32_t* last_ids, bool for_backward);
@@ -188,41 +216,58 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_TILES, int32_t, n_pairs, tiles);
     GET(SLOT_CUM, int32_t, n_pairs, cum);
     GET(SLOT_OFFSETS, int32_t, (int64_t)C * tile_w * tile_h, offsets);
+    // Two-level sort (see gs_isect.hip): pairs by (camera | depth) first, then the emitted records by
+    // their 32-bit (camera, tile) key with a stable sort -- the same final order as gsplat's single
+    // 64-bit (camera | tile | depth) sort at roughly a quarter of the sort traffic.
+    GET(SLOT_DKEYS_A, uint64_t, n_pairs, dkeys_a);
+    GET(SLOT_DKEYS_B, uint64_t, n_pairs, dkeys_b);
+    GET(SLOT_DVALS_A, int32_t, n_pairs, dvals_a);
+    GET(SLOT_DVALS_B, int32_t, n_pairs, perm);
+    GET(SLOT_CUM_D, int32_t, n_pairs, cum_d);
     st3r_prof_begin(ctx, s, STG_PROJECT);
-    int rc = st3r_gs_project_sh(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
-                                H, tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums);
+    int rc = st3r_project_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
+                               tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums, dkeys_a, dvals_a);
     st3r_prof_end(ctx, s, STG_PROJECT);
+    if (rc) return rc;
+    st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
+    rc = st3r_sort_depth_impl(ctx, s, n_pairs, 32 + bit_length_u32((uint32_t)(C - 1)), dkeys_a, dvals_a, dkeys_b,
+                              perm);
+    st3r_prof_end(ctx, s, STG_SORT_DEPTH);
     if (rc) return rc;
     int64_t n_isects = 0;
     st3r_prof_begin(ctx, s, STG_SCAN);
+    // pair-id order scan: slot base of every pair for the backward pass's per-(record, tile) partials
     rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, nullptr);
+    if (rc) return rc;
+    // depth order scan: write positions of the emit kernel
+    int32_t* total_dev = nullptr;
+    rc = st3r_isect_scan_perm_impl(ctx, s, n_pairs, tiles, perm, cum_d, &total_dev);
     st3r_prof_end(ctx, s, STG_SCAN);
     if (rc) return rc;
     {   // read back the intersection count (and the visible-pair count) -- the one host sync per step
-        int32_t* total_dev = (int32_t*)ctx->slot_ptr[SLOT_SCAN_TMP] + ceil_div(n_pairs, 4096);
         HIP_TRY(hipMemcpyAsync(ctx->pinned, total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (reg_sums) HIP_TRY(hipMemcpyAsync(ctx->pinned + 1, reg_sums + 2, sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         n_isects = (int64_t)((int32_t*)ctx->pinned)[0];
         o->n_visible = reg_sums ? (int64_t)((double*)ctx->pinned)[1] : -1;
     }
-    GET(SLOT_KEYS_A, int64_t, n_isects, keys_a);
-    GET(SLOT_KEYS_B, int64_t, n_isects, keys_b);
+    GET(SLOT_KEYS_A, uint32_t, n_isects, tkeys_a);
+    GET(SLOT_KEYS_B, uint32_t, n_isects, tkeys_b);
     GET(SLOT_VALS_A, int32_t, n_isects, vals_a);
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
     if (n_isects > 0) {
         st3r_prof_begin(ctx, s, STG_EMIT);
-        rc = st3r_isect_emit_impl(s, N, C, splats, cum, tile, tile_w, tile_h, keys_a, vals_a);
+        rc = st3r_isect_emit_sorted_impl(s, N, C, splats, perm, cum_d, tile, tile_w, tile_h, tkeys_a, vals_a);
         st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
-        const int end_bit = 32 + bit_length_u32((uint32_t)(tile_w * tile_h)) + bit_length_u32((uint32_t)C);
+        const int end_bit = bit_length_u32((uint32_t)((int64_t)C * tile_w * tile_h - 1));
         st3r_prof_begin(ctx, s, STG_SORT);
-        rc = st3r_sort_impl(ctx, s, n_isects, end_bit, keys_a, vals_a, keys_b, vals_b);
+        rc = st3r_sort_tile_impl(ctx, s, n_isects, end_bit, tkeys_a, vals_a, tkeys_b, vals_b);
         st3r_prof_end(ctx, s, STG_SORT);
         if (rc) return rc;
     }
     st3r_prof_begin(ctx, s, STG_OFFSETS);
-    rc = st3r_isect_offsets_impl(s, n_isects, keys_b, C, tile_w, tile_h, offsets);
+    rc = st3r_isect_offsets32_impl(s, n_isects, tkeys_b, C, tile_w, tile_h, offsets);
     st3r_prof_end(ctx, s, STG_OFFSETS);
     if (rc) return rc;
     o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->n_isects = n_isects;

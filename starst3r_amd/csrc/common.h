@@ -52,6 +52,11 @@ enum ArenaSlot {
     SLOT_CMASK,
     SLOT_TILE_NB,
     SLOT_VTILE,
+    SLOT_DKEYS_A,
+    SLOT_DKEYS_B,
+    SLOT_DVALS_A,
+    SLOT_DVALS_B,
+    SLOT_CUM_D,
     SLOT_COUNT
 };
 
@@ -67,6 +72,7 @@ enum Stage {
     STG_BLEND_BWD,
     STG_PROJECT_BWD,
     STG_ADAM,
+    STG_SORT_DEPTH,
     STG_COUNT
 };
 #define PROF_RING 64

@@ -37,14 +37,22 @@ __device__ __forceinline__ int block_incl_scan(int v, int* total) {
     return inc + base;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int32_t* __restrict__ in, int64_t n,
-                                                              int32_t* __restrict__ block_sums) {
+// `perm` (optional): scan in[perm[idx]] instead of in[idx] (tile counts visited in depth order)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int32_t* __restrict__ in,
+                                                              const int32_t* __restrict__ perm, int64_t n,
+                                                              int32_t* __restrict__ block_sums,
+                                                              int32_t* __restrict__ gathered) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
     int s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
-        if (idx < n) s += in[idx];
+        if (idx < n) {
+            int v;
+            if (perm) { v = in[perm[idx]]; gathered[idx] = v; }  // the downsweep then reads contiguously
+            else v = in[idx];
+            s += v;
+        }
     }
     int total;
     block_incl_scan(s, &total);
@@ -66,9 +74,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(int32_t* __rest
     if (threadIdx.x == 0) total_out[0] = carry;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* __restrict__ in, int64_t n,
-                                                            const int32_t* __restrict__ block_sums,
-                                                            int32_t* __restrict__ out) {
+// (in may alias out: every thread loads all of its items before it stores any)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, const int32_t* __restrict__ perm,
+                                                            int64_t n, const int32_t* __restrict__ block_sums,
+                                                            int32_t* out) {
     // thread t owns SCAN_ITEMS consecutive elements so the scan order is the array order
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* __res
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         int64_t idx = base + i;
-        v[i] = idx < n ? in[idx] : 0;
+        v[i] = idx < n ? (perm ? in[perm[idx]] : in[idx]) : 0;
         s += v[i];
     }
     int total;
@@ -91,26 +100,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* __res
 }
 
 // out = inclusive scan(in); the grand total is left in the SLOT_SCAN_TMP buffer at [nblocks]
-int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, int32_t* out, int64_t n,
-                            int32_t** total_dev) {
+int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, const int32_t* perm, int32_t* out,
+                            int64_t n, int32_t** total_dev) {
     int nblocks = ceil_div(n, SCAN_TILE);
     void* tmp;
     int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, sizeof(int32_t) * (size_t)(nblocks + 4), &tmp);
     if (rc) return rc;
     int32_t* bs = (int32_t*)tmp;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, n, bs);
+    // with a permutation the gathered values are parked in `out` by the reduce pass and scanned in place
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, perm, n, bs, out);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_THREADS), 0, s, bs, nblocks, bs + nblocks);
-    hipLaunchKernelGGL(k_scan_down, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, n, bs, out);
+    hipLaunchKernelGGL(k_scan_down, dim3(nblocks), dim3(SCAN_THREADS), 0, s, perm ? out : in,
+                       (const int32_t*)nullptr, n, bs, out);
     LAUNCH_CHECK();
     if (total_dev) *total_dev = bs + nblocks;
     return ST3R_OK;
+}
+
+// inclusive scan of tiles[perm[.]] (perm may be NULL); optional synchronous read-back of the total
+int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
+                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out) {
+    if (n_pairs == 0) return ST3R_OK;
+    return st3r_scan_inclusive_i32(ctx, s, tiles, perm, cum, n_pairs, total_dev_out);
 }
 
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
                          int64_t* n_isects_host) {
     if (n_pairs == 0) { if (n_isects_host) *n_isects_host = 0; return ST3R_OK; }
     int32_t* total_dev = nullptr;
-    int rc = st3r_scan_inclusive_i32(ctx, s, tiles, cum, n_pairs, &total_dev);
+    int rc = st3r_scan_inclusive_i32(ctx, s, tiles, nullptr, cum, n_pairs, &total_dev);
     if (rc) return rc;
     if (n_isects_host) {
         int32_t* pin = (int32_t*)ctx->pinned;
@@ -227,4 +245,85 @@ ST3R_EXPORT int st3r_gs_offsets(st3r_ctx* ctx, void* stream, int64_t n_isects, c
     ARG_CHECK(ctx && n_isects >= 0 && C > 0 && tile_w > 0 && tile_h > 0 && offsets);
     ARG_CHECK(n_isects == 0 || isect_ids_sorted);
     return st3r_isect_offsets_impl((hipStream_t)stream, n_isects, isect_ids_sorted, C, tile_w, tile_h, offsets);
+}
+
+// ------------------------------------------------------------------------------------
+// Two-level sort of the fused path (same final order as the 64-bit key sort above):
+//   1. pairs are sorted by (camera | depth bits) once            -> perm[s] = pair id
+//   2. records are emitted in that order with a 32-bit key        camera * n_tiles + tile
+//   3. a STABLE sort on that key groups them by (camera, tile) and keeps depth order inside
+// Ties (same camera, tile, depth bits) keep pair-id order in both schemes: step 1 is stable
+// on pair id, steps 2/3 preserve it.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_isect_emit_sorted(int N, int64_t n_pairs,
+                                                           const float4* __restrict__ splats,
+                                                           const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ cum_sorted, int tile_size,
+                                                           int tile_w, int tile_h,
+                                                           uint32_t* __restrict__ tile_keys,
+                                                           int32_t* __restrict__ vals) {
+    const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= n_pairs) return;
+    const int end = cum_sorted[sidx];
+    const int start = sidx == 0 ? 0 : cum_sorted[sidx - 1];
+    if (end == start) return;
+    const int64_t pid = perm[sidx];
+    const float4 r0 = splats[pid * 3 + 0];
+    const float4 r2 = splats[pid * 3 + 2];
+    const float radius = (float)__float_as_int(r2.z);
+    const float tile_radius = radius / (float)tile_size;
+    const float tile_x = r0.x / (float)tile_size, tile_y = r0.y / (float)tile_size;
+    const int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
+    const int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
+    const int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
+    const int y1 = tile_clampi(ceilf(tile_y + tile_radius), tile_h);
+    const uint32_t cam_base = (uint32_t)(pid / N) * (uint32_t)(tile_w * tile_h);
+    int cur = start;
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            tile_keys[cur] = cam_base + (uint32_t)(ty * tile_w + tx);
+            vals[cur] = (int32_t)pid;
+            ++cur;
+        }
+}
+
+int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
+                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h,
+                                uint32_t* tile_keys, int32_t* vals) {
+    const int64_t n_pairs = (int64_t)N * C;
+    if (n_pairs == 0) return ST3R_OK;
+    hipLaunchKernelGGL(k_isect_emit_sorted, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs,
+                       (const float4*)splats, perm, cum_sorted, tile_size, tile_w, tile_h, tile_keys, vals);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+// offsets[k] = first sorted position whose 32-bit (camera, tile) key is >= k
+__global__ __launch_bounds__(256) void k_isect_offsets32(int64_t n_isects, const uint32_t* __restrict__ keys,
+                                                         int64_t total, int32_t* __restrict__ offsets) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_isects) return;
+    const int64_t id_curr = keys[idx];
+    if (idx == 0) {
+        for (int64_t i = 0; i <= id_curr; ++i) offsets[i] = 0;
+    } else {
+        const int64_t id_prev = keys[idx - 1];
+        if (id_prev != id_curr)
+            for (int64_t i = id_prev + 1; i <= id_curr; ++i) offsets[i] = (int32_t)idx;
+    }
+    if (idx == n_isects - 1)
+        for (int64_t i = id_curr + 1; i < total; ++i) offsets[i] = (int32_t)n_isects;
+}
+
+int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
+                              int32_t* offsets) {
+    const int64_t total = (int64_t)C * tile_w * tile_h;
+    if (n_isects == 0) {
+        HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)total, s));
+        return ST3R_OK;
+    }
+    hipLaunchKernelGGL(k_isect_offsets32, dim3(ceil_div(n_isects, 256)), dim3(256), 0, s, n_isects, keys, total,
+                       offsets);
+    LAUNCH_CHECK();
+    return ST3R_OK;
 }

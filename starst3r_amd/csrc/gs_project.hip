@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
     int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     const float* __restrict__ campos, int W, int H, int tile_size, int tile_w, int tile_h, float eps2d,
     float near_plane, float far_plane, float radius_clip, float4* __restrict__ splats,
-    int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_sums) {
+    int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_sums,
+    uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals) {
     extern __shared__ float cam[];
     __shared__ float red[8];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -191,12 +192,35 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         splats[pid * 3 + 1] = r1;
         splats[pid * 3 + 2] = r2;
         tiles_per_gauss[pid] = ntiles;
+        if (depth_keys) {  // (camera | depth bits) key of the two-level sort; culled pairs sort last
+            const uint32_t dbits = valid ? (uint32_t)__float_as_int(z) : 0xFFFFFFFFu;
+            depth_keys[pid] = ((uint64_t)c << 32) | dbits;
+            depth_vals[pid] = (int32_t)pid;
+        }
         n_vis += valid ? 1 : 0;
     }
     if (reg_sums) {  // number of visible (camera, gaussian) pairs -> reg_sums[2]
         for (int off = 32; off > 0; off >>= 1) n_vis += __shfl_down(n_vis, off);
         if ((threadIdx.x & 63) == 0 && n_vis) atomicAdd(&reg_sums[2], (double)n_vis);
     }
+}
+
+// depth_keys/depth_vals (optional, [C*N]): per-pair (camera | depth bits) key and pair id for the
+// two-level sort of the fused path
+int st3r_project_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
+                      const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
+                      const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
+                      float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
+                      uint64_t* depth_keys, int32_t* depth_vals) {
+    if (N == 0) return ST3R_OK;
+    int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+    dim3 grid(ceil_div(N, 256)), block(256);
+    size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
+    hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
+                       viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
+                       radius_clip, (float4*)splats, tiles_per_gauss, reg_sums, depth_keys, depth_vals);
+    LAUNCH_CHECK();
+    return ST3R_OK;
 }
 
 ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, const float* means,
@@ -207,14 +231,7 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
                                    int32_t* tiles_per_gauss, double* reg_sums) {
     ARG_CHECK(ctx && N >= 0 && C > 0 && C <= 1024 && sh_stride >= 12 && width > 0 && height > 0 && tile_size > 0);
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
-    if (N == 0) return ST3R_OK;
-    int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(ceil_div(N, 256)), block(256);
-    size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
-    hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
-                       viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
-                       radius_clip, (float4*)splats, tiles_per_gauss, reg_sums);
-    LAUNCH_CHECK();
-    return ST3R_OK;
+    return st3r_project_impl((hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
+                             campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,
+                             tiles_per_gauss, reg_sums, nullptr, nullptr);
 }

@@ -199,13 +199,20 @@ def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fa
     return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]))
 
 
+def peek(ctx, which, count, dtype=torch.int32):
+    """Copy `count` elements of a ctx scratch buffer (see st3r_ctx_peek) into a new tensor (tests only)."""
+    out = torch.empty((count,), dtype=dtype, device=ctx.device)
+    _lib.check(_lib.lib().st3r_ctx_peek(ctx.handle, _stream(), which, _p(out, dtype), out.numel() * out.element_size()))
+    return out
+
+
 def set_profiling(ctx, enable):
     _lib.check(_lib.lib().st3r_ctx_set_profiling(ctx.handle, 1 if enable else 0))
 
 
 def stage_ms(ctx):
     """-> {stage: (total_ms, samples)} accumulated since the last call (synchronises the device)."""
-    n = 10
+    n = 11  # ST3R_NUM_STAGES
     ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
     _lib.check(_lib.lib().st3r_ctx_get_stage_ms(ctx.handle, ms, cnt))
     return {_lib.lib().st3r_stage_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}

@@ -71,6 +71,30 @@ def test_projection_tiles_sort_offsets_bit_exact(ctx, name):
     assert meta["isect_ids"].size > 0
 
 
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one"])
+def test_fused_two_level_sort_matches_reference_order(ctx, name):
+    """The fused render/train path sorts in two levels ((camera|depth) then a stable (camera,tile)
+    pass); its sorted pair ids and tile offsets must equal the oracle's single 64-bit-key sort."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make(name)
+    rgb_o, alpha_o, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks,
+                                            W, H, want_margin=True)
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    rgb, alpha, st = ops.render(ctx, P, vm, K, ops.camera_positions(vm), W, H)
+    n = st["n_isects"]
+    assert n == meta["isect_ids"].size
+    N = g["means"].shape[0]
+    flat_dense = ops.peek(ctx, 0, n).cpu().numpy()
+    off = ops.peek(ctx, 1, meta["isect_offsets"].size).cpu().numpy()
+    # oracle flatten ids are packed indices: map to dense pair ids cam*N + gaussian
+    dense_of_packed = meta["camera_ids"].astype(np.int64) * N + meta["gaussian_ids"]
+    assert np.array_equal(flat_dense, dense_of_packed[meta["flatten_ids"]])
+    assert np.array_equal(off, meta["isect_offsets"].reshape(-1))
+    ok = meta["margin"] > 1e-4
+    np.testing.assert_allclose(rgb.cpu().numpy()[ok], rgb_o[ok], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["small", "ragged", "medium"])
 def test_blend_forward(ctx, name):
     g, w2c, Ks, W, H = make(name)
