@@ -34,9 +34,6 @@
 #include "common.h"
 
 #define BLK 256
-#ifndef ST3R_EXP
-#define ST3R_EXP 0  // timing experiments only (1: no HBM flush, 2: +no LDS atomics, 3: +no reduction)
-#endif
 #define LOG2E 1.4426950408889634f
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -50,6 +47,15 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
+
+#ifdef ST3R_STATS
+__device__ unsigned long long g_blend_stats[8];
+ST3R_EXPORT int st3r_debug_blend_stats(unsigned long long* out_host, int reset) {
+    if (out_host) (void)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_blend_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 struct TileGeom {
     int lb, cam, i, j, start, end, tx0, ty0;
@@ -124,6 +130,9 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
     float T = 1.0f, r = 0.f, gg = 0.f, b = 0.f;
     int cur = 0;
     int nb = 0;
+#ifdef ST3R_STATS
+    unsigned long long st_rel = 0, st_any = 0, st_con = 0, st_lanes = 0, st_take = 0;
+#endif
     const int64_t mbase = mask_base(g.lb, g.start);
     for (int bs = g.start; bs < g.end; bs += BLK, ++nb) {
         if (__syncthreads_and(done)) break;
@@ -148,7 +157,13 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                 const float P = dx * (a.w * dx + q.x * dy) + q.y * dy * dy;
                 const float alpha = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
                 const bool valid = !done && !(P > 0.f) && !(alpha < 1.f / 255.f);
+#ifdef ST3R_STATS
+                st_rel++; st_lanes += __popcll(__ballot(valid));
+#endif
                 if (!__any(valid)) continue;
+#ifdef ST3R_STATS
+                st_any++;
+#endif
                 const float nT = T * (1.0f - alpha);
                 const bool stop = valid && (nT <= 1e-4f);
                 const bool take = valid && !stop;
@@ -160,6 +175,10 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                     T = nT;
                 }
                 if (__any(take)) contributed |= (1ull << bit);
+#ifdef ST3R_STATS
+                if (__any(take)) st_con++;
+                st_take += __popcll(__ballot(take));
+#endif
             }
             if (cmask && lane == 0) cmask[(int64_t)w * cmask_words + mbase + nb * 4 + jj] = contributed;
         }
@@ -171,6 +190,15 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
         last_ids[p] = cur;
     }
     if (tile_nb && threadIdx.x == 0) tile_nb[g.lb] = nb;
+#ifdef ST3R_STATS
+    if (lane == 0) {
+        atomicAdd(&g_blend_stats[0], (unsigned long long)(w == 0 ? nb : 0));
+        atomicAdd(&g_blend_stats[1], st_rel); atomicAdd(&g_blend_stats[2], st_any);
+        atomicAdd(&g_blend_stats[3], st_con); atomicAdd(&g_blend_stats[4], st_lanes);
+        atomicAdd(&g_blend_stats[5], st_take);
+        atomicAdd(&g_blend_stats[6], (unsigned long long)(w == 0 ? (g.end - g.start) : 0));
+    }
+#endif
 }
 
 // scratch for the forward->backward hand-off lives in the ctx
@@ -228,14 +256,30 @@ __device__ __forceinline__ float dpp_f(float v) {
 // __builtin_amdgcn_permlane32_swap / permlane16_swap came back equal to the first (measured, see
 // tools/probe/swap_probe.hip); the instruction itself behaves as documented.  "s_nop 1" = the two
 // wait states a VALU-written operand needs before v_permlane*_swap reads it.
-__device__ __forceinline__ float fold32(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-// rows (16 lanes) 0,2 end up with a summed over the row pair (0,1)/(2,3); rows 1,3 with b
-__device__ __forceinline__ float fold16(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;
+// The swaps of one butterfly level are independent of each other, so they are issued as one asm block
+// behind a single "s_nop 1".
+//
+// reduce9: sums g[0..8] over the 64 lanes.  On return, in every 16-lane row r:
+//   k0 holds the total of g[{0,2,1,3}[r]], k1 that of g[{4,6,5,7}[r]], k2 (row 0 only) that of g[8].
+__device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, float g4, float g5, float g6,
+                                        float g7, float g8, float& k0, float& k1, float& k2) {
+    float z0 = 0.f, z1 = 0.f;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\t"
+        "v_permlane32_swap_b32 %2, %3\n\t"
+        "v_permlane32_swap_b32 %4, %5\n\t"
+        "v_permlane32_swap_b32 %6, %7\n\t"
+        "v_permlane32_swap_b32 %8, %9"
+        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "+v"(z0));
+    float h0 = g0 + g1, h1 = g2 + g3, h2 = g4 + g5, h3 = g6 + g7, h4 = g8 + z0;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5"
+        : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(z1));
+    k0 = h0 + h1; k1 = h2 + h3; k2 = h4 + z1;
 }
 // every lane of a 16-lane row receives the row sum
 __device__ __forceinline__ float row_allsum(float v) {
@@ -292,6 +336,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     }
     float T = T_final;
     float bufr = 0.f, bufg = 0.f, bufb = 0.f;
+    const bool has_va = v_alpha != nullptr;
     const int64_t mbase = mask_base(g.lb, g.start);
     const uint64_t* wmask = cmask + (int64_t)w * cmask_words + mbase;
     // row (16 lanes) r of the folded registers holds: k0 -> slot {0,2,1,3}[r], k1 -> {4,6,5,7}[r], k2 -> 8 (row 0)
@@ -317,56 +362,49 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             while (m) {
                 const int bit = 63 - __builtin_clzll(m);
                 m &= ~(1ull << bit);
-                const int t = jj * 64 + bit;
+                const int t = __builtin_amdgcn_readfirstlane(jj * 64 + bit);
                 const float4 a = sA[t];
                 const float4 q = sB[t];
                 const float cb_ = sC[t];
                 const float dx = a.x - g.px, dy = a.y - g.py;
                 const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
                 const float P = dx * lx + q.y * dy * dy;
-                const float vis = __builtin_amdgcn_exp2f(P);
+                const float vis0 = __builtin_amdgcn_exp2f(P);
+                // same include test as the forward pass (bin_final is -1 outside the image)
+                const bool valid = (bs + t <= bin_final) && !(P > 0.f) && !(fminf(0.999f, a.z * vis0) < 1.f / 255.f);
+                // Branch-free from here: a lane that does not include this record gets vis = 0, hence
+                // alpha = 0, ra = 1, fac = 0, and all nine partial gradients vanish without a single branch.
+                const float vis = valid ? vis0 : 0.f;
                 const float ov = a.z * vis;
                 const float alpha = fminf(0.999f, ov);
-                const bool valid = g.inside && (bs + t <= bin_final) && !(P > 0.f) && !(alpha < 1.f / 255.f);
-                float g_x = 0.f, g_y = 0.f, g_o = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f;
-                if (valid) {
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    T *= ra;
-                    const float fac = alpha * T;
-                    g_r = fac * vr; g_g = fac * vg; g_b = fac * vb;
-                    float v_al = (q.z * T - bufr * ra) * vr + (q.w * T - bufg * ra) * vg + (cb_ * T - bufb * ra) * vb;
-                    v_al += T_final * ra * va;
-                    if (ov <= 0.999f) {
-                        const float v_sigma = -ov * v_al;
-                        g_ca = 0.5f * v_sigma * dx * dx;
-                        g_cb = v_sigma * dx * dy;
-                        g_cc = 0.5f * v_sigma * dy * dy;
-                        // d sigma/d mean = (a dx + b dy, b dx + c dy) with a = -2 qa/log2e, b = -qb/log2e, c = -2 qc/log2e
-                        const float wv = v_sigma * (-1.0f / LOG2E);
-                        g_x = wv * (lx + a.w * dx);
-                        g_y = wv * (q.x * dx + 2.0f * q.y * dy);
-                        g_o = vis * v_al;
-                    }
-                    bufr += q.z * fac; bufg += q.w * fac; bufb += cb_ * fac;
-                }
-#if ST3R_EXP >= 3
-                asm volatile("" ::"v"(g_x), "v"(g_y), "v"(g_o), "v"(g_ca), "v"(g_cb), "v"(g_cc), "v"(g_r), "v"(g_g), "v"(g_b));
-                continue;
-#endif
+                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T *= ra;
+                const float fac = alpha * T;
+                float v_al = (q.z * T - bufr * ra) * vr + (q.w * T - bufg * ra) * vg + (cb_ * T - bufb * ra) * vb;
+                if (has_va) v_al += T_final * ra * va;
+                // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
+                const float vis_u = (ov <= 0.999f) ? vis : 0.f;
+                const float v_sigma = -(a.z * vis_u) * v_al;
+                const float hs = 0.5f * v_sigma;
+                // d sigma/d mean = (a dx + b dy, b dx + c dy) with a = -2 qa/log2e, b = -qb/log2e, c = -2 qc/log2e
+                const float wv = v_sigma * (-1.0f / LOG2E);
+                const float g_x = wv * (lx + a.w * dx);
+                const float g_y = wv * (q.x * dx + 2.0f * q.y * dy);
+                const float g_o = vis_u * v_al;
+                const float g_ca = hs * dx * dx, g_cb = v_sigma * dx * dy, g_cc = hs * dy * dy;
+                const float g_r = fac * vr, g_g = fac * vg, g_b = fac * vb;
+                bufr += q.z * fac; bufg += q.w * fac; bufb += cb_ * fac;
                 // 9 values x 64 lanes -> halving butterfly
-                const float h0 = fold32(g_x, g_y), h1 = fold32(g_o, g_ca), h2 = fold32(g_cb, g_cc);
-                const float h3 = fold32(g_r, g_g), h4 = fold32(g_b, 0.f);
-                float k0 = fold16(h0, h1), k1 = fold16(h2, h3), k2 = fold16(h4, 0.f);
+                float k0, k1, k2;
+                reduce9(g_x, g_y, g_o, g_ca, g_cb, g_cc, g_r, g_g, g_b, k0, k1, k2);
                 k0 = row_allsum(k0); k1 = row_allsum(k1); k2 = row_allsum(k2);
-#if ST3R_EXP >= 2
-                asm volatile("" ::"v"(k0), "v"(k1), "v"(k2));
-                continue;
-#endif
                 if (row_leader) {
+                    // slot2 is written lane-dependent on purpose (a uniform address makes hipcc wrap the
+                    // single-lane atomic in its wave-reduction loop)
                     float* acc = sAcc + t * ACC_STRIDE;
                     atomicAdd(acc + slot0, k0);
                     atomicAdd(acc + 4 + slot0, k1);
-                    if (lane == 0) atomicAdd(acc + 8, k2);
+                    if (row == 0) atomicAdd(acc + 8 + row, k2);
                 }
             }
         }
@@ -376,10 +414,6 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             bool any = false;
 #pragma unroll
             for (int k = 0; k < ACC_STRIDE; ++k) any |= (acc[k] != 0.f);
-#if ST3R_EXP >= 1
-            asm volatile("" ::"v"(any));
-            any = false;
-#endif
             if (any) {
                 // slot of this (record, tile) pair in emission order: u = cum_excl[pid] + index of this
                 // tile inside the record's tile rectangle (same float ops as k_isect_emit => same ints)
