@@ -1,0 +1,80 @@
+"""Pins oracle/align_oracle.py against golden vectors produced by the REFERENCE function
+(starster/reconstruct.py:116-457 executed by tools/gen_align_goldens.py) -- CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import align_oracle as ao
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    flat = {k[4:]: z[k] for k in z.files if k.startswith("in__")}
+    return z, flat
+
+
+def gauge_free(res, params, root):
+    """The loss is invariant to a rigid motion of the whole rig (the MST root's own rotation and
+    translation) and to a common factor on all sizes (global_scaling = 1/min(sizes), reconstruct.py:221):
+    along those directions the analytic gradient is exactly zero, float32 autograd returns rounding
+    noise, and Adam(eps=1e-8) turns noise into lr-sized steps.  Neither the reference nor any
+    restatement follows a defined trajectory there, so comparisons use gauge-free quantities."""
+    cam2w = np.asarray(res["cam2w"], np.float64)
+    w2c0 = np.linalg.inv(cam2w[root])
+    rel = w2c0[None] @ cam2w
+    pts = np.asarray(res["pts3d"], np.float64) @ w2c0[:3, :3].T + w2c0[:3, 3]
+    ls = np.asarray(params["log_sizes"], np.float64).reshape(-1)
+    nonroot = [i for i in range(len(cam2w)) if i != root]
+    return dict(pps=np.asarray(params["pps"]).reshape(len(cam2w), -1), log_focals=np.asarray(params["log_focals"]).reshape(-1),
+                quats_nonroot=np.asarray(params["quats"]).reshape(len(cam2w), -1)[nonroot],
+                # raw translations live in "size" units: normalise by global_scaling = 1/min(sizes)
+                trans_nonroot=np.asarray(params["trans"]).reshape(len(cam2w), -1)[nonroot] * np.exp(-ls.min()),
+                log_sizes_rel=ls - ls.min(),
+                intrinsics=np.asarray(res["intrinsics"]), rel_cam2w=rel, depthmaps=np.asarray(res["depthmaps"]),
+                pts3d_cam0=pts)
+
+
+def check(z, tag, res, params, tol, root=0):
+    ref_params = {k: z[f"{tag}__p_{k}"] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")}
+    ref_res = {k: z[f"{tag}__{k}"] for k in ("intrinsics", "cam2w", "depthmaps", "pts3d")}
+    a = gauge_free(res, params, root); b = gauge_free(ref_res, ref_params, root)
+    np.testing.assert_allclose(params["core_depth"], z[f"{tag}__p_core_depth"], rtol=1e-6, atol=1e-7)
+    for k in a:
+        scale = max(1.0, float(np.abs(b[k]).max()))
+        np.testing.assert_allclose(a[k], b[k], rtol=tol, atol=tol * scale, err_msg=f"{tag} {k}")
+
+
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
+def test_first_steps_match_reference(name):
+    """1 and 10 iterations pin the parametrisation, both losses' gradients, Adam(0.9,0.9), the cosine
+    schedule and the quaternion renormalisation tightly (before any trajectory divergence)."""
+    z, flat = load(name)
+    for (n1, n2) in ((1, 0), (10, 0)):
+        res, params = ao.run(flat, niter1=n1, niter2=n2)
+        check(z, f"r{n1}_{n2}", res, params, 2e-5)
+
+
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
+def test_full_schedule_matches_reference(name):
+    """500 (+1, +200) iterations: float32 trajectories drift by rounding, so the tolerance is 2e-3."""
+    z, flat = load(name)
+    res, params = ao.run(flat, niter1=500, niter2=0)
+    check(z, "r500_0", res, params, 2e-3)
+    res, params = ao.run(flat, niter1=500, niter2=1)   # first reprojection step (loss_2d gradient incl. focals/pps)
+    check(z, "r500_1", res, params, 2e-3)
+    res, params = ao.run(flat, niter1=500, niter2=200)
+    check(z, "r500_200", res, params, 5e-3)
+
+
+def test_interp_se3_golden():
+    """starster/utils.py:13-78 restated by starst3r_amd.utils; vectors from the reference module itself."""
+    from starst3r_amd import utils
+    z = np.load(os.path.join(GOLD, "interp_se3.npz"))
+    A, B = torch.tensor(z["A"]), torch.tensor(z["B"])
+    np.testing.assert_allclose(utils.interp_se3(A, B, 0.25).numpy(), z["f025"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(utils.interp_se3(A, B, 0.7).numpy(), z["f07"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(utils.interp_se3_path(A, B, 5).numpy(), z["path5"], rtol=1e-6, atol=1e-6)
