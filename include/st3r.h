@@ -173,6 +173,38 @@ int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const float* means
                    const float* viewmats, const float* Ks, const float* campos, int width, int height,
                    float* rgb, float* alpha, int64_t* stats_host);
 
+/* ------------------------------------------------------------------------------------
+ * Path B -- global alignment.  Runs the whole two-stage optimisation of
+ * starster/reconstruct.py:116-457 (`sparse_scene_optimizer_slam`: stage 1 = loss_3d for niter1
+ * steps at lr1, stage 2 = loss_2d for niter2 steps at lr2; Adam betas (0.9,0.9), cosine schedule,
+ * quaternion renormalisation, loss_dust3r with weight dust_weight) on the device, two launches per
+ * iteration, no host synchronisation.  All arrays are device pointers.
+ *   views:    imsizes [C,2] (W,H as float), base_focals [C], median [C] (median of the raw core
+ *             depths), core [C,G] (core depths / median), min_focals/max_focals [C] (focal clamp)
+ *   anchors:  anchor_pix [A,2], anchor_idx int32 [A] (index into the view's core depths),
+ *             anchor_off [A], anchor_img int32 [A]
+ *   rows:     corr_* = loss_3d rows (anchor ids a1,a2, weight = conf/sum conf);
+ *             c2d_*  = loss_2d rows (pixel in img1, anchor id of the 3-D point, img1, weight);
+ *             dust_* = regression-fallback rows (anchor id, target point in img2's frame, img2, weight)
+ *   chain:    root, edges int32 [C-1,2] (parent, child) in root-outward order
+ *   params (in/out, the reference's optim_params): pps [C,2] NORMALISED by the image size,
+ *             log_focals [C], quats [C,4] (x,y,z,w), trans [C,3], log_sizes [C]
+ *   work:     >= 66*C + 8 floats of scratch
+ *   outputs:  cam_out [C,24] = R[9] (cam2w rotation, row major) T[3] f cx cy A B base_focal ...,
+ *             with depthmap = A + B*core;  pts_out [A,3] world points of the anchors (may be NULL);
+ *             losses_out [niter1+niter2]
+ * ---------------------------------------------------------------------------------- */
+int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
+                   const float* base_focals, const float* median, const float* core, const float* min_focals,
+                   const float* max_focals, const float* anchor_pix, const int32_t* anchor_idx,
+                   const float* anchor_off, const int32_t* anchor_img, int n_corr, const int32_t* corr_a1,
+                   const int32_t* corr_a2, const float* corr_w, int n_c2d, const float* c2d_pix,
+                   const int32_t* c2d_a2, const int32_t* c2d_img1, const float* c2d_w, int n_dust,
+                   const int32_t* dust_a1, const float* dust_tgt, const int32_t* dust_img2, const float* dust_w,
+                   int root, int n_edges, const int32_t* edges, float lr1, int niter1, float lr2, int niter2,
+                   float dust_weight, float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
+                   float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,9 @@ SIGNATURES = {
     "st3r_adam_step": [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, f64, f64, f64, f64, i32],
     "st3r_gs_train_fwd_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp,
                               vp, C.POINTER(i64)],
+    "st3r_align_run": [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp,
+                       vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, f32, i32, f32, i32, f32, vp, vp, vp, vp, vp, vp, i64,
+                       vp, vp, vp],
     "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],
 }
 _RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_stage_name": C.c_char_p, "st3r_ctx_arena_bytes": i64}

@@ -1,0 +1,81 @@
+"""Host side of the global alignment (path B): prepares the flat problem on the device and runs
+st3r_align_run.  Mirrors the reference's `sparse_scene_optimizer_slam`
+(starster/reconstruct.py:116-457): same parameters (`optim_params` keys pps, log_focals, quats,
+trans, log_sizes, core_depth), same defaults, same return pieces (intrinsics, cam2w, depthmaps, pts3d).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+PARAM_KEYS = ("pps", "log_focals", "quats", "trans", "log_sizes")
+
+
+def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, loss_dust3r_w=0.01, device="cuda:0"):
+    """flat: dict of numpy arrays (starst3r_amd.synth_align.flatten layout).
+    Returns (result, params): result has intrinsics [C,3,3], cam2w [C,4,4], depthmaps [C,G], pts3d [A,3],
+    losses [niter1+niter2]; params holds the optimised parameters (and the normalised core_depth) so that a
+    later call can warm start from them (reconstruct.py:408-415)."""
+    ctx = ops.get_context(device)
+    dev = ctx.device
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev).contiguous()
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a).astype(np.int32), dtype=torch.int32, device=dev).contiguous()
+    Cn = int(flat["n_views"])
+    imsizes = f32(flat["imsizes"])
+    base_focals = f32(flat["base_focals"])
+    core_raw = f32(flat["core_depth"])
+    G = core_raw.shape[1]
+    median = core_raw.median(dim=1).values.contiguous()                 # reconstruct.py:176
+    core = (core_raw / median[:, None]).contiguous()                    # :177
+    diags = imsizes.norm(dim=1)
+    min_f = (0.25 * diags).contiguous(); max_f = (10 * diags).contiguous()  # :203-205
+
+    def weights(conf):
+        c = f32(conf)
+        return (c / c.sum()).contiguous() if c.numel() else c
+
+    anchor_pix, anchor_idx = f32(flat["anchor_pix"]), i32(flat["anchor_idx"])
+    anchor_off, anchor_img = f32(flat["anchor_offset"]), i32(flat["anchor_img"])
+    corr_a1, corr_a2, corr_w = i32(flat["corr_a1"]), i32(flat["corr_a2"]), weights(flat["corr_conf"])
+    c2d_pix, c2d_a2, c2d_img1 = f32(flat["c2d_pix"]), i32(flat["c2d_a2"]), i32(flat["c2d_img1"])
+    c2d_w = weights(flat["c2d_conf"])
+    dust_a1, dust_tgt, dust_img2 = i32(flat["dust_a1"]), f32(flat["dust_tgt"]), i32(flat["dust_img2"])
+    dust_w = weights(flat["dust_conf"])
+    edges = i32(np.asarray(flat["mst_edges"]).reshape(-1, 2))
+
+    # parameters (reconstruct.py:150-152, 170, 200-201, 277); warm start splices the first n views (:408-415)
+    P = dict(pps=(f32(flat["pps"]) / imsizes).contiguous(), log_focals=base_focals.log().contiguous(),
+             quats=torch.tensor([[0, 0, 0, 1.0]], device=dev).repeat(Cn, 1).contiguous(),
+             trans=torch.zeros(Cn, 3, device=dev), log_sizes=torch.zeros(Cn, device=dev))
+    if prev_params is not None:
+        for k in PARAM_KEYS:
+            prev = torch.as_tensor(np.asarray(prev_params[k]), dtype=torch.float32, device=dev)
+            n = min(prev.shape[0], Cn)
+            P[k][:n] = prev[:n].reshape(P[k][:n].shape)
+    work = torch.zeros(66 * Cn + 8, device=dev)
+    cam = torch.empty(Cn, 24, device=dev)
+    A = anchor_idx.numel()
+    pts = torch.empty(A, 3, device=dev)
+    losses = torch.zeros(max(niter1 + niter2, 1), device=dev)
+    p = ops._p
+    _lib.check(_lib.lib().st3r_align_run(
+        ctx.handle, ops._stream(), Cn, G, A, p(imsizes), p(base_focals), p(median), p(core), p(min_f), p(max_f),
+        p(anchor_pix), p(anchor_idx, torch.int32), p(anchor_off), p(anchor_img, torch.int32),
+        corr_a1.numel(), p(corr_a1, torch.int32), p(corr_a2, torch.int32), p(corr_w),
+        c2d_a2.numel(), p(c2d_pix), p(c2d_a2, torch.int32), p(c2d_img1, torch.int32), p(c2d_w),
+        dust_a1.numel(), p(dust_a1, torch.int32), p(dust_tgt), p(dust_img2, torch.int32), p(dust_w),
+        int(flat["mst_root"]), edges.shape[0], p(edges, torch.int32), lr1, niter1, lr2, niter2, loss_dust3r_w,
+        p(P["pps"]), p(P["log_focals"]), p(P["quats"]), p(P["trans"]), p(P["log_sizes"]),
+        p(work), work.numel(), p(cam), p(pts), p(losses)))
+    K = torch.zeros(Cn, 3, 3, device=dev)
+    K[:, 0, 0] = K[:, 1, 1] = cam[:, 12]; K[:, 0, 2] = cam[:, 13]; K[:, 1, 2] = cam[:, 14]; K[:, 2, 2] = 1
+    cam2w = torch.zeros(Cn, 4, 4, device=dev)
+    cam2w[:, :3, :3] = cam[:, :9].reshape(Cn, 3, 3); cam2w[:, :3, 3] = cam[:, 9:12]; cam2w[:, 3, 3] = 1
+    depth = cam[:, 15:16] + cam[:, 16:17] * core
+    res = dict(intrinsics=K, cam2w=cam2w, depthmaps=depth, pts3d=pts, losses=losses[:niter1 + niter2],
+               _adam_m=work[:11 * Cn].clone())  # first moments, order pps|log_focals|quats|trans|log_sizes (tests)
+    params = dict(P)
+    params["core_depth"] = core
+    return res, params

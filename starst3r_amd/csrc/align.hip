@@ -1,0 +1,519 @@
+// K11: global alignment (path B) -- fused residual + analytic gradient + Adam.
+// Replaces the reference's optimisation loop starster/reconstruct.py:371-406 (`optimize_loop`,
+// called for the coarse 3-D stage :427 and the 2-D reprojection stage :440) together with
+// `make_K_cam_depth` (:209-261), `loss_3d` (:325-353), `loss_2d` (:355-369), `loss_dust3r` (:311-323)
+// and the make_pts3d / reproj2d / gamma_loss helpers it imports.
+//
+// The reference builds a ~6400-op autograd graph per iteration (launch/dispatch bound).
+// Here one iteration is two launches, with hand-derived gradients and no host round trip:
+//   k_align_resid  : one thread per correspondence row.  Rebuilds the two 3-D points from the anchors,
+//                    evaluates conf * rho(distance) and pushes the gradient back to the 17 quantities of
+//                    each touched camera (R[9] T[3] f cx cy A B, depth = A + B*core).  Per-workgroup LDS
+//                    accumulators (ds_add_f32), then one float atomic per slot per workgroup.
+//   k_align_update : ONE workgroup.  Back-propagates the per-camera sums through the reparametrised
+//                    translation, the MST kinematic chain, the focal clamp and global_scaling = 1/min(size)
+//                    to the 11 parameters per view, applies Adam(lr(t), betas (0.9,0.9), eps 1e-8) with the
+//                    cosine schedule, renormalises the quaternions (:394-395), and immediately rebuilds the
+//                    camera table for the next iteration.
+// The working set (a few MB) lives in L2/LDS: this path is latency bound, not roofline bound.
+//
+// Parameter conventions of the reference: quaternions are (x,y,z,w) (:150), principal
+// points are normalised by the image size (:170), core depths by their median (:176-177).
+#include "common.h"
+
+#define CAM_STRIDE 24   // R[9] T[3] f cx cy A B base_focal (+pad)
+#define ACC_STRIDE 20   // vR[9] vT[3] vf vcx vcy vA vB (+pad)
+#define MAXC 256
+
+struct AlignProblem {
+    int C;
+    const float* imsizes;      // [C,2] (W,H) as float
+    const float* base_focals;  // [C]
+    const float* median;       // [C]   median of the raw core depths
+    const float* core;         // [C,G] core depths / median
+    int G;
+    const float* anchor_pix;   // [A,2]
+    const int32_t* anchor_idx; // [A]
+    const float* anchor_off;   // [A]
+    const int32_t* anchor_img; // [A]
+    int n_corr; const int32_t* corr_a1; const int32_t* corr_a2; const float* corr_w;   // w = conf / sum(conf)
+    int n_c2d; const float* c2d_pix; const int32_t* c2d_a2; const int32_t* c2d_img1; const float* c2d_w;
+    int n_dust; const int32_t* dust_a1; const float* dust_tgt; const int32_t* dust_img2; const float* dust_w;
+    int root; int n_edges; const int32_t* edges;  // [n_edges,2] in chain order
+    const float* min_focals; const float* max_focals;
+};
+
+struct AlignState {
+    float* pps; float* log_focals; float* quats; float* trans; float* log_sizes;  // [C,2] [C] [C,4] [C,3] [C]
+    float* m; float* v;        // Adam moments [11*C] in the order pps, log_focals, quats, trans, log_sizes
+    float* cam;                // [C,CAM_STRIDE]
+    float* acc;                // [C*ACC_STRIDE + 4]: gradient sums, then [loss, nan flag]
+    float* losses;             // [niter1 + niter2]
+};
+
+__device__ __forceinline__ float rho_prime(float d, float gamma, float off, float* rho) {
+    // gamma_loss(gamma): rho(d) = (d + off)^gamma - off^gamma, off = (1/gamma)^(1/(gamma-1))
+    const float b = d + off;
+    const float pw = __powf(b, gamma - 1.0f);
+    *rho = pw * b - __powf(off, gamma);
+    return gamma * pw;
+}
+
+// 3-D point of anchor a in world coordinates; also returns the pieces the backward pass needs
+struct Pt { float pw[3]; float pc[3]; float dx, dy, D, offp, core; int img; };
+
+__device__ __forceinline__ Pt anchor_point(const AlignProblem& P, const float* __restrict__ cam, int a) {
+    Pt r;
+    r.img = P.anchor_img[a];
+    const float* c = cam + r.img * CAM_STRIDE;
+    const float f = c[12], cx = c[13], cy = c[14], A = c[15], B = c[16], bf = c[17];
+    const float u = P.anchor_pix[2 * a], v = P.anchor_pix[2 * a + 1];
+    r.core = P.core[(int64_t)r.img * P.G + P.anchor_idx[a]];
+    r.D = A + B * r.core;
+    r.offp = 1.0f + (P.anchor_off[a] - 1.0f) * (bf / f);
+    const float z = r.D * r.offp;
+    r.dx = (u - cx) / f; r.dy = (v - cy) / f;
+    r.pc[0] = z * r.dx; r.pc[1] = z * r.dy; r.pc[2] = z;
+    r.pw[0] = c[0] * r.pc[0] + c[1] * r.pc[1] + c[2] * r.pc[2] + c[9];
+    r.pw[1] = c[3] * r.pc[0] + c[4] * r.pc[1] + c[5] * r.pc[2] + c[10];
+    r.pw[2] = c[6] * r.pc[0] + c[7] * r.pc[1] + c[8] * r.pc[2] + c[11];
+    return r;
+}
+
+// push dL/d(pw) of an anchor point back to its camera's 17 accumulators (LDS)
+__device__ __forceinline__ void point_bwd(const AlignProblem& P, const float* __restrict__ cam, int a, const Pt& r,
+                                          const float vp[3], float* sacc) {
+    const float* c = cam + r.img * CAM_STRIDE;
+    float* g = sacc + r.img * ACC_STRIDE;
+    const float f = c[12], bf = c[17];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomicAdd(&g[i * 3 + j], vp[i] * r.pc[j]);
+        atomicAdd(&g[9 + i], vp[i]);
+    }
+    const float vpc0 = c[0] * vp[0] + c[3] * vp[1] + c[6] * vp[2];
+    const float vpc1 = c[1] * vp[0] + c[4] * vp[1] + c[7] * vp[2];
+    const float vpc2 = c[2] * vp[0] + c[5] * vp[1] + c[8] * vp[2];
+    const float z = r.pc[2];
+    const float vz = vpc0 * r.dx + vpc1 * r.dy + vpc2;
+    const float vdx = vpc0 * z, vdy = vpc1 * z;
+    float vf = -(vdx * r.dx + vdy * r.dy) / f;
+    atomicAdd(&g[13], -vdx / f);
+    atomicAdd(&g[14], -vdy / f);
+    const float vD = vz * r.offp;
+    atomicAdd(&g[15], vD);
+    atomicAdd(&g[16], vD * r.core);
+    vf += vz * r.D * (-(P.anchor_off[a] - 1.0f) * bf / (f * f));
+    atomicAdd(&g[12], vf);
+}
+
+// stage: 1 = loss_3d rows + dust rows, 2 = loss_2d rows + dust rows
+__global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState S, int stage, float dust_w) {
+    extern __shared__ float sacc[];  // [C*ACC_STRIDE + 1]
+    const int nacc = P.C * ACC_STRIDE + 1;
+    for (int i = threadIdx.x; i < nacc; i += blockDim.x) sacc[i] = 0.f;
+    __syncthreads();
+    if (S.acc[P.C * ACC_STRIDE + 1] == 0.f) {  // not stopped by a NaN loss
+        const int n_main = stage == 1 ? P.n_corr : P.n_c2d;
+        const int row = blockIdx.x * blockDim.x + threadIdx.x;
+        float lsum = 0.f;
+        if (row < n_main) {
+            if (stage == 1) {
+                const int a1 = P.corr_a1[row], a2 = P.corr_a2[row];
+                const Pt p1 = anchor_point(P, S.cam, a1), p2 = anchor_point(P, S.cam, a2);
+                const float ex = p1.pw[0] - p2.pw[0], ey = p1.pw[1] - p2.pw[1], ez = p1.pw[2] - p2.pw[2];
+                const float d = sqrtf(ex * ex + ey * ey + ez * ez);
+                const float off = 0.8717937f;  // (1/1.1)^(1/0.1) ... computed exactly below
+                (void)off;
+                float rho;
+                const float o11 = __powf(1.0f / 1.1f, 10.0f);
+                const float rp = rho_prime(d, 1.1f, o11, &rho);
+                const float w = P.corr_w[row];
+                lsum = w * rho;
+                if (d > 1e-20f) {
+                    const float k = w * rp / d;
+                    const float v1[3] = {k * ex, k * ey, k * ez}, v2[3] = {-k * ex, -k * ey, -k * ez};
+                    point_bwd(P, S.cam, a1, p1, v1, sacc);
+                    point_bwd(P, S.cam, a2, p2, v2, sacc);
+                }
+            } else {
+                const int a2 = P.c2d_a2[row], i1 = P.c2d_img1[row];
+                const Pt p2 = anchor_point(P, S.cam, a2);
+                const float* c = S.cam + i1 * CAM_STRIDE;
+                const float f = c[12], cx = c[13], cy = c[14];
+                const float e0 = p2.pw[0] - c[9], e1 = p2.pw[1] - c[10], e2 = p2.pw[2] - c[11];
+                const float qx = c[0] * e0 + c[3] * e1 + c[6] * e2;   // R1^T (p - T1)
+                const float qy = c[1] * e0 + c[4] * e1 + c[7] * e2;
+                const float qz = c[2] * e0 + c[5] * e1 + c[8] * e2;
+                const float rx = f * qx + cx * qz, ry = f * qy + cy * qz, rz = qz;
+                const bool zclip = !(rz >= 1e-3f);
+                const float zc = zclip ? 1e-3f : rz;
+                float u = rx / zc, v = ry / zc;
+                const bool uclip = (u < -1000.f) || (u > 2000.f), vclip = (v < -1000.f) || (v > 2000.f);
+                u = fminf(fmaxf(u, -1000.f), 2000.f); v = fminf(fmaxf(v, -1000.f), 2000.f);
+                const float du = P.c2d_pix[2 * row] - u, dv = P.c2d_pix[2 * row + 1] - v;
+                const float d = sqrtf(du * du + dv * dv);
+                float rho;
+                const float o04 = __powf(2.5f, -1.0f / 0.6f);  // (1/0.4)^(1/(0.4-1))
+                const float rp = rho_prime(d, 0.4f, o04, &rho);
+                const float w = P.c2d_w[row];
+                lsum = w * rho;
+                if (d > 1e-20f) {
+                    const float k = w * rp / d;
+                    const float vu = uclip ? 0.f : -k * du, vv = vclip ? 0.f : -k * dv;
+                    const float vrx = vu / zc, vry = vv / zc;
+                    const float vrz = zclip ? 0.f : -(vu * rx + vv * ry) / (zc * zc);
+                    float* g = sacc + i1 * ACC_STRIDE;
+                    atomicAdd(&g[12], vrx * qx + vry * qy);
+                    atomicAdd(&g[13], vrx * qz);
+                    atomicAdd(&g[14], vry * qz);
+                    const float vq0 = f * vrx, vq1 = f * vry, vq2 = cx * vrx + cy * vry + vrz;
+                    // q = R1^T e : vR1[m][k] += e_m vq_k ; ve = R1 vq ; vT1 -= ve ; vp += ve
+                    const float e[3] = {e0, e1, e2}, vq[3] = {vq0, vq1, vq2};
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int kk = 0; kk < 3; ++kk) atomicAdd(&g[m * 3 + kk], e[m] * vq[kk]);
+                    float ve[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) ve[m] = c[m * 3] * vq0 + c[m * 3 + 1] * vq1 + c[m * 3 + 2] * vq2;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) atomicAdd(&g[9 + m], -ve[m]);
+                    point_bwd(P, S.cam, a2, p2, ve, sacc);
+                }
+            }
+        } else if (row - n_main < P.n_dust) {
+            // DUSt3R regression fallback for pairs that failed the matching gate (reconstruct.py:311-323)
+            const int r = row - n_main;
+            const int a1 = P.dust_a1[r], i2 = P.dust_img2[r];
+            const Pt p1 = anchor_point(P, S.cam, a1);
+            const float* c = S.cam + i2 * CAM_STRIDE;
+            const float t0 = P.dust_tgt[3 * r], t1 = P.dust_tgt[3 * r + 1], t2 = P.dust_tgt[3 * r + 2];
+            const float gx = c[0] * t0 + c[1] * t1 + c[2] * t2 + c[9];
+            const float gy = c[3] * t0 + c[4] * t1 + c[5] * t2 + c[10];
+            const float gz = c[6] * t0 + c[7] * t1 + c[8] * t2 + c[11];
+            const float ex = p1.pw[0] - gx, ey = p1.pw[1] - gy, ez = p1.pw[2] - gz;
+            const float d = sqrtf(ex * ex + ey * ey + ez * ez);
+            float rho;
+            const float o11 = __powf(1.0f / 1.1f, 10.0f);
+            const float rp = rho_prime(d, 1.1f, o11, &rho);
+            const float w = dust_w * P.dust_w[r];
+            lsum = w * rho;
+            if (d > 1e-20f) {
+                const float k = w * rp / d;
+                const float v1[3] = {k * ex, k * ey, k * ez};
+                point_bwd(P, S.cam, a1, p1, v1, sacc);
+                float* g = sacc + i2 * ACC_STRIDE;
+                const float tg[3] = {t0, t1, t2};
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) atomicAdd(&g[m * 3 + kk], -v1[m] * tg[kk]);
+                    atomicAdd(&g[9 + m], -v1[m]);
+                }
+            }
+        }
+        if (lsum != 0.f) atomicAdd(&sacc[P.C * ACC_STRIDE], lsum);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nacc; i += blockDim.x)
+        if (sacc[i] != 0.f) atomicAdd(&S.acc[i], sacc[i]);
+}
+
+__device__ __forceinline__ void quat_to_rot(const float* q, float* R, float* qn, float* inv_norm) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float inv = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+    x *= inv; y *= inv; z *= inv; w *= inv;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+    qn[0] = x; qn[1] = y; qn[2] = z; qn[3] = w; *inv_norm = inv;
+}
+
+struct UpdateArgs {
+    int do_backward;   // 0: only build the camera table (first call)
+    int stage;         // trainable set: 1 = quats, trans, log_sizes ; 2 = + pps, log_focals
+    float lr;          // cosine-scheduled learning rate of this step
+    int step;          // 1-based Adam step within the stage
+    int loss_index;    // where to store the loss of the step just evaluated
+    int reset_moments; // first step of a stage: fresh optimiser (reconstruct.py:374)
+};
+
+// single workgroup; thread i < C owns view i for the element-wise parts, thread 0 walks the chain
+__global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState S, UpdateArgs U) {
+    __shared__ float sRr[MAXC * 9], sRt[MAXC * 9], stt[MAXC * 3];        // relative / chained rotations, chained translation
+    __shared__ float svRt[MAXC * 9], svtt[MAXC * 3];                      // their gradients
+    __shared__ float ssize[MAXC];
+    __shared__ float s_gs, s_vgs, s_min; __shared__ int s_argmin;
+    const int i = threadIdx.x;
+    const int C = P.C;
+    float* flags = S.acc + C * ACC_STRIDE;
+    if (U.do_backward && flags[1] != 0.f) return;  // stopped earlier by a NaN loss
+    if (U.do_backward && i == 0) {
+        const float loss = flags[0];
+        S.losses[U.loss_index] = loss;
+        if (loss != loss) flags[1] = 1.f;          // reference: `if loss != loss: break` (:397-399), before... after the step
+    }
+    if (U.reset_moments)
+        for (int k = i; k < 11 * C; k += blockDim.x) { S.m[k] = 0.f; S.v[k] = 0.f; }
+    __syncthreads();
+
+    // ---------------- backward of make_K_cam_depth + Adam (uses the forward state of the step just evaluated) ----------------
+    if (U.do_backward) {
+        // recompute the forward pieces this thread needs
+        float f = 0, s = 0, zc = 0, W = 0, H = 0, ppx = 0, ppy = 0, med = 0, bf = 0, to[3] = {0, 0, 0};
+        bool fclip = false;
+        if (i < C) {
+            W = P.imsizes[2 * i]; H = P.imsizes[2 * i + 1];
+            const float fe = __expf(S.log_focals[i]);
+            f = fminf(fmaxf(fe, P.min_focals[i]), P.max_focals[i]);
+            fclip = (fe < P.min_focals[i]) || (fe > P.max_focals[i]);
+            s = __expf(S.log_sizes[i]); ssize[i] = s;
+            med = P.median[i]; bf = P.base_focals[i];
+            zc = s * med * f / bf;
+            ppx = S.pps[2 * i]; ppy = S.pps[2 * i + 1];
+            to[0] = zc * (W / f) * (0.5f - ppx); to[1] = zc * (H / f) * (0.5f - ppy); to[2] = zc;
+            float qn[4], inv;
+            quat_to_rot(S.quats + 4 * i, sRr + 9 * i, qn, &inv);
+        }
+        __syncthreads();
+        if (i == 0) {
+            // torch's full-reduction min() splits its gradient evenly between tied minima (all sizes are
+            // exactly 1 on the very first step), so count the ties
+            float mn = ssize[0];
+            for (int k = 1; k < C; ++k) mn = fminf(mn, ssize[k]);
+            int ties = 0;
+            for (int k = 0; k < C; ++k) ties += (ssize[k] == mn) ? 1 : 0;
+            s_gs = 1.0f / mn; s_argmin = ties; s_vgs = 0.f; s_min = mn;
+            // forward chain (rotations + translations)
+            for (int k = 0; k < 9; ++k) sRt[9 * P.root + k] = sRr[9 * P.root + k];
+            for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = S.trans[3 * P.root + k];
+            for (int e = 0; e < P.n_edges; ++e) {
+                const int a = P.edges[2 * e], b = P.edges[2 * e + 1];
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c)
+                        sRt[9 * b + 3 * r + c] = sRt[9 * a + 3 * r] * sRr[9 * b + c] + sRt[9 * a + 3 * r + 1] * sRr[9 * b + 3 + c] +
+                                                 sRt[9 * a + 3 * r + 2] * sRr[9 * b + 6 + c];
+                    stt[3 * b + r] = sRt[9 * a + 3 * r] * S.trans[3 * b] + sRt[9 * a + 3 * r + 1] * S.trans[3 * b + 1] +
+                                     sRt[9 * a + 3 * r + 2] * S.trans[3 * b + 2] + stt[3 * a + r];
+                }
+            }
+        }
+        __syncthreads();
+        const float gs = s_gs;
+        float v_f = 0, v_ppx = 0, v_ppy = 0, v_s = 0, vgs_part = 0;
+        if (i < C) {
+            const float* g = S.acc + i * ACC_STRIDE;
+            const float* Rt = sRt + 9 * i;
+            const float vT[3] = {g[9], g[10], g[11]};
+            const float vA = g[15], vB = g[16];
+            // T = gs (tt - Rt to) ; A = gs (zc - med s) ; B = gs med s
+            float Rto[3];
+            for (int r = 0; r < 3; ++r) Rto[r] = Rt[3 * r] * to[0] + Rt[3 * r + 1] * to[1] + Rt[3 * r + 2] * to[2];
+            for (int r = 0; r < 3; ++r) vgs_part += vT[r] * (stt[3 * i + r] - Rto[r]);
+            vgs_part += vA * (zc - med * s) + vB * med * s;
+            float vto[3];
+            for (int c = 0; c < 3; ++c) vto[c] = -gs * (Rt[c] * vT[0] + Rt[3 + c] * vT[1] + Rt[6 + c] * vT[2]);
+            for (int r = 0; r < 3; ++r) {
+                svtt[3 * i + r] = gs * vT[r];
+                for (int c = 0; c < 3; ++c) svRt[9 * i + 3 * r + c] = g[3 * r + c] - gs * vT[r] * to[c];
+            }
+            const float ax = (W / f) * (0.5f - ppx), ay = (H / f) * (0.5f - ppy);
+            const float v_zc = vA * gs + vto[0] * ax + vto[1] * ay + vto[2];
+            v_f = g[12] + vto[0] * zc * (-(W / (f * f)) * (0.5f - ppx)) + vto[1] * zc * (-(H / (f * f)) * (0.5f - ppy)) +
+                  v_zc * s * med / bf;
+            v_ppx = g[13] * W - vto[0] * zc * (W / f);
+            v_ppy = g[14] * H - vto[1] * zc * (H / f);
+            v_s = v_zc * med * f / bf - vA * gs * med + vB * gs * med;
+            atomicAdd(&s_vgs, vgs_part);
+        }
+        __syncthreads();
+        if (i == 0) {
+            // reverse chain
+            for (int e = P.n_edges - 1; e >= 0; --e) {
+                const int a = P.edges[2 * e], b = P.edges[2 * e + 1];
+                float vRr[9], vtr[3];
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) {
+                        // Rt_b = Rt_a Rr_b : vRt_a += vRt_b Rr_b^T ; vRr_b = Rt_a^T vRt_b
+                        svRt[9 * a + 3 * r + c] += svRt[9 * b + 3 * r] * sRr[9 * b + 3 * c] + svRt[9 * b + 3 * r + 1] * sRr[9 * b + 3 * c + 1] +
+                                                   svRt[9 * b + 3 * r + 2] * sRr[9 * b + 3 * c + 2];
+                        vRr[3 * r + c] = sRt[9 * a + r] * svRt[9 * b + c] + sRt[9 * a + 3 + r] * svRt[9 * b + 3 + c] +
+                                         sRt[9 * a + 6 + r] * svRt[9 * b + 6 + c];
+                        // tt_b = Rt_a tr_b + tt_a : vRt_a += vtt_b (x) tr_b
+                        svRt[9 * a + 3 * r + c] += svtt[3 * b + r] * S.trans[3 * b + c];
+                    }
+                    vtr[r] = sRt[9 * a + r] * svtt[3 * b] + sRt[9 * a + 3 + r] * svtt[3 * b + 1] + sRt[9 * a + 6 + r] * svtt[3 * b + 2];
+                }
+                for (int r = 0; r < 3; ++r) svtt[3 * a + r] += svtt[3 * b + r];
+                // from here on svRt[b] / svtt[b] hold the gradients of the RELATIVE pose of view b
+                for (int k = 0; k < 9; ++k) svRt[9 * b + k] = vRr[k];
+                for (int k = 0; k < 3; ++k) svtt[3 * b + k] = vtr[k];
+            }
+        }
+        __syncthreads();
+        if (i < C) {
+            if (s == s_min) v_s += s_vgs * (-gs * gs) / (float)s_argmin;  // gs = 1/min(s); s_argmin = tie count
+            // quaternion (x,y,z,w): rotmat VJP, then the normalisation VJP
+            float R[9], qn[4], inv;
+            quat_to_rot(S.quats + 4 * i, R, qn, &inv);
+            const float* vR = svRt + 9 * i;
+            const float x = qn[0], y = qn[1], z = qn[2], w = qn[3];
+            float vq[4];
+            vq[3] = 2.0f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+            vq[0] = 2.0f * (-2.0f * x * (vR[4] + vR[8]) + y * (vR[3] + vR[1]) + z * (vR[6] + vR[2]) + w * (vR[7] - vR[5]));
+            vq[1] = 2.0f * (x * (vR[3] + vR[1]) - 2.0f * y * (vR[0] + vR[8]) + z * (vR[7] + vR[5]) + w * (vR[2] - vR[6]));
+            vq[2] = 2.0f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.0f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+            const float dq = vq[0] * x + vq[1] * y + vq[2] * z + vq[3] * w;
+            for (int k = 0; k < 4; ++k) vq[k] = (vq[k] - dq * qn[k]) * inv;
+            // gradients in the optimiser's parameter order
+            float grad[11];
+            grad[0] = v_ppx; grad[1] = v_ppy; grad[2] = fclip ? 0.f : v_f * f;
+            for (int k = 0; k < 4; ++k) grad[3 + k] = vq[k];
+            for (int k = 0; k < 3; ++k) grad[7 + k] = svtt[3 * i + k];
+            grad[10] = v_s * s;
+            float* pptr[11] = {S.pps + 2 * i, S.pps + 2 * i + 1, S.log_focals + i, S.quats + 4 * i, S.quats + 4 * i + 1,
+                               S.quats + 4 * i + 2, S.quats + 4 * i + 3, S.trans + 3 * i, S.trans + 3 * i + 1,
+                               S.trans + 3 * i + 2, S.log_sizes + i};
+            const int moff[11] = {2 * i, 2 * i + 1, 2 * C + i, 3 * C + 4 * i, 3 * C + 4 * i + 1, 3 * C + 4 * i + 2,
+                                  3 * C + 4 * i + 3, 7 * C + 3 * i, 7 * C + 3 * i + 1, 7 * C + 3 * i + 2, 10 * C + i};
+            // Adam(lr, betas=(0.9, 0.9), eps=1e-8), torch single-tensor semantics
+            const double bc1 = 1.0 - pow(0.9, (double)U.step), bc2 = bc1;
+            const float step_size = (float)((double)U.lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+            const float w1 = (float)(1.0 - 0.9), b2 = 0.9f, eps = 1e-8f;
+            for (int k = 0; k < 11; ++k) {
+                const bool trainable = (k >= 3) || (U.stage == 2);
+                if (!trainable) continue;
+                const float gk = grad[k];
+                float mk = S.m[moff[k]], vk = S.v[moff[k]];
+                mk = fmaf(w1, gk - mk, mk);
+                vk = vk * b2 + (w1 * gk) * gk;
+                S.m[moff[k]] = mk; S.v[moff[k]] = vk;
+                *pptr[k] = *pptr[k] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+            }
+            // make sure the pose remains well optimizable (reconstruct.py:394-395)
+            float* q = S.quats + 4 * i;
+            const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+        }
+        __syncthreads();
+    }
+
+    // ---------------- forward: camera table for the next residual launch ----------------
+    if (i < C) {
+        const float s = __expf(S.log_sizes[i]);
+        ssize[i] = s;
+        float qn[4], inv;
+        quat_to_rot(S.quats + 4 * i, sRr + 9 * i, qn, &inv);
+    }
+    __syncthreads();
+    if (i == 0) {
+        float mn = ssize[0];
+        for (int k = 1; k < C; ++k) mn = fminf(mn, ssize[k]);
+        s_gs = 1.0f / mn;
+        for (int k = 0; k < 9; ++k) sRt[9 * P.root + k] = sRr[9 * P.root + k];
+        for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = S.trans[3 * P.root + k];
+        for (int e = 0; e < P.n_edges; ++e) {
+            const int a = P.edges[2 * e], b = P.edges[2 * e + 1];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c)
+                    sRt[9 * b + 3 * r + c] = sRt[9 * a + 3 * r] * sRr[9 * b + c] + sRt[9 * a + 3 * r + 1] * sRr[9 * b + 3 + c] +
+                                             sRt[9 * a + 3 * r + 2] * sRr[9 * b + 6 + c];
+                stt[3 * b + r] = sRt[9 * a + 3 * r] * S.trans[3 * b] + sRt[9 * a + 3 * r + 1] * S.trans[3 * b + 1] +
+                                 sRt[9 * a + 3 * r + 2] * S.trans[3 * b + 2] + stt[3 * a + r];
+            }
+        }
+    }
+    __syncthreads();
+    if (i < C) {
+        const float gs = s_gs;
+        const float W = P.imsizes[2 * i], H = P.imsizes[2 * i + 1];
+        const float f = fminf(fmaxf(__expf(S.log_focals[i]), P.min_focals[i]), P.max_focals[i]);
+        const float s = ssize[i], med = P.median[i], bf = P.base_focals[i];
+        const float zc = s * med * f / bf;
+        const float ppx = S.pps[2 * i], ppy = S.pps[2 * i + 1];
+        const float to[3] = {zc * (W / f) * (0.5f - ppx), zc * (H / f) * (0.5f - ppy), zc};
+        float* c = S.cam + i * CAM_STRIDE;
+        const float* Rt = sRt + 9 * i;
+        for (int k = 0; k < 9; ++k) c[k] = Rt[k];
+        for (int r = 0; r < 3; ++r)
+            c[9 + r] = gs * (stt[3 * i + r] - (Rt[3 * r] * to[0] + Rt[3 * r + 1] * to[1] + Rt[3 * r + 2] * to[2]));
+        c[12] = f; c[13] = ppx * W; c[14] = ppy * H;
+        c[15] = gs * (zc - med * s); c[16] = gs * med * s; c[17] = bf;
+    }
+    // clear the accumulators for the next residual launch (keep the NaN flag)
+    for (int k = i; k < C * ACC_STRIDE + 1; k += blockDim.x) S.acc[k] = 0.f;
+}
+
+// world points of every anchor from the current camera table (the reference's `pts3d` result, :405-406)
+__global__ void k_align_points(AlignProblem P, AlignState S, int n_anchors, float* __restrict__ pts) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_anchors) return;
+    const Pt r = anchor_point(P, S.cam, a);
+    pts[3 * a] = r.pw[0]; pts[3 * a + 1] = r.pw[1]; pts[3 * a + 2] = r.pw[2];
+}
+
+ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
+                               const float* base_focals, const float* median, const float* core,
+                               const float* min_focals, const float* max_focals, const float* anchor_pix,
+                               const int32_t* anchor_idx, const float* anchor_off, const int32_t* anchor_img,
+                               int n_corr, const int32_t* corr_a1, const int32_t* corr_a2, const float* corr_w,
+                               int n_c2d, const float* c2d_pix, const int32_t* c2d_a2, const int32_t* c2d_img1,
+                               const float* c2d_w, int n_dust, const int32_t* dust_a1, const float* dust_tgt,
+                               const int32_t* dust_img2, const float* dust_w, int root, int n_edges,
+                               const int32_t* edges, float lr1, int niter1, float lr2, int niter2, float dust_weight,
+                               float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
+                               float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out) {
+    ARG_CHECK(ctx && C > 0 && C <= MAXC && G > 0 && n_anchors >= 0 && niter1 >= 0 && niter2 >= 0);
+    ARG_CHECK(imsizes && base_focals && median && core && min_focals && max_focals && pps && log_focals && quats &&
+              trans && log_sizes && work && cam_out && edges);
+    ARG_CHECK(n_edges == C - 1 && root >= 0 && root < C);
+    const int64_t need = 22 * (int64_t)C + (int64_t)C * CAM_STRIDE + (int64_t)C * ACC_STRIDE + 8;
+    ARG_CHECK(work_floats >= need);
+    hipStream_t s = (hipStream_t)stream;
+    AlignProblem P;
+    P.C = C; P.imsizes = imsizes; P.base_focals = base_focals; P.median = median; P.core = core; P.G = G;
+    P.anchor_pix = anchor_pix; P.anchor_idx = anchor_idx; P.anchor_off = anchor_off; P.anchor_img = anchor_img;
+    P.n_corr = n_corr; P.corr_a1 = corr_a1; P.corr_a2 = corr_a2; P.corr_w = corr_w;
+    P.n_c2d = n_c2d; P.c2d_pix = c2d_pix; P.c2d_a2 = c2d_a2; P.c2d_img1 = c2d_img1; P.c2d_w = c2d_w;
+    P.n_dust = n_dust; P.dust_a1 = dust_a1; P.dust_tgt = dust_tgt; P.dust_img2 = dust_img2; P.dust_w = dust_w;
+    P.root = root; P.n_edges = n_edges; P.edges = edges; P.min_focals = min_focals; P.max_focals = max_focals;
+    AlignState S;
+    S.pps = pps; S.log_focals = log_focals; S.quats = quats; S.trans = trans; S.log_sizes = log_sizes;
+    S.m = work; S.v = work + 11 * C; S.cam = work + 22 * C; S.acc = S.cam + (int64_t)C * CAM_STRIDE;
+    S.losses = losses_out;
+    HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (size_t)need, s));
+    const size_t sh = sizeof(float) * ((size_t)C * ACC_STRIDE + 1);
+    UpdateArgs U0 = {0, 1, 0.f, 0, 0, 0};
+    hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U0);
+    // The reference returns K / cam2w / depthmaps / pts3d as computed at the START of the last iteration,
+    // i.e. one optimiser step behind the returned parameters (optimize_loop builds them before
+    // loss.backward()/step and never refreshes them, reconstruct.py:379-380,405-406).  Reproduced here:
+    // the camera table is exported right before the final update launch.
+    auto export_results = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(cam_out, S.cam, sizeof(float) * (size_t)C * CAM_STRIDE, hipMemcpyDeviceToDevice, s));
+        if (pts_out && n_anchors > 0)
+            hipLaunchKernelGGL(k_align_points, dim3(ceil_div(n_anchors, 256)), dim3(256), 0, s, P, S, n_anchors, pts_out);
+        return ST3R_OK;
+    };
+    const int last_stage = niter2 > 0 ? 2 : 1;
+    if (niter1 == 0 && niter2 == 0) { int rc = export_results(); if (rc) return rc; }
+    int li = 0;
+    for (int stage = 1; stage <= 2; ++stage) {
+        const int niter = stage == 1 ? niter1 : niter2;
+        const float lr_base = stage == 1 ? lr1 : lr2;
+        const int rows = (stage == 1 ? n_corr : n_c2d) + n_dust;
+        for (int it = 0; it < niter; ++it) {
+            if (stage == last_stage && it == niter - 1) { int rc = export_results(); if (rc) return rc; }
+            if (rows > 0) hipLaunchKernelGGL(k_align_resid, dim3(ceil_div(rows, 256)), dim3(256), sh, s, P, S, stage, dust_weight);
+            UpdateArgs U;
+            U.do_backward = 1; U.stage = stage;
+            U.lr = (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
+            U.step = it + 1; U.loss_index = li++; U.reset_moments = (it == 0);
+            hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U);
+        }
+    }
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
