@@ -205,6 +205,17 @@ int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, con
                    float dust_weight, float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
                    float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out);
 
+/* ------------------------------------------------------------------------------------
+ * Path A -- matching.  The nearest-neighbour query of Mast3r's fast_reciprocal_NNs with
+ * dist='dot' (reached from starster/reconstruct.py:97):
+ *     nn_out[q] = argmax_j  queries[q] . db[j]     (smallest j on ties), score_out[q] = that maximum
+ * queries [n,dim], db [m,dim] row major float32 (dim must be 24, Mast3r's descriptor size),
+ * nn_out int32 [n], score_out float [n] or NULL.  fp32 MFMA block-matmul with fused arg-max.
+ * The reciprocal iteration around it lives in starst3r_amd/matching.py.
+ * ---------------------------------------------------------------------------------- */
+int st3r_nn_dot_argmax(st3r_ctx* ctx, void* stream, const float* queries, int n, const float* db, int m, int dim,
+                       int32_t* nn_out, float* score_out);
+
 #ifdef __cplusplus
 }
 #endif

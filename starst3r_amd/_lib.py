@@ -41,6 +41,7 @@ SIGNATURES = {
     "st3r_align_run": [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp,
                        vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, f32, i32, f32, i32, f32, vp, vp, vp, vp, vp, vp, i64,
                        vp, vp, vp],
+    "st3r_nn_dot_argmax": [vp, vp, vp, i32, vp, i32, i32, vp, vp],
     "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],
 }
 _RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_stage_name": C.c_char_p, "st3r_ctx_arena_bytes": i64}

@@ -57,6 +57,7 @@ enum ArenaSlot {
     SLOT_DVALS_A,
     SLOT_DVALS_B,
     SLOT_CUM_D,
+    SLOT_NN_PART,
     SLOT_COUNT
 };
 

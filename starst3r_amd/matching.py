@@ -1,0 +1,70 @@
+"""Reciprocal nearest-neighbour matching of dense descriptors (path A).
+
+Mirrors Mast3r's `fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy=..., dist='dot',
+block_size=2**13)` as the reference reaches it (starster/reconstruct.py:97 -> forward_mast3r ->
+extract_correspondences): same seeds, same iteration, same convergence rule, same
+unique/sort of the result.  The nearest-neighbour queries run on the MFMA kernel (st3r_nn_dot_argmax);
+the bookkeeping around it (a few thousand int32 per iteration) is torch on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def nn_dot_argmax(ctx, queries, db, want_score=False):
+    """argmax_j queries[q] . db[j]  ->  int32 [n] (first index on ties)."""
+    n, m, d = queries.shape[0], db.shape[0], db.shape[1]
+    nn = torch.empty((n,), dtype=torch.int32, device=db.device)
+    score = torch.empty((n,), dtype=torch.float32, device=db.device) if want_score else None
+    if n:
+        _lib.check(_lib.lib().st3r_nn_dot_argmax(ctx.handle, ops._stream(), ops._p(queries), n, ops._p(db), m, d,
+                                                 ops._p(nn, torch.int32), ops._p(score)))
+    return (nn, score) if want_score else nn
+
+
+def merge_corres(idx1, idx2, shape1=None, shape2=None, ret_xy=True):
+    """unique correspondences sorted on (idx2, idx1) packed as one int64 -- Mast3r merge_corres."""
+    key = (idx2.to(torch.int64) & 0xFFFFFFFF) | (idx1.to(torch.int64) << 32)  # little endian view of np.c_[idx2, idx1]
+    key = torch.unique(key)  # sorted
+    i2 = (key & 0xFFFFFFFF).to(torch.int32); i1 = (key >> 32).to(torch.int32)
+    if ret_xy and shape1 is not None:
+        W1, W2 = shape1[1], shape2[1]
+        xy1 = torch.stack((i1 % W1, torch.div(i1, W1, rounding_mode="floor")), dim=-1)
+        xy2 = torch.stack((i2 % W2, torch.div(i2, W2, rounding_mode="floor")), dim=-1)
+        return xy1, xy2
+    return i1, i2
+
+
+def fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy=True, device="cuda", max_iter=10, **matcher_kw):
+    """pts1 [H1,W1,D], pts2 [H2,W2,D] float32 descriptors -> matched (xy1, xy2) or flat indices.
+    Only the reference's configuration is implemented: integer subsample, pixel_tol=0, dist='dot'."""
+    assert matcher_kw.get("dist", "dot") == "dot", "only dist='dot' (the reference's choice) is implemented"
+    ctx = ops.get_context(device)
+    dev = ctx.device
+    H1, W1, D1 = pts1.shape; H2, W2, D2 = pts2.shape
+    assert D1 == D2
+    A = pts1.reshape(-1, D1).to(dev, torch.float32).contiguous()
+    B = pts2.reshape(-1, D2).to(dev, torch.float32).contiguous()
+    S = int(subsample_or_initxy1)
+    y1, x1 = np.mgrid[S // 2:H1:S, S // 2:W1:S].reshape(2, -1)
+    xy1 = torch.as_tensor(np.int32(np.unique(x1 + W1 * y1)), device=dev)
+    xy2 = torch.full_like(xy1, -1)
+    old_xy1 = xy1.clone(); old_xy2 = xy2.clone()
+    notyet = torch.ones_like(xy1, dtype=torch.bool)
+    niter = 0
+    while bool(notyet.any()):
+        act = torch.nonzero(notyet).reshape(-1)
+        xy2[act] = nn_dot_argmax(ctx, A[xy1[act].long()], B)
+        notyet &= (old_xy2 != xy2)      # remove points that have converged
+        act = torch.nonzero(notyet).reshape(-1)
+        xy1[act] = nn_dot_argmax(ctx, B[xy2[act].long()], A)
+        notyet &= (old_xy1 != xy1)
+        niter += 1
+        if niter >= max_iter:
+            break
+        old_xy2.copy_(xy2); old_xy1.copy_(xy1)
+    converged = ~notyet
+    return merge_corres(xy1[converged], xy2[converged], (H1, W1), (H2, W2), ret_xy=ret_xy)

@@ -76,6 +76,8 @@ def make_problem(n_views=2, width=512, height=384, n_corr=2000, seed=0, bad_pair
                 keep.append(facing & inside & (pc[:, 2] > 0.1)); proj[v] = (uv, pc[:, 2])
             ok = np.nonzero(keep[0] & keep[1])[0][:n_corr]
             n = len(ok)
+            if n == 0:
+                continue  # the two views see disjoint parts of the sphere: no pair, as in a real scene graph
             starts = {}
             for v in (i, j):
                 uv, z = proj[v][0][ok], proj[v][1][ok]
