@@ -51,7 +51,9 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
              trans=torch.zeros(Cn, 3, device=dev), log_sizes=torch.zeros(Cn, device=dev))
     if prev_params is not None:
         for k in PARAM_KEYS:
-            prev = torch.as_tensor(np.asarray(prev_params[k]), dtype=torch.float32, device=dev)
+            prev = prev_params[k]
+            prev = prev.detach() if torch.is_tensor(prev) else torch.as_tensor(np.asarray(prev))
+            prev = prev.to(dev, torch.float32)
             n = min(prev.shape[0], Cn)
             P[k][:n] = prev[:n].reshape(P[k][:n].shape)
     work = torch.zeros(66 * Cn + 8, device=dev)

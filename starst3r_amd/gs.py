@@ -1,0 +1,254 @@
+"""3D Gaussian Splatting refinement -- drop-in for the reference's `starster.gs`
+(starster/gs.py:14-166; docs/api.rst "3DGS refinement"): same function names, arguments, defaults,
+return values and `scene.*` attributes, with every per-iteration operation running in
+libst3r_hip.so (no gsplat, no torchmetrics, no autograd graph in the training loop).
+
+Reference quirks that are reproduced on purpose: scales/opacities are rendered RAW
+(gs.py:79-80) while the regularisers treat them as log / logit (gs.py:132,134); sh0 is allocated and
+given an optimiser but never rendered (gs.py:25,29 vs :81); colours are initialised as 1 - colour in every
+SH row (gs.py:29-31); both regularisers are added once per view (gs.py:150-152); `step` restarts at 0 on
+every run_3dgs_optim call (gs.py:143) while the Adam step counters persist.
+"""
+__all__ = (
+    "init_3dgs",
+    "render_3dgs",
+    "render_3dgs_original",
+    "run_3dgs_optim",
+    "train",
+)
+
+import numpy as np
+import torch
+
+from . import dist as _dist
+from . import ops
+
+GAUSSIAN_KEYS = ("means", "scales", "quats", "opacities", "sh0", "shN")
+ADAM_BLOCKS = (("means", 3), ("quats", 4), ("scales", 3), ("opacities", 1), ("shN", 12))  # block layout of [23N]
+
+
+class FusedAdam:
+    """Stands where the reference keeps one torch.optim.Adam per tensor (gs.py:37): exposes the slice of the
+    fused optimiser state (exp_avg, exp_avg_sq, step) that belongs to one parameter."""
+
+    def __init__(self, owner, key):
+        self._owner, self.key = owner, key
+        self.param_groups = [dict(params=[owner.scene.gaussians[key]], lr=owner.lr, betas=owner.betas, eps=owner.eps)]
+
+    @property
+    def state(self):
+        o = self._owner
+        if self.key == "sh0":  # never receives a gradient in the reference (grad is None): no state
+            return {}
+        sl = o.block_slice(self.key)
+        return {self.param_groups[0]["params"][0]: dict(step=o.step, exp_avg=o.m[sl], exp_avg_sq=o.v[sl])}
+
+    def step(self):
+        raise RuntimeError("the fused optimiser is stepped by run_3dgs_optim (st3r_adam_step), not per tensor")
+
+    def zero_grad(self, set_to_none=True):
+        pass
+
+
+class _OptimState:
+    def __init__(self, scene, lr):
+        N = scene.gaussians["means"].shape[0]
+        dev = scene.gaussians["means"].device
+        self.scene, self.lr, self.betas, self.eps, self.step, self.N = scene, lr, (0.9, 0.999), 1e-8, 0, N
+        self.m = torch.zeros(23 * N, device=dev); self.v = torch.zeros(23 * N, device=dev)
+        self.grads = torch.empty(23 * N, device=dev)
+
+    def block_slice(self, key):
+        off = 0
+        for k, w in ADAM_BLOCKS:
+            if k == key:
+                return slice(off * self.N, (off + w) * self.N)
+            off += w
+        raise KeyError(key)
+
+
+class SSIM:
+    """Callable stand-in for torchmetrics StructuralSimilarityIndexMeasure(data_range=1) (gs.py:39):
+    `ssim(preds, target)` with (B,3,H,W) tensors returns the mean SSIM, computed by st3r_loss_l1_ssim."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def __call__(self, preds, target):
+        ctx = ops.get_context(self.device)
+        x = preds.permute(0, 2, 3, 1).contiguous().float(); y = target.permute(0, 2, 3, 1).contiguous().float()
+        sums, _ = ops.loss_l1_ssim(ctx, x, y, 1.0, 0.0, want_grad=False)
+        H, W = x.shape[1], x.shape[2]
+        return (sums[:, 1] / ((H - 10) * (W - 10) * 3)).mean().float()
+
+
+class MCMCStrategy:
+    """Place holder for gsplat.MCMCStrategy() (gs.py:43-45) with its default hyper-parameters.  Position
+    noise is applied as in the reference; relocation / growth (fires only for step > 500 inside one call,
+    SURVEY App. B-6) is the next hot-path row and raises until it lands."""
+    cap_max = 1_000_000; noise_lr = 5e5; refine_start_iter = 500; refine_stop_iter = 25_000
+    refine_every = 100; min_opacity = 0.005
+
+    def check_sanity(self, params, optimizers):
+        for k in ("means", "scales", "quats", "opacities"):
+            assert k in params and k in optimizers, f"{k} is required"
+
+    def initialize_state(self):
+        return {"binoms": None}
+
+    def step_pre_backward(self, params, optimizers, state, step, info):
+        return None
+
+    def step_post_backward(self, params, optimizers, state, step, info, lr):
+        if self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0:
+            raise NotImplementedError("MCMC relocation/growth is not implemented yet (SURVEY.md 8(f) row 1)")
+        with torch.no_grad():  # inject_noise_to_position (gsplat) -- O(N) element-wise, not on the hot path
+            op = torch.sigmoid(params["opacities"])
+            gate = 1.0 / (1.0 + torch.exp(-100.0 * ((1.0 - op) - 0.995)))
+            q = torch.nn.functional.normalize(params["quats"], dim=-1)
+            w, x, y, z = q.unbind(-1)
+            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                             2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                             2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+            M = R * torch.exp(params["scales"])[:, None, :]
+            cov = M @ M.transpose(1, 2)
+            noise = torch.randn_like(params["means"]) * gate[:, None] * (lr * self.noise_lr)
+            params["means"].add_((cov @ noise[..., None]).squeeze(-1))
+
+
+def init_3dgs(scene, init_scale=3e-3, lr=1e-3):
+    """Initialize 3DGS splats and optims from Mast3r dense points (reference gs.py:14-45)."""
+    pts = scene.dense_pts_flat
+    colors = scene.dense_cols_flat
+    n = pts.shape[0]
+    g = {
+        "means": pts.clone().float(),
+        "scales": torch.full_like(pts, init_scale, dtype=torch.float32),
+        "quats": torch.zeros(n, 4),
+        "opacities": torch.ones(n),
+        "sh0": torch.zeros(n, 1, 3),
+        "shN": torch.zeros(n, 24, 3),
+    }
+    g["quats"][:, 0] = 1.0
+    inv = (1 - colors).float()
+    g["sh0"][:, 0] = inv
+    g["shN"][:] = inv[:, None, :]
+    scene.gaussians = {k: torch.nn.Parameter(v.to(scene.device).contiguous(), requires_grad=True) for k, v in g.items()}
+    scene._gs_optim = _OptimState(scene, lr)
+    scene.optimizers = {k: FusedAdam(scene._gs_optim, k) for k in scene.gaussians}
+    scene.ssim = SSIM(scene.device)
+    scene.strategy = MCMCStrategy()
+    scene.strategy.check_sanity(scene.gaussians, scene.optimizers)
+    scene.strategy_state = scene.strategy.initialize_state()
+    scene._gt_dev = None
+
+
+class _Rasterize(torch.autograd.Function):
+    """Differentiable wrapper so user code can still back-propagate through render_3dgs."""
+
+    @staticmethod
+    def forward(fctx, means, quats, scales, opacities, shN, w2c, Ks, width, height, ctx):
+        rgb, alpha, info = ops.rasterization(ctx, means, quats, scales, opacities, shN, w2c, Ks, width, height)
+        fctx.save_for_backward(means, quats, scales, opacities, shN, w2c, Ks, alpha)
+        fctx.info, fctx.ctx, fctx.wh = info, ctx, (width, height)
+        return rgb, alpha
+
+    @staticmethod
+    def backward(fctx, v_rgb, v_alpha):
+        means, quats, scales, opacities, shN, w2c, Ks, alpha = fctx.saved_tensors
+        info, ctx, (W, H) = fctx.info, fctx.ctx, fctx.wh
+        Cn = w2c.shape[0]
+        # the backward consumes the contribution masks the forward left in the ctx: re-run the blend forward so
+        # that they belong to THIS rasterization even if other renders happened in between
+        ops.blend_fwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], Cn, W, H)
+        v_splats = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
+                                 info["_last_ids"], v_rgb.contiguous().float(),
+                                 None if v_alpha is None else v_alpha.contiguous().float(), info["_cum_tiles"], Cn, W, H)
+        grads = ops.project_sh_bwd(ctx, means, quats, scales, opacities, shN, w2c, Ks, info["_campos"], W, H,
+                                   info["_splats"], v_splats)
+        G = ops.split_grads(grads, means.shape[0])
+        v_sh = torch.zeros_like(shN)
+        v_sh[:, :4] = G["sh"]
+        return G["means"], G["quats"], G["scales"], G["opacities"], v_sh, None, None, None, None, None
+
+
+def render_3dgs(scene, w2c: torch.Tensor, intrinsics: torch.Tensor, width: int, height: int):
+    """Render the splats from a set of camera views (reference gs.py:47-88).
+
+    Returns the tuple the reference gets from gsplat.rasterization: (render_img (N,H,W,3),
+    render_alpha (N,H,W,1), info)."""
+    g = scene.gaussians
+    ctx = ops.get_context(scene.device)
+    w2c = w2c.to(scene.device, torch.float32).contiguous(); Ks = intrinsics.to(scene.device, torch.float32).contiguous()
+    rgb, alpha = _Rasterize.apply(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, width,
+                                  height, ctx)
+    # the info dict of the most recent rasterization (gsplat's `meta`)
+    info = {k: v for k, v in ops.last_info().items() if not k.startswith("_")}
+    return rgb, alpha, info
+
+
+def render_3dgs_original(scene, width: int, height: int):
+    """Render from camera views of original scene (reference gs.py:90-95)."""
+    return scene.render_3dgs(scene.w2c, scene.intrinsics, width, height)
+
+
+def _gt_on_device(scene, views):
+    """GT images are uploaded once and cached (the reference re-uploads every view every iteration, gs.py:151)."""
+    key = (tuple(views), len(scene.imgs))
+    if getattr(scene, "_gt_dev", None) is None or scene._gt_dev[0] != key:
+        imgs = [torch.as_tensor(np.asarray(scene.imgs[i]), dtype=torch.float32) for i in views]
+        scene._gt_dev = (key, torch.stack(imgs).to(scene.device).contiguous())
+    return scene._gt_dev[1]
+
+
+def run_3dgs_optim(
+        scene,
+        iters: int,
+        enable_pruning: bool = False,
+        loss_ssim_fac=0.2,
+        loss_opacity_fac=0.01,
+        loss_scale_fac=0.01,
+        verbose: bool = False,
+    ) -> list:
+    """Run 3DGS optimization and pruning (optional) for a number of iterations (reference gs.py:97-166).
+
+    Returns the list of per-iteration losses (floats).  Under torch.distributed (one process per GPU, RCCL)
+    the views are sharded over the ranks, the [23N] gradient buffer is sum-all-reduced every iteration and
+    every rank applies the identical fused Adam update; the returned losses are the sums over all views.
+    """
+    height, width = scene.imgs[0].shape[:2]
+    ctx = ops.get_context(scene.device)
+    st = scene._gs_optim
+    g = scene.gaussians
+    rank, world = _dist.rank_world()
+    views = _dist.shard_views(len(scene.imgs), rank, world)
+    w2c_all = scene.w2c.to(scene.device, torch.float32)
+    w2c = w2c_all[views].contiguous()
+    Ks = scene.intrinsics.to(scene.device, torch.float32)[views].contiguous()
+    campos = ops.camera_positions(w2c)
+    gt = _gt_on_device(scene, views)
+    losses = torch.zeros(max(iters, 1), device=scene.device)
+    P = {k: g[k].data for k in ("means", "quats", "scales", "opacities", "shN")}
+    it_range = range(iters)
+    if verbose:
+        from tqdm import trange
+        it_range = trange(iters)
+    for step in it_range:
+        if enable_pruning:
+            scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
+        ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
+                          loss_scale_fac, st.grads, losses[step:step + 1])
+        _dist.all_reduce_sum(st.grads)
+        st.step += 1
+        ops.adam_step(ctx, P, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step)
+        if enable_pruning:
+            scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
+    _dist.all_reduce_sum(losses)
+    return losses[:iters].cpu().tolist()   # one device->host copy for the whole call (reference: .item() per step)
+
+
+train = run_3dgs_optim  # alias for the wording of BASELINE.json's north_star ("gs.train()")

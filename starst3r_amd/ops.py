@@ -261,4 +261,14 @@ def rasterization(ctx, means, quats, scales, opacities, colors, viewmats, Ks, wi
             # dense-id extras used by the backward / tests
             _splats=splats, _flatten_ids_dense=flat_s, _last_ids=last, _isect_ids_unsorted=ids,
             _flatten_ids_dense_unsorted=flat, _packed_of_dense=packed_of_dense, _campos=campos, _cum_tiles=cum)
+        global _LAST_INFO
+        _LAST_INFO = info
     return rgb, alpha, info
+
+
+_LAST_INFO = None
+
+
+def last_info():
+    """info dict of the most recent ops.rasterization(want_info=True) call (gsplat's `meta`)."""
+    return _LAST_INFO

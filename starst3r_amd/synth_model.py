@@ -1,0 +1,47 @@
+"""A synthetic stand-in for the Mast3r front end (BASELINE.json configs[0]: plumbing without weights).
+
+Implements the `model.condense(...)` protocol of starst3r_amd.reconstruct on a textured unit sphere seen by
+n cameras: "pairwise predictions" are exact geometry plus noise, so the alignment has a known answer and the
+3DGS stage has real images to fit.  Pure numpy; used by tests and examples, never by the hot path itself.
+"""
+import numpy as np
+
+from . import synth_align
+
+
+class SyntheticPairwiseModel:
+    def __init__(self, width=256, height=192, n_corr=600, seed=0, conf=3.0):
+        self.width, self.height, self.n_corr, self.seed, self.conf = width, height, n_corr, seed, conf
+
+    def condense(self, imgs, filelist, device, cache_dir):
+        C = len(imgs)
+        W, H = self.width, self.height
+        P = synth_align.make_problem(n_views=C, width=W, height=H, n_corr=self.n_corr, seed=self.seed)
+        flat = synth_align.flatten(P)
+        f = float(P["K_true"][0, 0])
+        S = 8
+        gw = W // S
+        ys, xs = np.mgrid[0:H, 0:W]
+        pix = np.stack([xs.reshape(-1) + 0.5, ys.reshape(-1) + 0.5], -1).astype(np.float64)
+        out_imgs, dense = [], []
+        for v in range(C):
+            c2w = P["c2w_true"][v].astype(np.float64)
+            rays = np.stack([(pix[:, 0] - W / 2) / f, (pix[:, 1] - H / 2) / f, np.ones(len(pix))], -1)
+            d = rays @ c2w[:3, :3].T; o = c2w[:3, 3]
+            b = d @ o; a = (d * d).sum(-1); cc = o @ o - 1.0
+            disc = b * b - a * cc
+            hit = disc > 0
+            t = np.where(hit, (-b - np.sqrt(np.maximum(disc, 0))) / a, 3.5)
+            pw = o + d * t[:, None]
+            # procedural texture of the sphere surface (smooth, view independent), grey background
+            tex = 0.5 + 0.5 * np.stack([np.sin(4 * pw[:, 0] + 1), np.sin(5 * pw[:, 1] + 2), np.sin(3 * pw[:, 2])], -1)
+            img = np.where(hit[:, None], tex, 0.35).reshape(H, W, 3).astype(np.float32)
+            out_imgs.append(img)
+            idx = (np.floor(pix[:, 1] / S).astype(np.int64) * gw + np.floor(pix[:, 0] / S).astype(np.int64))
+            off = (t / P["core_depth"][v][idx]).astype(np.float32)
+            confs = np.where(hit, self.conf, 1.0).astype(np.float32)  # only sphere pixels pass conf_thres=1.5
+            dense.append(dict(pixels=pix.astype(np.float32), idxs=idx, offsets=off, confs=confs,
+                              base_focal=float(P["base_focals"][v])))
+        flat["imgs"] = out_imgs
+        flat["dense"] = dense
+        return flat
