@@ -115,6 +115,44 @@ def cpu_baseline(args):
     }
 
 
+def align_bench(device, with_cpu=True, views=8):
+    """Secondary metric "align sec": wall time of the reference's 500+200-iteration global alignment
+    (starster/reconstruct.py:427,440) on a synthetic condensed problem -- HIP path vs the torch-CPU oracle
+    (a port of the reference loop, validated against reference-generated goldens) on the host cores."""
+    from starst3r_amd import align, synth_align
+    flat = synth_align.flatten(synth_align.make_problem(n_views=views, n_corr=2000 // (views - 1) + 1, seed=1))
+    align.run(flat, niter1=3, niter2=3, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res, _ = align.run(flat, device=device)
+    torch.cuda.synchronize()
+    hip_s = time.perf_counter() - t0
+    L = res["losses"].cpu().numpy()
+    out = {"views": views, "anchors": int(flat["anchor_idx"].size), "correspondence_rows": int(flat["corr_a1"].size),
+           "iterations": "500+200", "hip_seconds": hip_s, "hip_ms_per_iter": hip_s / 700 * 1e3,
+           "loss_stage1": [float(L[0]), float(L[499])], "loss_stage2": [float(L[500]), float(L[-1])],
+           "bound": "launch latency (2 launches/iteration; working set in L2) -- not roofline bound"}
+    if with_cpu:
+        from oracle import align_oracle
+        # The loop is ~6400 tiny ATen ops per iteration (SURVEY.md 6): more intra-op threads only add
+        # synchronisation cost (256 threads on the GPU box's host: >20 minutes).  8 threads is the setting the
+        # survey measured (7.3-7.9 s on 8 Xeon cores); a 100+40-iteration sample keeps the run bounded and is
+        # scaled to the full 500+200 schedule (cost per iteration is constant).
+        cores = min(8, os.cpu_count() or 1)
+        prev_threads = torch.get_num_threads()
+        torch.set_num_threads(cores)
+        t0 = time.perf_counter()
+        align_oracle.run(flat, niter1=100, niter2=40)
+        cpu_sample = time.perf_counter() - t0
+        torch.set_num_threads(prev_threads)
+        cpu_s = cpu_sample * 5.0
+        out.update(cpu_port_seconds=cpu_s, cpu_cores=cores, cpu_kind="port", cpu_sample_seconds=cpu_sample,
+                   cpu_note="oracle/align_oracle.py (torch CPU autograd restatement of reconstruct.py:116-457), "
+                            f"{cores} intra-op threads, 100+40 iterations timed and scaled x5 to 500+200",
+                   speedup=cpu_s / hip_s)
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -219,6 +257,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         else:
             out["cpu_baseline"] = None
+        if world == 1:
+            out["align"] = align_bench(device, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
