@@ -126,7 +126,10 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
     __shared__ uint64_t sMask[4][4];  // [quadrant][64-record chunk]
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    bool done = !g.inside;
+    // Per-lane state is kept in VGPRs and updated with selects instead of branches: the scalar unit (one per
+    // CU, shared by the 4 SIMDs) was the limiter of the branchy version (~38 SALU instructions of exec-mask
+    // bookkeeping per record; PMC: SQ_INSTS_SALU ~ SQ_INSTS_VALU).  `live` is 1.0 until the pixel saturates.
+    float live = g.inside ? 1.0f : 0.0f;
     float T = 1.0f, r = 0.f, gg = 0.f, b = 0.f;
     int cur = 0;
     int nb = 0;
@@ -135,49 +138,47 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
 #endif
     const int64_t mbase = mask_base(g.lb, g.start);
     for (int bs = g.start; bs < g.end; bs += BLK, ++nb) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(live == 0.0f)) break;
         const int idx = bs + threadIdx.x;
         int rel = 0;
         if (idx < g.end) rel = stage_record(splats, flat[idx], threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
         const uint64_t m0 = __ballot(rel & 1), m1 = __ballot(rel & 2), m2 = __ballot(rel & 4), m3 = __ballot(rel & 8);
         if (lane == 0) { sMask[0][w] = m0; sMask[1][w] = m1; sMask[2][w] = m2; sMask[3][w] = m3; }
+#ifdef ST3R_STATS
+        if (lane == 0) atomicAdd(&g_blend_stats[7], (unsigned long long)__popcll(m0 | m1 | m2 | m3));
+#endif
         __syncthreads();
 #pragma unroll 1
         for (int jj = 0; jj < 4; ++jj) {
             uint64_t m = uniform_u64(sMask[w][jj]);
             uint64_t contributed = 0;
-            if (__all(done)) m = 0;
+            if (__builtin_amdgcn_ballot_w64(live != 0.0f) == 0) m = 0;  // every pixel of this wave is saturated
             while (m) {
                 const int bit = __builtin_ctzll(m);
                 m &= m - 1;
                 const int t = jj * 64 + bit;
                 const float4 a = sA[t];
                 const float4 q = sB[t];
+                const float cb = sC[t];
                 const float dx = a.x - g.px, dy = a.y - g.py;
                 const float P = dx * (a.w * dx + q.x * dy) + q.y * dy * dy;
-                const float alpha = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
-                const bool valid = !done && !(P > 0.f) && !(alpha < 1.f / 255.f);
+                float al = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
+                al = (P > 0.f) ? 0.f : al;               // sigma < 0: skipped
+                al = (al < 1.f / 255.f) ? 0.f : al;      // below the visibility threshold: skipped
+                al *= live;                              // saturated pixel: skipped
+                const float nT = T * (1.0f - al);        // == T exactly when al == 0
+                const bool stop = nT <= 1e-4f;           // only a live pixel with al > 0 can get here (T > 1e-4 otherwise)
+                live = stop ? 0.0f : live;
+                al = stop ? 0.0f : al;                   // the record that saturates the pixel is not blended
+                const float vis = al * T;
+                T = stop ? T : nT;
+                r += q.z * vis; gg += q.w * vis; b += cb * vis;
+                const bool took = al > 0.0f;
+                cur = took ? bs + t : cur;
+                const uint64_t tm = __builtin_amdgcn_ballot_w64(took);
+                contributed |= tm ? (1ull << bit) : 0ull;
 #ifdef ST3R_STATS
-                st_rel++; st_lanes += __popcll(__ballot(valid));
-#endif
-                if (!__any(valid)) continue;
-#ifdef ST3R_STATS
-                st_any++;
-#endif
-                const float nT = T * (1.0f - alpha);
-                const bool stop = valid && (nT <= 1e-4f);
-                const bool take = valid && !stop;
-                done = done || stop;
-                if (take) {
-                    const float vis = alpha * T;
-                    r += q.z * vis; gg += q.w * vis; b += sC[t] * vis;
-                    cur = bs + t;
-                    T = nT;
-                }
-                if (__any(take)) contributed |= (1ull << bit);
-#ifdef ST3R_STATS
-                if (__any(take)) st_con++;
-                st_take += __popcll(__ballot(take));
+                st_rel++; st_con += tm ? 1 : 0; st_take += __popcll(tm); st_any += tm ? 1 : 0; st_lanes += __popcll(tm);
 #endif
             }
             if (cmask && lane == 0) cmask[(int64_t)w * cmask_words + mbase + nb * 4 + jj] = contributed;

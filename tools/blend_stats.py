@@ -15,7 +15,7 @@ rgb, alpha, st = ops.render(ctx, P, vm, K, ops.camera_positions(vm), W, H)
 torch.cuda.synchronize()
 L.st3r_debug_blend_stats(buf, 0)
 I = st["n_isects"]
-names = ["batches", "relevant (entry,wave)", "any-valid", "contributed", "valid lanes", "taken lanes", "entries in lists"]
+names = ["batches", "relevant (entry,wave)", "any-valid", "contributed", "valid lanes", "taken lanes", "entries in lists", "staged records relevant to >=1 quadrant"]
 for n, v in zip(names, buf):
     print(f"{n:24s} {v:>14d}")
 print("I =", I, " entries staged =", buf[0] * 256, " staged/I = %.3f" % (buf[0] * 256 / I))
