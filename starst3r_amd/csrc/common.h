@@ -52,6 +52,7 @@ enum ArenaSlot {
     SLOT_CMASK,
     SLOT_TILE_NB,
     SLOT_VTILE,
+    SLOT_VSTAMP,
     SLOT_DKEYS_A,
     SLOT_DKEYS_B,
     SLOT_DVALS_A,

@@ -298,7 +298,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 #define ACC_STRIDE 9
-#define VT_STRIDE 10  // per-(record, tile) slot: 9 partial gradients + stamp
+#define VT_STRIDE 12  // per-(record, tile) slot: 9 partial gradients (+3 pad) = 3 x 16 B; stamps live in a side array
 
 __device__ __forceinline__ int tile_clampi(float v, int hi) {
     if (!(v > 0.0f)) return 0;
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const uint64_t* __restrict__ cmask, int64_t cmask_words,
                                                    const int32_t* __restrict__ tile_nb,
                                                    const int32_t* __restrict__ cum, int tile_size_unused,
-                                                   float* __restrict__ vtile, int stamp) {
+                                                   float* __restrict__ vtile, int32_t* __restrict__ vstamp,
+                                                   int stamp) {
     __shared__ float4 sA[BLK];
     __shared__ float4 sB[BLK];
     __shared__ float sC[BLK];
@@ -426,10 +427,11 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                 const int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
                 const int cum_excl = my_id == 0 ? 0 : cum[my_id - 1];
                 const int64_t u = (int64_t)cum_excl + ((g.ty0 >> 4) - y0) * (x1 - x0) + ((g.tx0 >> 4) - x0);
-                float* dst = vtile + u * VT_STRIDE;
-#pragma unroll
-                for (int k = 0; k < ACC_STRIDE; ++k) dst[k] = acc[k];
-                dst[ACC_STRIDE] = __int_as_float(stamp);
+                float4* dst = reinterpret_cast<float4*>(vtile + u * VT_STRIDE);
+                dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+                vstamp[u] = stamp;
             }
         }
     }
@@ -438,7 +440,8 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
 // v_splats[pid] = sum over the pair's tiles of the slots stamped by this backward call, in slot order
 // (deterministic given the slots).  One thread per (camera, gaussian) pair.
 __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int32_t* __restrict__ cum,
-                                                      const float* __restrict__ vtile, int stamp,
+                                                      const float* __restrict__ vtile,
+                                                      const int32_t* __restrict__ vstamp, int stamp,
                                                       float4* __restrict__ v_splats) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= n_pairs) return;
@@ -448,10 +451,12 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
 #pragma unroll
     for (int k = 0; k < ACC_STRIDE; ++k) acc[k] = 0.f;
     for (int u = start; u < end; ++u) {
-        const float* src = vtile + (int64_t)u * VT_STRIDE;
-        if (__float_as_int(src[ACC_STRIDE]) == stamp) {
-#pragma unroll
-            for (int k = 0; k < ACC_STRIDE; ++k) acc[k] += src[k];
+        if (vstamp[u] == stamp) {  // the payload is only fetched for slots written by this backward call
+            const float4* src = reinterpret_cast<const float4*>(vtile + (int64_t)u * VT_STRIDE);
+            const float4 a = src[0], b = src[1];
+            const float c = vtile[(int64_t)u * VT_STRIDE + 8];
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c;
         }
     }
     v_splats[pid * 3 + 0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -463,8 +468,10 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
                         const int32_t* cum, int64_t n_pairs, float* v_splats) {
+    // v_splats == NULL: leave the result in the stamped partial slots (consumed by the fused project backward)
     if (n_isects == 0) {
-        HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
+        ++ctx->bwd_stamp;
+        if (v_splats) HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
         return ST3R_OK;
     }
     uint64_t* cmask; int64_t words; int32_t* tile_nb;
@@ -475,17 +482,22 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     void* p; int grown = 0;
     rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * VT_STRIDE * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
-    if (grown) HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VTILE], s));
     float* vtile = (float*)p;
+    rc = st3r_arena_get2(ctx, SLOT_VSTAMP, sizeof(int32_t) * (size_t)n_isects, &p, &grown);
+    if (rc) return rc;
+    if (grown) HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VSTAMP], s));
+    int32_t* vstamp = (int32_t*)p;
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
     hipLaunchKernelGGL(k_blend_bwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
                        offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask, words, tile_nb, cum, 16,
-                       vtile, stamp);
+                       vtile, vstamp, stamp);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp,
-                       (float4*)v_splats);
-    LAUNCH_CHECK();
+    if (v_splats) {
+        hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, vstamp, stamp,
+                           (float4*)v_splats);
+        LAUNCH_CHECK();
+    }
     return ST3R_OK;
 }
 
