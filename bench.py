@@ -218,7 +218,10 @@ def main():
     L = losses.cpu().numpy()
 
     if rank == 0:
-        V, I = stats["n_visible"], stats["n_isects"]
+        # I = tile intersections of the reference algorithm (gsplat's 3-sigma squares): the unit the algorithmic-byte
+        # formula is written in.  The fused path sorts/blends only the I_kept of them whose alpha >= 1/255 box
+        # reaches the tile (the dropped ones fail the alpha test on all 256 pixels).
+        V, I, I_kept = stats["n_visible"], stats["n_isects_ref"], stats["n_isects"]
         P_px = C_local * H * W
         tw, th = ops.tile_grid(W, H)
         keybits = 32 + (tw * th).bit_length() + C_local.bit_length()
@@ -238,7 +241,8 @@ def main():
                 "workload": f"SYNTH-1M (BASELINE.json configs[2]): {N} gaussians, {args.views} views {W}x{H}, "
                             f"3DGS train only; views sharded {C_local}/GPU, gaussians replicated",
                 "gaussians": N, "views": args.views, "width": W, "height": H, "views_per_gpu": C_local,
-                "parallelism": f"view-dp{world}", "n_visible_pairs": V, "n_isects": I, "sort_key_bits": keybits,
+                "parallelism": f"view-dp{world}", "n_visible_pairs": V, "n_isects": I, "n_isects_kept_after_exact_culling": I_kept,
+                "sort_key_bits": keybits,
                 "mean_tiles_per_visible_gaussian": (I / V) if V else 0.0,
                 "mean_gaussians_per_tile": I / (C_local * tw * th),
                 "loss_first": float(L[0]), "loss_last": float(L[-1]),

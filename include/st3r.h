@@ -157,7 +157,8 @@ int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quat
  *   grads   [23*N]  written (not accumulated)
  *   loss_out        device float; receives this rank's loss (sum over its views, regularisers
  *                   added reg_views times)
- *   stats_host[4]   optional host int64: n_visible_pairs, n_isects, arena bytes, 0
+ *   stats_host[4]   optional host int64: n_visible_pairs, n_isects actually sorted/blended (after exact tile
+ *                   culling), arena bytes, n_isects of the reference algorithm (gsplat's 3-sigma squares)
  * The second half is an (optional) all-reduce of `grads` by the caller, then st3r_adam_step.
  * ---------------------------------------------------------------------------------- */
 int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,

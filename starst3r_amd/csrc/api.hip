@@ -167,11 +167,11 @@ int st3r_project_impl(hipStream_t s, int N, int C, const float* means, const flo
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals);
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight);
 int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
                               const int32_t* perm, int32_t* cum, int32_t** total_dev_out);
 int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
-                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h,
+                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h, int tight,
                                 uint32_t* tile_keys, int32_t* vals);
 int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
                               int32_t* offsets);
@@ -185,7 +185,7 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        const int32_t* cum, int64_t n_pairs, float* v_splats);
+                        const int32_t* cum, int tight, int64_t n_pairs, float* v_splats);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -201,14 +201,14 @@ static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } r
     }
 
 struct RasterOut {
-    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; int64_t n_isects, n_visible; int tile_w, tile_h;
+    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
 };
 
 // project -> scan -> emit -> sort -> offsets, all in ctx scratch
 static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats,
                            const float* scales, const float* opacities, const float* sh, int sh_stride,
                            const float* viewmats, const float* Ks, const float* campos, int W, int H,
-                           double* reg_sums, RasterOut* o) {
+                           double* reg_sums, int tight, RasterOut* o) {
     const int tile = 16;
     const int tile_w = (W + tile - 1) / tile, tile_h = (H + tile - 1) / tile;
     const int64_t n_pairs = (int64_t)N * C;
@@ -226,7 +226,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_CUM_D, int32_t, n_pairs, cum_d);
     st3r_prof_begin(ctx, s, STG_PROJECT);
     int rc = st3r_project_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                               tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums, dkeys_a, dvals_a);
+                               tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums, dkeys_a, dvals_a, tight);
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
@@ -246,10 +246,11 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     if (rc) return rc;
     {   // read back the intersection count (and the visible-pair count) -- the one host sync per step
         HIP_TRY(hipMemcpyAsync(ctx->pinned, total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        if (reg_sums) HIP_TRY(hipMemcpyAsync(ctx->pinned + 1, reg_sums + 2, sizeof(double), hipMemcpyDeviceToHost, s));
+        if (reg_sums) HIP_TRY(hipMemcpyAsync(ctx->pinned + 1, reg_sums + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         n_isects = (int64_t)((int32_t*)ctx->pinned)[0];
         o->n_visible = reg_sums ? (int64_t)((double*)ctx->pinned)[1] : -1;
+        o->n_isects_ref = reg_sums ? (int64_t)((double*)ctx->pinned)[2] : n_isects;
     }
     GET(SLOT_KEYS_A, uint32_t, n_isects, tkeys_a);
     GET(SLOT_KEYS_B, uint32_t, n_isects, tkeys_b);
@@ -257,7 +258,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
     if (n_isects > 0) {
         st3r_prof_begin(ctx, s, STG_EMIT);
-        rc = st3r_isect_emit_sorted_impl(s, N, C, splats, perm, cum_d, tile, tile_w, tile_h, tkeys_a, vals_a);
+        rc = st3r_isect_emit_sorted_impl(s, N, C, splats, perm, cum_d, tile, tile_w, tile_h, tight, tkeys_a, vals_a);
         st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
         const int end_bit = bit_length_u32((uint32_t)((int64_t)C * tile_w * tile_h - 1));
@@ -299,12 +300,12 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     const int64_t n_pairs = (int64_t)N * C, n_px = (int64_t)C * H * W;
     GET(SLOT_SMALL, double, 2 * (size_t)C + 8, small);
     double* sums = small;              // [C,2]
-    double* reg_sums = small + 2 * C;  // [3]
-    HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 3, s));
+    double* reg_sums = small + 2 * C;  // [4]: sum sigmoid(o), sum exp(s), visible pairs, reference intersections
+    HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 4, s));
     st3r_prof_next_step(ctx);
     RasterOut ro;
     int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                             reg_sums, &ro);
+                             reg_sums, 1, &ro);
     if (rc) return rc;
     GET(SLOT_RGB, float, n_px * 3, rgb);
     GET(SLOT_ALPHA, float, n_px, alpha);
@@ -322,7 +323,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, n_pairs, v_splats);
+                             last, v_rgb, nullptr, ro.cum, 1, n_pairs, v_splats);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
@@ -338,7 +339,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     LAUNCH_CHECK();
     if (stats_host) {
         stats_host[0] = ro.n_visible; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx);
-        stats_host[3] = 0;
+        stats_host[3] = ro.n_isects_ref;
     }
     return ST3R_OK;
 }
@@ -352,7 +353,7 @@ ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const 
     hipStream_t s = (hipStream_t)stream;
     RasterOut ro;
     int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width,
-                             height, nullptr, &ro);
+                             height, nullptr, 0, &ro);
     if (rc) return rc;
     GET(SLOT_LAST, int32_t, (int64_t)C * height * width, last);
     rc = st3r_blend_fwd_impl(ctx, s, C, width, height, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat,

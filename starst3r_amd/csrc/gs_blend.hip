@@ -32,6 +32,7 @@
 // one v_exp_f32.  Forward and backward use the identical expression, hence identical
 // include/skip decisions.
 #include "common.h"
+#include "tile_rect.h"
 
 #define BLK 256
 #define LOG2E 1.4426950408889634f
@@ -92,13 +93,8 @@ __device__ __forceinline__ int stage_record(const float4* __restrict__ splats, i
     sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
     sC[t] = c.x;
     // influence box of {opacity*exp(-sigma) >= 1/255}: |dx| <= sqrt(2 tau cov_xx), tau = ln(255 o)
-    const float o255 = 255.0f * a.z;
-    if (!(o255 > 1.0f)) return 0;
-    const float tau = __logf(o255) * 1.0002f + 1e-4f;
-    const float det = a.w * b.y - b.x * b.x;
-    const float inv = 1.0f / det;
-    const float ex = sqrtf(2.0f * tau * b.y * inv) + 0.02f;
-    const float ey = sqrtf(2.0f * tau * a.w * inv) + 0.02f;
+    float ex, ey;
+    if (!influence_extent(a.z, a.w, b.x, b.y, 0.02f, &ex, &ey)) return 0;
     // pixel centres of quadrant (qx,qy): tx0 + 8qx + [0.5, 7.5]
     const float rx = a.x - ((float)tx0 + 0.5f), ry = a.y - ((float)ty0 + 0.5f);
     const bool x0 = (rx + ex >= 0.0f) && (rx - ex <= 7.0f);
@@ -300,11 +296,6 @@ __device__ __forceinline__ int wave_max_i(int v) {
 #define ACC_STRIDE 9
 #define VT_STRIDE 12  // per-(record, tile) slot: 9 partial gradients (+3 pad) = 3 x 16 B; stamps live in a side array
 
-__device__ __forceinline__ int tile_clampi(float v, int hi) {
-    if (!(v > 0.0f)) return 0;
-    if (v >= (float)hi) return hi;
-    return (int)v;
-}
 
 __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
@@ -316,7 +307,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const float* __restrict__ v_alpha,
                                                    const uint64_t* __restrict__ cmask, int64_t cmask_words,
                                                    const int32_t* __restrict__ tile_nb,
-                                                   const int32_t* __restrict__ cum, int tile_size_unused,
+                                                   const int32_t* __restrict__ cum, int tight,
                                                    float* __restrict__ vtile, int32_t* __restrict__ vstamp,
                                                    int stamp) {
     __shared__ float4 sA[BLK];
@@ -419,12 +410,14 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             if (any) {
                 // slot of this (record, tile) pair in emission order: u = cum_excl[pid] + index of this
                 // tile inside the record's tile rectangle (same float ops as k_isect_emit => same ints)
-                const float4 a = sA[threadIdx.x];
+                const float4 a = splats[my_id * 3 + 0];
                 const float radius = (float)__float_as_int(splats[my_id * 3 + 2].z);
-                const float tile_radius = radius / 16.0f, tile_x = a.x / 16.0f, tile_y = a.y / 16.0f;
-                const int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
-                const int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
-                const int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
+                TileRect tr = ref_tile_rect(a.x, a.y, radius, 16, tile_w, tile_h);
+                if (tight) {
+                    const float4 b1 = splats[my_id * 3 + 1];
+                    tr = tight_tile_rect(tr, a.x, a.y, a.z, a.w, b1.x, b1.y);
+                }
+                const int x0 = tr.x0, y0 = tr.y0, x1 = tr.x1;
                 const int cum_excl = my_id == 0 ? 0 : cum[my_id - 1];
                 const int64_t u = (int64_t)cum_excl + ((g.ty0 >> 4) - y0) * (x1 - x0) + ((g.tx0 >> 4) - x0);
                 float4* dst = reinterpret_cast<float4*>(vtile + u * VT_STRIDE);
@@ -467,7 +460,7 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        const int32_t* cum, int64_t n_pairs, float* v_splats) {
+                        const int32_t* cum, int tight, int64_t n_pairs, float* v_splats) {
     // v_splats == NULL: leave the result in the stamped partial slots (consumed by the fused project backward)
     if (n_isects == 0) {
         ++ctx->bwd_stamp;
@@ -490,7 +483,7 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
     hipLaunchKernelGGL(k_blend_bwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask, words, tile_nb, cum, 16,
+                       offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask, words, tile_nb, cum, tight,
                        vtile, vstamp, stamp);
     LAUNCH_CHECK();
     if (v_splats) {
@@ -511,5 +504,5 @@ ST3R_EXPORT int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width,
     ARG_CHECK(splats && offsets && alpha && last_ids && v_rgb && v_splats && cum_tiles && n_pairs >= 0);
     ARG_CHECK(n_isects >= 0 && n_isects < 2147483647LL && (n_isects == 0 || flatten_ids));
     return st3r_blend_bwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
-                               flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, cum_tiles, n_pairs, v_splats);
+                               flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, cum_tiles, 0, n_pairs, v_splats);
 }

@@ -6,6 +6,7 @@
 //   offsets -- gsplat isect_offset_encode.
 // All integer work: results are bit-exact against oracle/gs_oracle.c.
 #include "common.h"
+#include "tile_rect.h"
 
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 16
@@ -145,12 +146,6 @@ ST3R_EXPORT int st3r_gs_isect_scan(st3r_ctx* ctx, void* stream, int64_t n_pairs,
     return st3r_isect_scan_impl(ctx, (hipStream_t)stream, n_pairs, tiles_per_gauss, cum_tiles, n_isects_host);
 }
 
-__device__ __forceinline__ int tile_clampi(float v, int hi) {
-    if (!(v > 0.0f)) return 0;
-    if (v >= (float)hi) return hi;
-    return (int)v;
-}
-
 __global__ __launch_bounds__(256) void k_isect_emit(int N, int64_t n_pairs, const float4* __restrict__ splats,
                                                     const int32_t* __restrict__ cum, int tile_size, int tile_w,
                                                     int tile_h, int tile_n_bits, int64_t* __restrict__ isect_ids,
@@ -163,12 +158,8 @@ __global__ __launch_bounds__(256) void k_isect_emit(int N, int64_t n_pairs, cons
     const float4 r0 = splats[pid * 3 + 0];
     const float4 r2 = splats[pid * 3 + 2];
     const float radius = (float)__float_as_int(r2.z);
-    const float tile_radius = radius / (float)tile_size;
-    const float tile_x = r0.x / (float)tile_size, tile_y = r0.y / (float)tile_size;
-    const int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
-    const int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
-    const int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
-    const int y1 = tile_clampi(ceilf(tile_y + tile_radius), tile_h);
+    const TileRect tr = ref_tile_rect(r0.x, r0.y, radius, tile_size, tile_w, tile_h);
+    const int x0 = tr.x0, y0 = tr.y0, x1 = tr.x1, y1 = tr.y1;
     const int64_t cid = pid / N;
     const int64_t cid_enc = cid << (32 + tile_n_bits);
     const int64_t depth_enc = (int64_t)(uint32_t)__float_as_int(r2.y);
@@ -259,7 +250,7 @@ __global__ __launch_bounds__(256) void k_isect_emit_sorted(int N, int64_t n_pair
                                                            const float4* __restrict__ splats,
                                                            const int32_t* __restrict__ perm,
                                                            const int32_t* __restrict__ cum_sorted, int tile_size,
-                                                           int tile_w, int tile_h,
+                                                           int tile_w, int tile_h, int tight,
                                                            uint32_t* __restrict__ tile_keys,
                                                            int32_t* __restrict__ vals) {
     const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,12 +262,12 @@ __global__ __launch_bounds__(256) void k_isect_emit_sorted(int N, int64_t n_pair
     const float4 r0 = splats[pid * 3 + 0];
     const float4 r2 = splats[pid * 3 + 2];
     const float radius = (float)__float_as_int(r2.z);
-    const float tile_radius = radius / (float)tile_size;
-    const float tile_x = r0.x / (float)tile_size, tile_y = r0.y / (float)tile_size;
-    const int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
-    const int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
-    const int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
-    const int y1 = tile_clampi(ceilf(tile_y + tile_radius), tile_h);
+    TileRect tr = ref_tile_rect(r0.x, r0.y, radius, tile_size, tile_w, tile_h);
+    if (tight) {
+        const float4 r1 = splats[pid * 3 + 1];
+        tr = tight_tile_rect(tr, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
+    }
+    const int x0 = tr.x0, y0 = tr.y0, x1 = tr.x1, y1 = tr.y1;
     const uint32_t cam_base = (uint32_t)(pid / N) * (uint32_t)(tile_w * tile_h);
     int cur = start;
     for (int ty = y0; ty < y1; ++ty)
@@ -288,12 +279,12 @@ __global__ __launch_bounds__(256) void k_isect_emit_sorted(int N, int64_t n_pair
 }
 
 int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
-                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h,
+                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h, int tight,
                                 uint32_t* tile_keys, int32_t* vals) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
     hipLaunchKernelGGL(k_isect_emit_sorted, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs,
-                       (const float4*)splats, perm, cum_sorted, tile_size, tile_w, tile_h, tile_keys, vals);
+                       (const float4*)splats, perm, cum_sorted, tile_size, tile_w, tile_h, tight, tile_keys, vals);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

@@ -10,6 +10,7 @@
 // operation below is a single IEEE binary32 op in a fixed order (sums of three products
 // left to right; 1/x and sqrt correctly rounded -- hipcc's default for HIP).
 #include "common.h"
+#include "tile_rect.h"
 
 #define CAM_STRIDE 32
 // per-camera block in LDS: [0..11] view matrix rows 0..2 (R|t), 12 fx, 13 fy, 14 cx, 15 cy,
@@ -17,12 +18,6 @@
 
 __device__ __forceinline__ float dot3f(float a0, float a1, float a2, float b0, float b1, float b2) {
     return (a0 * b0 + a1 * b1) + a2 * b2;
-}
-
-__device__ __forceinline__ int tile_clampi(float v, int hi) {
-    if (!(v > 0.0f)) return 0;
-    if (v >= (float)hi) return hi;
-    return (int)v;
 }
 
 #define SH_C0 0.2820947917738781f
@@ -35,7 +30,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
     const float* __restrict__ campos, int W, int H, int tile_size, int tile_w, int tile_h, float eps2d,
     float near_plane, float far_plane, float radius_clip, float4* __restrict__ splats,
     int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_sums,
-    uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals) {
+    uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals, int tight) {
     extern __shared__ float cam[];
     __shared__ float red[8];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -102,7 +97,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
             atomicAdd(&reg_sums[1], (double)((red[4] + red[5]) + (red[6] + red[7])));
         }
     }
-    int n_vis = 0;
+    int n_vis = 0, n_ref = 0;
     for (int c = 0; active && c < C; ++c) {
         const float* o = cam + c * CAM_STRIDE;
         const float R00 = o[0], R01 = o[1], R02 = o[2], t0 = o[3];
@@ -177,13 +172,10 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
                 col[ch] = r < 0.0f ? 0.0f : r;
             }
             // tile rectangle (isect_tiles pass 1)
-            float tile_radius = radius / (float)tile_size;
-            float tile_x = m2x / (float)tile_size, tile_y = m2y / (float)tile_size;
-            int x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
-            int y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
-            int x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
-            int y1 = tile_clampi(ceilf(tile_y + tile_radius), tile_h);
-            ntiles = (y1 - y0) * (x1 - x0);
+            TileRect tr = ref_tile_rect(m2x, m2y, radius, tile_size, tile_w, tile_h);
+            n_ref += (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
+            if (tight) tr = tight_tile_rect(tr, m2x, m2y, opac, ca, cb, cc);  // fused train path only
+            ntiles = (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
             r0 = make_float4(m2x, m2y, opac, ca);
             r1 = make_float4(cb, cc, col[0], col[1]);
             r2 = make_float4(col[2], z, __int_as_float((int)radius), 0.0f);
@@ -199,9 +191,12 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         }
         n_vis += valid ? 1 : 0;
     }
-    if (reg_sums) {  // number of visible (camera, gaussian) pairs -> reg_sums[2]
-        for (int off = 32; off > 0; off >>= 1) n_vis += __shfl_down(n_vis, off);
-        if ((threadIdx.x & 63) == 0 && n_vis) atomicAdd(&reg_sums[2], (double)n_vis);
+    if (reg_sums) {  // visible (camera, gaussian) pairs -> reg_sums[2]; reference tile intersections -> reg_sums[3]
+        for (int off = 32; off > 0; off >>= 1) { n_vis += __shfl_down(n_vis, off); n_ref += __shfl_down(n_ref, off); }
+        if ((threadIdx.x & 63) == 0 && n_vis) {
+            atomicAdd(&reg_sums[2], (double)n_vis);
+            atomicAdd(&reg_sums[3], (double)n_ref);
+        }
     }
 }
 
@@ -211,14 +206,14 @@ int st3r_project_impl(hipStream_t s, int N, int C, const float* means, const flo
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals) {
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight) {
     if (N == 0) return ST3R_OK;
     int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
     dim3 grid(ceil_div(N, 256)), block(256);
     size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
     hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
                        viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
-                       radius_clip, (float4*)splats, tiles_per_gauss, reg_sums, depth_keys, depth_vals);
+                       radius_clip, (float4*)splats, tiles_per_gauss, reg_sums, depth_keys, depth_vals, tight);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -233,5 +228,5 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
     return st3r_project_impl((hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
                              campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,
-                             tiles_per_gauss, reg_sums, nullptr, nullptr);
+                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0);
 }

@@ -1,0 +1,64 @@
+// Tile rectangles of a projected Gaussian -- shared by the kernels that must agree on them exactly
+// (tile count in k_project_sh_fwd, emission in k_isect_emit*, slot index in k_blend_bwd).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct TileRect { int x0, y0, x1, y1; };  // [x0,x1) x [y0,y1) in tile units
+
+__device__ __forceinline__ int tile_clampi(float v, int hi) {
+    // CUDA's float -> uint32 conversion saturates negatives to 0; then min(max(0, .), hi)
+    if (!(v > 0.0f)) return 0;
+    if (v >= (float)hi) return hi;
+    return (int)v;
+}
+
+// gsplat isect_tiles: tiles overlapped by the square [mean2d - radius, mean2d + radius] (tile size 16)
+__device__ __forceinline__ TileRect ref_tile_rect(float x, float y, float radius, int tile_size, int tile_w,
+                                                  int tile_h) {
+    const float tile_radius = radius / (float)tile_size;
+    const float tile_x = x / (float)tile_size, tile_y = y / (float)tile_size;
+    TileRect r;
+    r.x0 = tile_clampi(floorf(tile_x - tile_radius), tile_w);
+    r.y0 = tile_clampi(floorf(tile_y - tile_radius), tile_h);
+    r.x1 = tile_clampi(ceilf(tile_x + tile_radius), tile_w);
+    r.y1 = tile_clampi(ceilf(tile_y + tile_radius), tile_h);
+    return r;
+}
+
+// Half extents of the axis-aligned box around {p : opacity * exp(-sigma(p)) >= 1/255}, slightly inflated
+// (tau by 2e-4 relative + 1e-4, extents by `slack` pixels) so that every pixel OUTSIDE the box fails the
+// reference's alpha test in float arithmetic too.  Returns false when the Gaussian can never pass the test.
+__device__ __forceinline__ bool influence_extent(float opac, float ca, float cb, float cc, float slack, float* ex,
+                                                 float* ey) {
+#pragma clang fp contract(off)
+    const float o255 = 255.0f * opac;
+    if (!(o255 > 1.0f)) return false;
+    // single hardware instructions (v_log_f32, v_rcp_f32, v_sqrt_f32: ~1 ulp, identical in every kernel that
+    // includes this header); their error is orders of magnitude below the inflation
+    const float tau = __logf(o255) * 1.0002f + 1e-4f;
+    const float det = ca * cc - cb * cb;
+    const float k = 2.0f * tau * __builtin_amdgcn_rcpf(det);
+    *ex = __builtin_amdgcn_sqrtf(k * cc) * 1.0001f + slack;
+    *ey = __builtin_amdgcn_sqrtf(k * ca) * 1.0001f + slack;
+    return true;
+}
+
+// Reference rectangle intersected with the tiles whose pixel centres the influence box can reach (16-pixel
+// tiles: centres 16*t + 0.5 ... 16*t + 15.5).  Used only by the fused train path: the dropped (record, tile)
+// pairs fail the alpha test on all 256 pixels, so images and gradients are unchanged.  The slack (0.05 px) is
+// larger than the one of the per-quadrant test in k_blend_* (0.02 px): a superset of what blending needs.
+__device__ __forceinline__ TileRect tight_tile_rect(TileRect r, float x, float y, float opac, float ca, float cb,
+                                                    float cc) {
+#pragma clang fp contract(off)
+    float ex, ey;
+    if (!influence_extent(opac, ca, cb, cc, 0.05f, &ex, &ey)) { r.x1 = r.x0; r.y1 = r.y0; return r; }
+    const int tx_lo = (int)fmaxf(ceilf((x - ex - 15.5f) * 0.0625f), -1.0f);
+    const int tx_hi = (int)fminf(floorf((x + ex - 0.5f) * 0.0625f), 1.0e6f);
+    const int ty_lo = (int)fmaxf(ceilf((y - ey - 15.5f) * 0.0625f), -1.0f);
+    const int ty_hi = (int)fminf(floorf((y + ey - 0.5f) * 0.0625f), 1.0e6f);
+    r.x0 = max(r.x0, tx_lo); r.x1 = min(r.x1, tx_hi + 1);
+    r.y0 = max(r.y0, ty_lo); r.y1 = min(r.y1, ty_hi + 1);
+    if (r.x1 < r.x0) r.x1 = r.x0;
+    if (r.y1 < r.y0) r.y1 = r.y0;
+    return r;
+}

@@ -196,7 +196,7 @@ def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fa
         ctx.handle, _stream(), N, Cn, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
         _p(params["opacities"]), _p(sh), sh_stride_of(sh), _p(viewmats), _p(Ks), _p(campos), _p(gt), W, H, ssim_fac,
         opac_fac, scale_fac, _p(grads), _p(loss_out), stats))
-    return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]))
+    return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
 
 
 def peek(ctx, which, count, dtype=torch.int32):

@@ -230,6 +230,36 @@ def test_empty_and_culled(ctx):
     assert float(rgb.abs().max()) == 0.0 or meta["isect_ids"].size > 0
 
 
+@pytest.mark.parametrize("name", ["small", "medium"])
+def test_fused_train_gradients_equal_stage_path(ctx, name):
+    """The fused train step culls (record, tile) pairs whose alpha >= 1/255 box misses the tile and sorts in
+    two levels; its gradients must equal the reference-exact stage path's (the dropped pairs fail the alpha
+    test on all 256 pixels).  Also pins the loss against the oracle's composite loss."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make(name)
+    N, Cn = g["means"].shape[0], w2c.shape[0]
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    rgb, alpha, info = ops.rasterization(ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], vm, K, W, H)
+    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
+    sums, v_rgb = ops.loss_l1_ssim(ctx, rgb, gt, 0.8, 0.2)
+    v_splats = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
+                             info["_last_ids"], v_rgb, None, info["_cum_tiles"], Cn, W, H)
+    ref = ops.project_sh_bwd(ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], vm, K, campos, W, H,
+                             info["_splats"], v_splats, float(Cn), 0.01, 0.01)
+    grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+    st = ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+    torch.cuda.synchronize()
+    assert st["n_isects_ref"] == info["isect_ids"].numel() and st["n_isects"] <= st["n_isects_ref"]
+    scale = float(ref.abs().max())
+    assert float((grads - ref).abs().max()) <= 2e-5 * scale
+    s = sums.cpu().numpy()
+    expect = sum(0.8 * s[c, 0] / (H * W * 3) + 0.2 * (1 - s[c, 1] / ((H - 10) * (W - 10) * 3)) for c in range(Cn))
+    expect += Cn * (0.01 * float(torch.sigmoid(P["opacities"]).mean()) + 0.01 * float(torch.exp(P["scales"]).mean()))
+    assert abs(float(loss[0]) - expect) <= 1e-5 * abs(expect)
+
+
 def test_train_step_end_to_end(ctx):
     """Fused fwd+bwd+Adam: the first-iteration loss equals the oracle's composite loss and the
     loss goes down over 30 iterations (starster/gs.py:143-161 semantics)."""
