@@ -328,7 +328,9 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         bin_final = last_ids[p];
     }
     float T = T_final;
-    float bufr = 0.f, bufg = 0.f, bufb = 0.f;
+    // gsplat keeps buffer[k] = sum of the colours blended behind the current record; only its dot product
+    // with the pixel's v_rgb is ever used, so one scalar replaces the three components
+    float bv = 0.f;
     const bool has_va = v_alpha != nullptr;
     const int64_t mbase = mask_base(g.lb, g.start);
     const uint64_t* wmask = cmask + (int64_t)w * cmask_words + mbase;
@@ -373,20 +375,22 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                 const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
                 T *= ra;
                 const float fac = alpha * T;
-                float v_al = (q.z * T - bufr * ra) * vr + (q.w * T - bufg * ra) * vg + (cb_ * T - bufb * ra) * vb;
+                const float cv = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
+                float v_al = cv * T - bv * ra;
                 if (has_va) v_al += T_final * ra * va;
                 // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
                 const float vis_u = (ov <= 0.999f) ? vis : 0.f;
-                const float v_sigma = -(a.z * vis_u) * v_al;
-                const float hs = 0.5f * v_sigma;
-                // d sigma/d mean = (a dx + b dy, b dx + c dy) with a = -2 qa/log2e, b = -qb/log2e, c = -2 qc/log2e
-                const float wv = v_sigma * (-1.0f / LOG2E);
-                const float g_x = wv * (lx + a.w * dx);
-                const float g_y = wv * (q.x * dx + 2.0f * q.y * dy);
                 const float g_o = vis_u * v_al;
-                const float g_ca = hs * dx * dx, g_cb = v_sigma * dx * dy, g_cc = hs * dy * dy;
+                const float v_sigma = -a.z * g_o;
+                // Per-record constant factors are applied once per (record, tile) at flush time instead of per
+                // pixel: g_ca, g_cc lack their 1/2; g_x, g_y lack -1/log2(e)
+                // (d sigma/d mean = (a dx + b dy, b dx + c dy) with a = -2 qa/log2e, b = -qb/log2e, c = -2 qc/log2e).
+                const float sdx = v_sigma * dx, sdy = v_sigma * dy;
+                const float g_x = 2.0f * a.w * sdx + q.x * sdy;
+                const float g_y = q.x * sdx + 2.0f * q.y * sdy;
+                const float g_ca = sdx * dx, g_cb = sdx * dy, g_cc = sdy * dy;
                 const float g_r = fac * vr, g_g = fac * vg, g_b = fac * vb;
-                bufr += q.z * fac; bufg += q.w * fac; bufb += cb_ * fac;
+                bv += cv * fac;
                 // 9 values x 64 lanes -> halving butterfly
                 float k0, k1, k2;
                 reduce9(g_x, g_y, g_o, g_ca, g_cb, g_cc, g_r, g_g, g_b, k0, k1, k2);
@@ -421,8 +425,8 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                 const int cum_excl = my_id == 0 ? 0 : cum[my_id - 1];
                 const int64_t u = (int64_t)cum_excl + ((g.ty0 >> 4) - y0) * (x1 - x0) + ((g.tx0 >> 4) - x0);
                 float4* dst = reinterpret_cast<float4*>(vtile + u * VT_STRIDE);
-                dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                dst[0] = make_float4(acc[0] * (-1.0f / LOG2E), acc[1] * (-1.0f / LOG2E), acc[2], 0.5f * acc[3]);
+                dst[1] = make_float4(acc[4], 0.5f * acc[5], acc[6], acc[7]);
                 dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
                 vstamp[u] = stamp;
             }
