@@ -217,6 +217,34 @@ int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, con
 int st3r_nn_dot_argmax(st3r_ctx* ctx, void* stream, const float* queries, int n, const float* db, int m, int dim,
                        int32_t* nn_out, float* score_out);
 
+/* ----------------------------------------------------------------------------------
+ * C7 -- refinement hooks of gsplat.MCMCStrategy() with its default hyper-parameters, as the reference
+ * drives them from starster/gs.py:43-45 (construction), :146-147 (pre-backward no-op) and :163-164
+ * (step_post_backward(step, info, lr=1e-3)) when run_3dgs_optim(enable_pruning=True).
+ * All three interpret `opacities` as logits and `scales` as logs (the renderer reads them raw, SURVEY B-1).
+ * Random draws are Philox4x32-10(key = seed, counter = (index, stream, step)): replicas that hold the same
+ * parameters make identical decisions.  Buffers are caller-owned device memory, updated in place.
+ *
+ * st3r_mcmc_relocate: Gaussians with sigmoid(opacity) <= min_opacity take the parameters of alive ones
+ *   drawn with probability ~ sigmoid(opacity); drawn sources get the relocation opacity/scale; the Adam
+ *   moments (block layout [23N], or NULL) of the sources are zeroed.  n_dead_host (or NULL) receives the
+ *   number of relocated Gaussians (forces one stream sync).
+ * st3r_mcmc_add: the arrays have room for N + n_new rows; rows [N, N + n_new) are filled the same way
+ *   (n_new = min(cap_max, int(1.05 N)) - N is the caller's business, as is extending the Adam state by zeros).
+ * st3r_mcmc_noise: means += Sigma(quats, exp(scales)) @ (randn * sigmoid_100(1 - sigmoid(opacity) - 0.995) * scaler)
+ * st3r_ctx_peek(which = 4..7) reads back the integer sampling state of the last relocate/add call:
+ *   4 = uint64 inclusive prefix sums of the 24-bit weights [N], 5 = uint32 dead mask [N],
+ *   6 = int32 sampled source per row [n] followed by int32 destination row [n] (relocate), 7 = uint32 draw counts [N].
+ * ---------------------------------------------------------------------------------- */
+int st3r_mcmc_relocate(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
+                       float* opacities, float* sh0, float* shN, int shN_floats, float* adam_m, float* adam_v,
+                       float min_opacity, uint64_t seed, uint32_t step, int64_t* n_dead_host);
+int st3r_mcmc_add(st3r_ctx* ctx, void* stream, int N, int n_new, float* means, float* quats, float* scales,
+                  float* opacities, float* sh0, float* shN, int shN_floats, float min_opacity, uint64_t seed,
+                  uint32_t step);
+int st3r_mcmc_noise(st3r_ctx* ctx, void* stream, int N, float* means, const float* quats, const float* scales,
+                    const float* opacities, float scaler, uint64_t seed, uint32_t step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libst3r_hip.so")
 _lib = None
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+u32, u64 = C.c_uint32, C.c_uint64
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/st3r.h
 SIGNATURES = {
@@ -42,6 +43,9 @@ SIGNATURES = {
                        vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, f32, i32, f32, i32, f32, vp, vp, vp, vp, vp, vp, i64,
                        vp, vp, vp],
     "st3r_nn_dot_argmax": [vp, vp, vp, i32, vp, i32, i32, vp, vp],
+    "st3r_mcmc_relocate": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, u64, u32, C.POINTER(i64)],
+    "st3r_mcmc_add": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, u64, u32],
+    "st3r_mcmc_noise": [vp, vp, i32, vp, vp, vp, vp, f32, u64, u32],
     "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],
 }
 _RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_stage_name": C.c_char_p, "st3r_ctx_arena_bytes": i64}

@@ -86,8 +86,9 @@ int st3r_arena_get2(st3r_ctx* ctx, int slot, size_t bytes, void** out, int* grow
 // which: 0 = sorted pair ids ("flatten ids", int32 [n_isects]), 1 = tile offsets (int32 [C*tiles]),
 //        2 = splat records (float [C*N*12]), 3 = inclusive tile scan in pair-id order (int32 [C*N])
 ST3R_EXPORT int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t bytes) {
-    ARG_CHECK(ctx && dst && bytes >= 0 && which >= 0 && which <= 3);
-    static const int slots[4] = {SLOT_VALS_B, SLOT_OFFSETS, SLOT_SPLATS, SLOT_CUM};
+    ARG_CHECK(ctx && dst && bytes >= 0 && which >= 0 && which <= 7);
+    static const int slots[8] = {SLOT_VALS_B, SLOT_OFFSETS, SLOT_SPLATS, SLOT_CUM,
+                                 SLOT_MCMC_CUM, SLOT_MCMC_DEAD, SLOT_MCMC_SAMPLED, SLOT_MCMC_COUNT};
     ARG_CHECK((size_t)bytes <= ctx->slot_bytes[slots[which]]);
     HIP_TRY(hipMemcpyAsync(dst, ctx->slot_ptr[slots[which]], (size_t)bytes, hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));

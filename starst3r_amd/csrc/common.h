@@ -59,6 +59,12 @@ enum ArenaSlot {
     SLOT_DVALS_B,
     SLOT_CUM_D,
     SLOT_NN_PART,
+    SLOT_MCMC_CUM,
+    SLOT_MCMC_DEAD,
+    SLOT_MCMC_RANK,
+    SLOT_MCMC_COUNT,
+    SLOT_MCMC_SAMPLED,
+    SLOT_MCMC_BINOMS,
     SLOT_COUNT
 };
 

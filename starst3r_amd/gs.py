@@ -33,7 +33,11 @@ class FusedAdam:
 
     def __init__(self, owner, key):
         self._owner, self.key = owner, key
-        self.param_groups = [dict(params=[owner.scene.gaussians[key]], lr=owner.lr, betas=owner.betas, eps=owner.eps)]
+
+    @property
+    def param_groups(self):  # always the live parameter (growth replaces the tensors)
+        o = self._owner
+        return [dict(params=[o.scene.gaussians[self.key]], lr=o.lr, betas=o.betas, eps=o.eps)]
 
     @property
     def state(self):
@@ -57,6 +61,18 @@ class _OptimState:
         self.scene, self.lr, self.betas, self.eps, self.step, self.N = scene, lr, (0.9, 0.999), 1e-8, 0, N
         self.m = torch.zeros(23 * N, device=dev); self.v = torch.zeros(23 * N, device=dev)
         self.grads = torch.empty(23 * N, device=dev)
+
+    def grow(self, n_total):
+        """Zero-extend the moments to n_total Gaussians (block layout: every block moves)."""
+        N = self.N
+        m = torch.zeros(23 * n_total, device=self.m.device); v = torch.zeros_like(m)
+        off = 0
+        for _, w in ADAM_BLOCKS:
+            m[off * n_total:off * n_total + w * N].copy_(self.m[off * N:(off + w) * N])
+            v[off * n_total:off * n_total + w * N].copy_(self.v[off * N:(off + w) * N])
+            off += w
+        self.m, self.v, self.N = m, v, n_total
+        self.grads = torch.empty(23 * n_total, device=m.device)
 
     def block_slice(self, key):
         off = 0
@@ -87,9 +103,16 @@ class SSIM:
 
 
 class MCMCStrategy:
-    """Place holder for gsplat.MCMCStrategy() (gs.py:43-45) with its default hyper-parameters.  Position
-    noise is applied as in the reference; relocation / growth (fires only for step > 500 inside one call,
-    SURVEY App. B-6) is the next hot-path row (SURVEY 8(f) #1) and raises until it lands."""
+    """Stands where the reference constructs gsplat.MCMCStrategy() (gs.py:43-45) with its default
+    hyper-parameters; the three refinement operations run in libst3r_hip.so (csrc/mcmc.hip):
+
+      step_post_backward(step, lr): inside the refine window (500 < step < 25000, every 100 steps) dead
+      Gaussians are relocated onto alive ones and the set grows by 5 % up to cap_max; position noise is
+      injected on every call.  Opacities/scales are read as logits/logs here while the renderer uses the
+      same tensors raw -- the reference's behaviour.
+
+    Random draws come from a counter-based generator keyed by state["seed"] and a call counter, not from
+    torch's global generator: view-sharded replicas take identical decisions with no communication."""
     cap_max = 1_000_000; noise_lr = 5e5; refine_start_iter = 500; refine_stop_iter = 25_000
     refine_every = 100; min_opacity = 0.005
 
@@ -97,27 +120,36 @@ class MCMCStrategy:
         for k in ("means", "scales", "quats", "opacities"):
             assert k in params and k in optimizers, f"{k} is required"
 
-    def initialize_state(self):
-        return {"binoms": None}
+    def initialize_state(self, seed=0):
+        return {"binoms": None, "seed": int(seed), "calls": 0, "n_relocated": 0, "n_added": 0}
 
     def step_pre_backward(self, params, optimizers, state, step, info):
         return None
 
     def step_post_backward(self, params, optimizers, state, step, info, lr):
-        if self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0:
-            raise NotImplementedError("MCMC relocation/growth is not implemented yet (SURVEY.md 8(f) row 1)")
-        with torch.no_grad():  # inject_noise_to_position (gsplat) -- O(N) element-wise, not on the hot path
-            op = torch.sigmoid(params["opacities"])
-            gate = 1.0 / (1.0 + torch.exp(-100.0 * ((1.0 - op) - 0.995)))
-            q = torch.nn.functional.normalize(params["quats"], dim=-1)
-            w, x, y, z = q.unbind(-1)
-            R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
-                             2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
-                             2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
-            M = R * torch.exp(params["scales"])[:, None, :]
-            cov = M @ M.transpose(1, 2)
-            noise = torch.randn_like(params["means"]) * gate[:, None] * (lr * self.noise_lr)
-            params["means"].add_((cov @ noise[..., None]).squeeze(-1))
+        owner = optimizers["means"]._owner
+        ctx = ops.get_context(params["means"].device)
+        seed, call = state.get("seed", 0), state.get("calls", 0)
+        state["calls"] = call + 1
+        with torch.no_grad():
+            if self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0:
+                P = {k: params[k].data for k in GAUSSIAN_KEYS}
+                state["n_relocated"] = ops.mcmc_relocate(ctx, P, owner.m, owner.v, self.min_opacity, seed, call)
+                N = P["means"].shape[0]
+                n_new = max(0, min(self.cap_max, int(1.05 * N)) - N)
+                if n_new > 0:
+                    grown = {}
+                    for k in GAUSSIAN_KEYS:
+                        t = torch.empty((N + n_new,) + tuple(P[k].shape[1:]), dtype=P[k].dtype, device=P[k].device)
+                        t[:N].copy_(P[k])
+                        grown[k] = t
+                    ops.mcmc_add(ctx, grown, N, n_new, self.min_opacity, seed, call)
+                    for k in GAUSSIAN_KEYS:  # new leaf tensors, as gsplat re-creates the nn.Parameters
+                        params[k] = torch.nn.Parameter(grown[k], requires_grad=True)
+                    owner.grow(N + n_new)
+                state["n_added"] = n_new
+            P = {k: params[k].data for k in ("means", "quats", "scales", "opacities")}
+            ops.mcmc_noise(ctx, P, lr * self.noise_lr, seed, call)
 
 
 def init_3dgs(scene, init_scale=3e-3, lr=1e-3):
@@ -232,7 +264,6 @@ def run_3dgs_optim(
     campos = ops.camera_positions(w2c)
     gt = _gt_on_device(scene, views)
     losses = torch.zeros(max(iters, 1), device=scene.device)
-    P = {k: g[k].data for k in ("means", "quats", "scales", "opacities", "shN")}
     it_range = range(iters)
     if verbose:
         from tqdm import trange
@@ -240,6 +271,7 @@ def run_3dgs_optim(
     for step in it_range:
         if enable_pruning:
             scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
+        P = {k: g[k].data for k in ("means", "quats", "scales", "opacities", "shN")}  # growth replaces the tensors
         ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
                           loss_scale_fac, st.grads, losses[step:step + 1])
         _dist.all_reduce_sum(st.grads)

@@ -199,6 +199,35 @@ def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fa
     return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
 
 
+def mcmc_relocate(ctx, params, m, v, min_opacity, seed, step, want_count=True):
+    """In place on params (means, quats, scales, opacities, sh0 or None, shN) and on the fused Adam moments
+    m, v ([23N] blocks, or None).  Returns the number of relocated Gaussians (None if not wanted: no sync)."""
+    N = params["means"].shape[0]
+    sh = params["shN"]; sh0 = params.get("sh0")
+    n_dead = C.c_int64(0)
+    _lib.check(_lib.lib().st3r_mcmc_relocate(
+        ctx.handle, _stream(), N, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
+        _p(params["opacities"]), None if sh0 is None else _p(sh0), _p(sh), sh_stride_of(sh),
+        None if m is None else _p(m), None if v is None else _p(v), min_opacity, seed, step,
+        C.byref(n_dead) if want_count else None))
+    return int(n_dead.value) if want_count else None
+
+
+def mcmc_add(ctx, params, N, n_new, min_opacity, seed, step):
+    """params hold N + n_new rows; rows [N, N + n_new) are filled in place."""
+    sh = params["shN"]; sh0 = params.get("sh0")
+    assert params["means"].shape[0] >= N + n_new
+    _lib.check(_lib.lib().st3r_mcmc_add(
+        ctx.handle, _stream(), N, n_new, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
+        _p(params["opacities"]), None if sh0 is None else _p(sh0), _p(sh), sh_stride_of(sh), min_opacity, seed, step))
+
+
+def mcmc_noise(ctx, params, scaler, seed, step):
+    N = params["means"].shape[0]
+    _lib.check(_lib.lib().st3r_mcmc_noise(ctx.handle, _stream(), N, _p(params["means"]), _p(params["quats"]),
+                                          _p(params["scales"]), _p(params["opacities"]), scaler, seed, step))
+
+
 def peek(ctx, which, count, dtype=torch.int32):
     """Copy `count` elements of a ctx scratch buffer (see st3r_ctx_peek) into a new tensor (tests only)."""
     out = torch.empty((count,), dtype=dtype, device=ctx.device)
