@@ -212,10 +212,23 @@ int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, con
  *     nn_out[q] = argmax_j  queries[q] . db[j]     (smallest j on ties), score_out[q] = that maximum
  * queries [n,dim], db [m,dim] row major float32 (dim must be 24, Mast3r's descriptor size),
  * nn_out int32 [n], score_out float [n] or NULL.  fp32 MFMA block-matmul with fused arg-max.
- * The reciprocal iteration around it lives in starst3r_amd/matching.py.
+ * st3r_recip_nn below runs the reciprocal iteration around it on the device.
  * ---------------------------------------------------------------------------------- */
 int st3r_nn_dot_argmax(st3r_ctx* ctx, void* stream, const float* queries, int n, const float* db, int m, int dim,
                        int32_t* nn_out, float* score_out);
+
+/* The whole reciprocal iteration of fast_reciprocal_NNs(A, B, subsample_or_initxy1=subsample, dist='dot')
+ * (starster/reconstruct.py:97 passes subsample=8) resident on the device, no host synchronisation:
+ *   seeds = flat indices x + W1*y on the grid np.mgrid[S//2:H1:S, S//2:W1:S]   (n = st3r_recip_nn_seed_count)
+ *   repeat max_iter (10) times, only for seeds that have not converged:
+ *       idx2 = argmax_B(A[idx1] . B^T); converged if idx2 did not change
+ *       idx1 = argmax_A(B[idx2] . A^T); converged if idx1 did not change
+ * descA [H1*W1, dim], descB [H2*W2, dim] float32, dim = 24.  Outputs int32 [n]: idx1_out, idx2_out, and
+ * notyet_out (0 = converged: a reciprocal match; the caller keeps those, then de-duplicates and sorts --
+ * merge_corres -- which stays host-side bookkeeping). */
+int st3r_recip_nn_seed_count(int H1, int W1, int subsample);
+int st3r_recip_nn(st3r_ctx* ctx, void* stream, const float* descA, int H1, int W1, const float* descB, int H2, int W2,
+                  int dim, int subsample, int max_iter, int32_t* idx1_out, int32_t* idx2_out, int32_t* notyet_out);
 
 /* ----------------------------------------------------------------------------------
  * C7 -- refinement hooks of gsplat.MCMCStrategy() with its default hyper-parameters, as the reference
@@ -244,6 +257,33 @@ int st3r_mcmc_add(st3r_ctx* ctx, void* stream, int N, int n_new, float* means, f
                   uint32_t step);
 int st3r_mcmc_noise(st3r_ctx* ctx, void* stream, int N, float* means, const float* quats, const float* scales,
                     const float* opacities, float scaler, uint64_t seed, uint32_t step);
+
+/* ----------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, views sharded, Gaussians and Adam state replicated; the one
+ * exchange step is a sum all-reduce of the [23N] gradient buffer per iteration over RCCL.  The reference is
+ * single-process (starster/gs.py:143-164); sharding is valid because its loss is a sum over views
+ * (gs.py:149-152).  RCCL is bound at run time (dlopen); without it only these entry points fail.
+ *
+ *   st3r_comm_unique_id  rank 0 creates the 128-byte id, the host distributes it by its own means
+ *   st3r_comm_init       every rank joins (collective; the ctx then owns the communicator)
+ *   st3r_comm_attach     alternatively adopt a caller-owned ncclComm_t (never destroyed by the library)
+ *   st3r_grad_allreduce  in place, asynchronous on `stream`; a no-op for a single replica
+ *   st3r_gs_train_step   st3r_gs_train_fwd_bwd -> st3r_grad_allreduce -> st3r_adam_step in one call:
+ *                        one iteration of starster/gs.py:143-164 for this rank's views.  loss_out holds
+ *                        this rank's part of the loss (sum over ranks = the reference's loss).
+ * ---------------------------------------------------------------------------------- */
+#define ST3R_COMM_ID_BYTES 128
+int st3r_comm_unique_id(char* id_out);
+int st3r_comm_init(st3r_ctx* ctx, int world_size, int rank, const char* id);
+int st3r_comm_attach(st3r_ctx* ctx, void* rccl_comm, int world_size, int rank);
+int st3r_comm_destroy(st3r_ctx* ctx);
+int st3r_comm_world(st3r_ctx* ctx, int* world_size, int* rank);
+int st3r_grad_allreduce(st3r_ctx* ctx, void* stream, float* grads, int64_t count);
+int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, float* means, float* quats, float* scales,
+                       float* opacities, float* sh, int sh_stride, const float* viewmats, const float* Ks,
+                       const float* campos, const float* gt_images, int width, int height, float ssim_fac,
+                       float opac_fac, float scale_fac, float* grads, float* m, float* v, double lr, double beta1,
+                       double beta2, double eps, int step, float* loss_out, int64_t* stats_host);
 
 #ifdef __cplusplus
 }

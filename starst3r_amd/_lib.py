@@ -46,6 +46,16 @@ SIGNATURES = {
     "st3r_mcmc_relocate": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, u64, u32, C.POINTER(i64)],
     "st3r_mcmc_add": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, u64, u32],
     "st3r_mcmc_noise": [vp, vp, i32, vp, vp, vp, vp, f32, u64, u32],
+    "st3r_comm_unique_id": [C.c_char_p],
+    "st3r_comm_init": [vp, i32, i32, C.c_char_p],
+    "st3r_comm_attach": [vp, vp, i32, i32],
+    "st3r_comm_destroy": [vp],
+    "st3r_comm_world": [vp, C.POINTER(i32), C.POINTER(i32)],
+    "st3r_grad_allreduce": [vp, vp, vp, i64],
+    "st3r_gs_train_step": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp,
+                           vp, f64, f64, f64, f64, i32, vp, C.POINTER(i64)],
+    "st3r_recip_nn_seed_count": [i32, i32, i32],
+    "st3r_recip_nn": [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],
 }
 _RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_stage_name": C.c_char_p, "st3r_ctx_arena_bytes": i64}

@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
         res = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
     objs = [o for o, _ in res]
     if force or any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

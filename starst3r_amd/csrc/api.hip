@@ -35,6 +35,7 @@ ST3R_EXPORT int st3r_ctx_create(int device, st3r_ctx** out) {
 ST3R_EXPORT int st3r_ctx_destroy(st3r_ctx* ctx) {
     if (!ctx) return ST3R_OK;
     (void)hipSetDevice(ctx->device);
+    (void)st3r_comm_destroy(ctx);
     for (int i = 0; i < SLOT_COUNT; ++i)
         if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -92,6 +92,8 @@ struct st3r_ctx {
     int64_t* pinned;  // small pinned host buffer for read-backs
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
+    void* comm;     // ncclComm_t of the view-sharded job (NULL: single replica)
+    int comm_owned, comm_rank, comm_size;
     int prof_enabled;
     hipEvent_t prof_ev[PROF_RING][STG_COUNT][2];
     unsigned char prof_used[PROF_RING][STG_COUNT];

@@ -24,14 +24,18 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Query i reads row qsel[act[i]] of Q when the indirections are given (device-resident reciprocal loop: `act`
+// lists the seeds that have not converged, `n_dev` holds how many there are), row i otherwise.
 __global__ __launch_bounds__(256) void k_nn_argmax(const float* __restrict__ Q, int n, const float* __restrict__ DB,
                                                    int m, int S, int tiles_per_seg, float* __restrict__ part_val,
-                                                   int32_t* __restrict__ part_idx) {
+                                                   int32_t* __restrict__ part_idx, const int32_t* __restrict__ qsel,
+                                                   const int32_t* __restrict__ act, const int32_t* __restrict__ n_dev) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int groups = (n + 63) >> 6;
     if (wid >= groups * S) return;
     const int group = wid / S, seg = wid - group * S;
+    if (n_dev) { n = *n_dev; if (group * 64 >= n) return; }
     const int j = lane & 31, h = lane >> 5;
     // query fragments: column j of tile t, components 12h .. 12h+11
     float q[2][NN_HALF];
@@ -39,7 +43,9 @@ __global__ __launch_bounds__(256) void k_nn_argmax(const float* __restrict__ Q, 
     for (int t = 0; t < 2; ++t) {
         const int qi = group * 64 + t * 32 + j;
         if (qi < n) {
-            const float4* src = reinterpret_cast<const float4*>(Q + (int64_t)qi * NN_D + NN_HALF * h);
+            const int slot = act ? act[qi] : qi;
+            const int64_t qrow = qsel ? qsel[slot] : slot;
+            const float4* src = reinterpret_cast<const float4*>(Q + qrow * NN_D + NN_HALF * h);
             const float4 a = src[0], b = src[1], c = src[2];
             q[t][0] = a.x; q[t][1] = a.y; q[t][2] = a.z; q[t][3] = a.w; q[t][4] = b.x; q[t][5] = b.y;
             q[t][6] = b.z; q[t][7] = b.w; q[t][8] = c.x; q[t][9] = c.y; q[t][10] = c.z; q[t][11] = c.w;
@@ -93,19 +99,37 @@ __global__ __launch_bounds__(256) void k_nn_argmax(const float* __restrict__ Q, 
     }
 }
 
+// winner over the S segment partials of one query, one wave per query (S can be ~1000 when few queries are
+// active: a serial scan per thread would dominate the call)
+__device__ __forceinline__ void wave_best(const float* __restrict__ pv, const int32_t* __restrict__ pi, int S,
+                                          float* bv_out, int* bi_out) {
+    const int lane = threadIdx.x & 63;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int s = lane; s < S; s += 64) {
+        const float v = pv[s];
+        const int i = pi[s];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    *bv_out = bv; *bi_out = bi;
+}
+
 __global__ __launch_bounds__(256) void k_nn_reduce(int n, int S, const float* __restrict__ part_val,
                                                    const int32_t* __restrict__ part_idx, int32_t* __restrict__ nn,
                                                    float* __restrict__ score) {
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= n) return;
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int s = 0; s < S; ++s) {
-        const float v = part_val[(int64_t)qi * S + s];
-        const int i = part_idx[(int64_t)qi * S + s];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    float bv; int bi;
+    wave_best(part_val + (int64_t)qi * S, part_idx + (int64_t)qi * S, S, &bv, &bi);
+    if ((threadIdx.x & 63) == 0) {
+        nn[qi] = bi;
+        if (score) score[qi] = bv;
     }
-    nn[qi] = bi;
-    if (score) score[qi] = bv;
 }
 
 ST3R_EXPORT int st3r_nn_dot_argmax(st3r_ctx* ctx, void* stream, const float* queries, int n, const float* db,
@@ -128,8 +152,119 @@ ST3R_EXPORT int st3r_nn_dot_argmax(st3r_ctx* ctx, void* stream, const float* que
     int32_t* part_idx = (int32_t*)(part_val + (size_t)n * S);
     const int waves = groups * S;
     hipLaunchKernelGGL(k_nn_argmax, dim3((waves + 3) / 4), dim3(256), 0, s, queries, n, db, m, S, tiles_per_seg,
-                       part_val, part_idx);
-    hipLaunchKernelGGL(k_nn_reduce, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, S, part_val, part_idx, nn_out, score_out);
+                       part_val, part_idx, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(k_nn_reduce, dim3(ceil_div(n, 4)), dim3(256), 0, s, n, S, part_val, part_idx, nn_out, score_out);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+// ---- device-resident reciprocal loop (Mast3r fast_reciprocal_NNs) ----
+
+// seeds on the grid S/2, S/2+S, ... in x and y (np.mgrid[S//2:H:S, S//2:W:S], flat index x + W*y, ascending)
+__global__ void k_nn_seeds(int nx, int ny, int S, int W, int32_t* __restrict__ xy1, int32_t* __restrict__ xy2,
+                           int32_t* __restrict__ notyet) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx * ny) return;
+    const int y = S / 2 + (i / nx) * S, x = S / 2 + (i % nx) * S;
+    xy1[i] = x + W * y; xy2[i] = -1; notyet[i] = 1;
+}
+
+// act[] = indices with notyet != 0, in ascending order; one block, chunked LDS scan
+__global__ __launch_bounds__(1024) void k_nn_compact(int n, const int32_t* __restrict__ notyet,
+                                                     int32_t* __restrict__ act, int32_t* __restrict__ n_act) {
+    __shared__ int sWave[16];
+    __shared__ int sBase;
+    if (threadIdx.x == 0) sBase = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        const bool on = i < n && notyet[i] != 0;
+        const uint64_t ball = __ballot(on);
+        const int before = __popcll(ball & ((1ull << lane) - 1ull));
+        if (lane == 0) sWave[w] = __popcll(ball);
+        __syncthreads();
+        int off = sBase;
+        for (int k = 0; k < w; ++k) off += sWave[k];
+        if (on) act[off + before] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += sWave[k]; sBase += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_act = sBase;
+}
+
+// winner over the segments of active query i -> dst[act[i]]; a seed whose neighbour did not change has converged
+__global__ __launch_bounds__(256) void k_nn_reduce_update(const int32_t* __restrict__ n_act, int S,
+                                                          const float* __restrict__ part_val,
+                                                          const int32_t* __restrict__ part_idx,
+                                                          const int32_t* __restrict__ act, int32_t* __restrict__ dst,
+                                                          int32_t* __restrict__ notyet) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= *n_act) return;
+    float bv; int bi;
+    wave_best(part_val + (int64_t)i * S, part_idx + (int64_t)i * S, S, &bv, &bi);
+    if ((threadIdx.x & 63) == 0) {
+        const int slot = act[i];
+        if (dst[slot] == bi) notyet[slot] = 0;  // notyet &= (old != new)
+        dst[slot] = bi;
+    }
+}
+
+ST3R_EXPORT int st3r_recip_nn_seed_count(int H1, int W1, int subsample) {
+    if (H1 <= 0 || W1 <= 0 || subsample <= 0) return 0;
+    const int S = subsample;
+    const int ny = (H1 - S / 2 + S - 1) / S, nx = (W1 - S / 2 + S - 1) / S;
+    return (ny > 0 && nx > 0) ? nx * ny : 0;
+}
+
+ST3R_EXPORT int st3r_recip_nn(st3r_ctx* ctx, void* stream, const float* descA, int H1, int W1, const float* descB,
+                              int H2, int W2, int dim, int subsample, int max_iter, int32_t* idx1_out,
+                              int32_t* idx2_out, int32_t* notyet_out) {
+    ARG_CHECK(ctx && descA && descB && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && dim == NN_D && subsample > 0);
+    ARG_CHECK(max_iter > 0 && idx1_out && idx2_out && notyet_out);
+    const int S0 = subsample;
+    const int ny = (H1 - S0 / 2 + S0 - 1) / S0, nx = (W1 - S0 / 2 + S0 - 1) / S0;
+    const int n = nx * ny;
+    if (n <= 0) return ST3R_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int mA = H1 * W1, mB = H2 * W2;
+    const int groups = (n + 63) / 64;
+    auto plan = [&](int m, int* S, int* tps) {
+        const int tiles = (m + 31) / 32;
+        int Sx = 4096 / groups;
+        if (Sx < 1) Sx = 1;
+        if (Sx > (tiles + 3) / 4) Sx = (tiles + 3) / 4;
+        if (Sx < 1) Sx = 1;
+        *tps = (tiles + Sx - 1) / Sx;
+        *S = (tiles + *tps - 1) / *tps;
+    };
+    int SA, tpsA, SB, tpsB;
+    plan(mA, &SA, &tpsA); plan(mB, &SB, &tpsB);
+    const int Smax = SA > SB ? SA : SB;
+    void* p;
+    int rc = st3r_arena_get(ctx, SLOT_NN_PART, (sizeof(float) + sizeof(int32_t)) * (size_t)n * Smax +
+                                                   sizeof(int32_t) * ((size_t)n + 4), &p);
+    if (rc) return rc;
+    float* part_val = (float*)p;
+    int32_t* part_idx = (int32_t*)(part_val + (size_t)n * Smax);
+    int32_t* act = part_idx + (size_t)n * Smax;
+    int32_t* n_act = act + n;
+    hipLaunchKernelGGL(k_nn_seeds, dim3(ceil_div(n, 256)), dim3(256), 0, s, nx, ny, S0, W1, idx1_out, idx2_out, notyet_out);
+    for (int it = 0; it < max_iter; ++it) {
+        // xy2 = NN_B(A[xy1]) for the seeds still moving
+        hipLaunchKernelGGL(k_nn_compact, dim3(1), dim3(1024), 0, s, n, notyet_out, act, n_act);
+        hipLaunchKernelGGL(k_nn_argmax, dim3((groups * SB + 3) / 4), dim3(256), 0, s, descA, n, descB, mB, SB, tpsB,
+                           part_val, part_idx, (const int32_t*)idx1_out, (const int32_t*)act, (const int32_t*)n_act);
+        hipLaunchKernelGGL(k_nn_reduce_update, dim3(ceil_div(n, 4)), dim3(256), 0, s, n_act, SB, part_val, part_idx, act,
+                           idx2_out, notyet_out);
+        // xy1 = NN_A(B[xy2])
+        hipLaunchKernelGGL(k_nn_compact, dim3(1), dim3(1024), 0, s, n, notyet_out, act, n_act);
+        hipLaunchKernelGGL(k_nn_argmax, dim3((groups * SA + 3) / 4), dim3(256), 0, s, descB, n, descA, mA, SA, tpsA,
+                           part_val, part_idx, (const int32_t*)idx2_out, (const int32_t*)act, (const int32_t*)n_act);
+        hipLaunchKernelGGL(k_nn_reduce_update, dim3(ceil_div(n, 4)), dim3(256), 0, s, n_act, SA, part_val, part_idx, act,
+                           idx1_out, notyet_out);
+    }
     LAUNCH_CHECK();
     return ST3R_OK;
 }

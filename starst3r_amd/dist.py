@@ -40,3 +40,30 @@ def sharded_step(local_views_fn, grads, loss):
     all_reduce_sum(grads)
     all_reduce_sum(loss)
     return grads, loss
+
+
+def attach_native_comm(ctx):
+    """Create the library's own RCCL communicator for `ctx` (st3r_comm_init) so that the whole iteration --
+    render, loss, backward, gradient all-reduce, Adam -- is one C call (st3r_gs_train_step) with no Python
+    between the kernels and the collective.  torch.distributed only ships the 128-byte id from rank 0.
+    Collective: every rank must call it.  Returns (rank, world)."""
+    import ctypes as C
+    import torch.distributed as dist
+    from . import _lib
+    rank, world = rank_world()
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(_lib.lib().st3r_comm_unique_id(buf))
+    if world > 1:
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0)
+        buf = C.create_string_buffer(box[0], 128)
+    _lib.check(_lib.lib().st3r_comm_init(ctx.handle, world, rank, buf))
+    ctx.native_comm = True
+    return rank, world
+
+
+def detach_native_comm(ctx):
+    from . import _lib
+    _lib.check(_lib.lib().st3r_comm_destroy(ctx.handle))
+    ctx.native_comm = False

@@ -264,6 +264,7 @@ def run_3dgs_optim(
     campos = ops.camera_positions(w2c)
     gt = _gt_on_device(scene, views)
     losses = torch.zeros(max(iters, 1), device=scene.device)
+    fused = world == 1 or getattr(ctx, "native_comm", False)
     it_range = range(iters)
     if verbose:
         from tqdm import trange
@@ -272,11 +273,16 @@ def run_3dgs_optim(
         if enable_pruning:
             scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
         P = {k: g[k].data for k in ("means", "quats", "scales", "opacities", "shN")}  # growth replaces the tensors
-        ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
-                          loss_scale_fac, st.grads, losses[step:step + 1])
-        _dist.all_reduce_sum(st.grads)
         st.step += 1
-        ops.adam_step(ctx, P, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step)
+        if fused:   # the whole iteration is one C call (gradient all-reduce inside, over the ctx's communicator)
+            ops.train_step(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
+                           loss_scale_fac, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step,
+                           losses[step:step + 1])
+        else:       # gradient all-reduce through the host framework's process group (torch.distributed -> RCCL)
+            ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
+                              loss_scale_fac, st.grads, losses[step:step + 1])
+            _dist.all_reduce_sum(st.grads)
+            ops.adam_step(ctx, P, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step)
         if enable_pruning:
             scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
     _dist.all_reduce_sum(losses)

@@ -4,7 +4,7 @@ Mirrors Mast3r's `fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy
 block_size=2**13)` as the reference reaches it (starster/reconstruct.py:97 -> forward_mast3r ->
 extract_correspondences): same seeds, same iteration, same convergence rule, same
 unique/sort of the result.  The nearest-neighbour queries run on the MFMA kernel (st3r_nn_dot_argmax);
-the bookkeeping around it (a few thousand int32 per iteration) is torch on the device.
+the iteration around them is device resident too (st3r_recip_nn); only the final unique/sort is torch.
 """
 import ctypes as C
 
@@ -49,22 +49,11 @@ def fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy=True, device=
     A = pts1.reshape(-1, D1).to(dev, torch.float32).contiguous()
     B = pts2.reshape(-1, D2).to(dev, torch.float32).contiguous()
     S = int(subsample_or_initxy1)
-    y1, x1 = np.mgrid[S // 2:H1:S, S // 2:W1:S].reshape(2, -1)
-    xy1 = torch.as_tensor(np.int32(np.unique(x1 + W1 * y1)), device=dev)
-    xy2 = torch.full_like(xy1, -1)
-    old_xy1 = xy1.clone(); old_xy2 = xy2.clone()
-    notyet = torch.ones_like(xy1, dtype=torch.bool)
-    niter = 0
-    while bool(notyet.any()):
-        act = torch.nonzero(notyet).reshape(-1)
-        xy2[act] = nn_dot_argmax(ctx, A[xy1[act].long()], B)
-        notyet &= (old_xy2 != xy2)      # remove points that have converged
-        act = torch.nonzero(notyet).reshape(-1)
-        xy1[act] = nn_dot_argmax(ctx, B[xy2[act].long()], A)
-        notyet &= (old_xy1 != xy1)
-        niter += 1
-        if niter >= max_iter:
-            break
-        old_xy2.copy_(xy2); old_xy1.copy_(xy1)
-    converged = ~notyet
+    lib = _lib.lib()
+    n = lib.st3r_recip_nn_seed_count(H1, W1, S)
+    xy1 = torch.empty((n,), dtype=torch.int32, device=dev); xy2 = torch.empty_like(xy1); notyet = torch.empty_like(xy1)
+    if n:  # the whole reciprocal iteration runs on the device without a host round trip
+        _lib.check(lib.st3r_recip_nn(ctx.handle, ops._stream(), ops._p(A), H1, W1, ops._p(B), H2, W2, D1, S, max_iter,
+                                     ops._p(xy1, torch.int32), ops._p(xy2, torch.int32), ops._p(notyet, torch.int32)))
+    converged = notyet == 0
     return merge_corres(xy1[converged], xy2[converged], (H1, W1), (H2, W2), ret_xy=ret_xy)

@@ -199,6 +199,20 @@ def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fa
     return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
 
 
+def train_step(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fac, scale_fac, grads, m, v, lr, b1, b2, eps,
+               step, loss_out):
+    """One whole iteration in one C call: fwd/bwd -> gradient all-reduce over the ctx's RCCL communicator (if
+    one is attached, see dist.attach_native_comm) -> Adam.  loss_out gets this rank's part of the loss."""
+    N, Cn = params["means"].shape[0], viewmats.shape[0]
+    sh = params["shN"]
+    stats = (C.c_int64 * 4)()
+    _lib.check(_lib.lib().st3r_gs_train_step(
+        ctx.handle, _stream(), N, Cn, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
+        _p(params["opacities"]), _p(sh), sh_stride_of(sh), _p(viewmats), _p(Ks), _p(campos), _p(gt), W, H, ssim_fac,
+        opac_fac, scale_fac, _p(grads), _p(m), _p(v), lr, b1, b2, eps, step, _p(loss_out), stats))
+    return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
+
+
 def mcmc_relocate(ctx, params, m, v, min_opacity, seed, step, want_count=True):
     """In place on params (means, quats, scales, opacities, sh0 or None, shN) and on the fused Adam moments
     m, v ([23N] blocks, or None).  Returns the number of relocated Gaussians (None if not wanted: no sync)."""

@@ -67,3 +67,31 @@ def test_fast_reciprocal_nns_vs_oracle(ctx, shape, S):
     assert np.all(np.diff(key) > 0)
     xy1, xy2 = matching.fast_reciprocal_NNs(dev(A), dev(B), subsample_or_initxy1=S, ret_xy=True, device="cuda:0")
     assert np.array_equal(xy1.cpu().numpy()[:, 0] + W * xy1.cpu().numpy()[:, 1], i1)
+
+
+@pytest.mark.parametrize("shape,S", [((48, 64), 4), ((96, 128), 8), ((50, 70), 8)])
+def test_device_resident_loop_equals_stepwise_loop(ctx, shape, S):
+    """st3r_recip_nn (no host round trip) == the same iteration driven step by step from the host with
+    st3r_nn_dot_argmax: identical arithmetic, so identical indices and convergence flags."""
+    from starst3r_amd import matching
+    H, W = shape
+    A, B, _, _ = no.synth_descriptors(H, W, planted=0.3, seed=11)
+    Ad = dev(A).reshape(-1, A.shape[-1]).contiguous(); Bd = dev(B).reshape(-1, B.shape[-1]).contiguous()
+    y1, x1 = np.mgrid[S // 2:H:S, S // 2:W:S].reshape(2, -1)
+    xy1 = torch.as_tensor(np.int32(np.unique(x1 + W * y1)), device="cuda:0")
+    xy2 = torch.full_like(xy1, -1); old1 = xy1.clone(); old2 = xy2.clone()
+    notyet = torch.ones_like(xy1, dtype=torch.bool)
+    for it in range(10):
+        if not bool(notyet.any()):
+            break
+        act = torch.nonzero(notyet).reshape(-1)
+        xy2[act] = matching.nn_dot_argmax(ctx, Ad[xy1[act].long()], Bd)
+        notyet &= (old2 != xy2)
+        act = torch.nonzero(notyet).reshape(-1)
+        xy1[act] = matching.nn_dot_argmax(ctx, Bd[xy2[act].long()], Ad)
+        notyet &= (old1 != xy1)
+        old2.copy_(xy2); old1.copy_(xy1)
+    conv = ~notyet
+    e1, e2 = matching.merge_corres(xy1[conv], xy2[conv], ret_xy=False)
+    g1, g2 = matching.fast_reciprocal_NNs(dev(A), dev(B), subsample_or_initxy1=S, ret_xy=False, device="cuda:0")
+    assert g1.numel() > 0 and torch.equal(g1, e1) and torch.equal(g2, e2)
