@@ -165,7 +165,7 @@ int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t
                    int64_t* keys_out, int32_t* vals_out);
 int st3r_isect_offsets_impl(hipStream_t s, int64_t n_isects, const int64_t* ids, int C, int tile_w, int tile_h,
                             int32_t* offsets);
-int st3r_project_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
+int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
@@ -227,7 +227,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_DVALS_B, int32_t, n_pairs, perm);
     GET(SLOT_CUM_D, int32_t, n_pairs, cum_d);
     st3r_prof_begin(ctx, s, STG_PROJECT);
-    int rc = st3r_project_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
+    int rc = st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
                                tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums, dkeys_a, dvals_a, tight);
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;

@@ -65,6 +65,7 @@ enum ArenaSlot {
     SLOT_MCMC_COUNT,
     SLOT_MCMC_SAMPLED,
     SLOT_MCMC_BINOMS,
+    SLOT_REG_PART,
     SLOT_COUNT
 };
 

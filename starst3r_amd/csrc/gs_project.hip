@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
     int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     const float* __restrict__ campos, int W, int H, int tile_size, int tile_w, int tile_h, float eps2d,
     float near_plane, float far_plane, float radius_clip, float4* __restrict__ splats,
-    int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_sums,
+    int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_part,
     uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals, int tight) {
     extern __shared__ float cam[];
     __shared__ float red[8];
@@ -79,12 +79,12 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         cov3 = dot3f(m3, m4, m5, m3, m4, m5);
         cov4 = dot3f(m3, m4, m5, m6, m7, m8);
         cov5 = dot3f(m6, m7, m8, m6, m7, m8);
-        if (reg_sums) {
+        if (reg_part) {
             reg_o = 1.0f / (1.0f + __expf(-opac));
             reg_s = (__expf(s0) + __expf(s1)) + __expf(s2);
         }
     }
-    if (reg_sums) {  // block reduction of the two regulariser sums -> one double atomic each
+    if (reg_part) {  // block reduction of the two regulariser sums
         for (int off = 32; off > 0; off >>= 1) {
             reg_o += __shfl_down(reg_o, off);
             reg_s += __shfl_down(reg_s, off);
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         if ((threadIdx.x & 63) == 0) { red[w] = reg_o; red[4 + w] = reg_s; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&reg_sums[0], (double)((red[0] + red[1]) + (red[2] + red[3])));
-            atomicAdd(&reg_sums[1], (double)((red[4] + red[5]) + (red[6] + red[7])));
+            reg_part[4 * blockIdx.x + 0] = (double)((red[0] + red[1]) + (red[2] + red[3]));
+            reg_part[4 * blockIdx.x + 1] = (double)((red[4] + red[5]) + (red[6] + red[7]));
         }
     }
     int n_vis = 0, n_ref = 0;
@@ -191,18 +191,40 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         }
         n_vis += valid ? 1 : 0;
     }
-    if (reg_sums) {  // visible (camera, gaussian) pairs -> reg_sums[2]; reference tile intersections -> reg_sums[3]
+    if (reg_part) {  // visible (camera, gaussian) pairs and reference tile intersections of this block
         for (int off = 32; off > 0; off >>= 1) { n_vis += __shfl_down(n_vis, off); n_ref += __shfl_down(n_ref, off); }
-        if ((threadIdx.x & 63) == 0 && n_vis) {
-            atomicAdd(&reg_sums[2], (double)n_vis);
-            atomicAdd(&reg_sums[3], (double)n_ref);
+        __shared__ int redi[8];
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { redi[w] = n_vis; redi[4 + w] = n_ref; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            reg_part[4 * blockIdx.x + 2] = (double)((redi[0] + redi[1]) + (redi[2] + redi[3]));
+            reg_part[4 * blockIdx.x + 3] = (double)((redi[4] + redi[5]) + (redi[6] + redi[7]));
         }
     }
 }
 
+// reg_sums[k] += sum over blocks of reg_part[., k], in a fixed order (bit-reproducible; thousands of
+// same-address double atomics from the projection kernel used to cost more than the projection itself)
+__global__ __launch_bounds__(256) void k_reg_reduce(int n_blocks, const double* __restrict__ reg_part,
+                                                    double* __restrict__ reg_sums) {
+    __shared__ double sh[4][256];
+    double acc[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+        for (int k = 0; k < 4; ++k) acc[k] += reg_part[4 * b + k];
+    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off)
+            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) reg_sums[threadIdx.x] += sh[threadIdx.x][0];
+}
+
 // depth_keys/depth_vals (optional, [C*N]): per-pair (camera | depth bits) key and pair id for the
 // two-level sort of the fused path
-int st3r_project_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
+int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
@@ -211,9 +233,17 @@ int st3r_project_impl(hipStream_t s, int N, int C, const float* means, const flo
     int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
     dim3 grid(ceil_div(N, 256)), block(256);
     size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
+    double* reg_part = nullptr;
+    if (reg_sums) {
+        void* p;
+        int rc = st3r_arena_get(ctx, SLOT_REG_PART, sizeof(double) * 4 * (size_t)grid.x, &p);
+        if (rc) return rc;
+        reg_part = (double*)p;
+    }
     hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
                        viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
-                       radius_clip, (float4*)splats, tiles_per_gauss, reg_sums, depth_keys, depth_vals, tight);
+                       radius_clip, (float4*)splats, tiles_per_gauss, reg_part, depth_keys, depth_vals, tight);
+    if (reg_sums) hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(256), 0, s, (int)grid.x, reg_part, reg_sums);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -226,7 +256,7 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
                                    int32_t* tiles_per_gauss, double* reg_sums) {
     ARG_CHECK(ctx && N >= 0 && C > 0 && C <= 1024 && sh_stride >= 12 && width > 0 && height > 0 && tile_size > 0);
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
-    return st3r_project_impl((hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
+    return st3r_project_impl(ctx, (hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
                              campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,
                              tiles_per_gauss, reg_sums, nullptr, nullptr, 0);
 }
