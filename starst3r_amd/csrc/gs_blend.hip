@@ -287,16 +287,38 @@ __device__ __forceinline__ float row_allsum(float v) {
     return v;
 }
 
+// row_allsum of three registers, interleaved so that consecutive DPP reads of one register are three
+// instructions apart (no wait states needed) and the adds stay fused with their DPP operand
+__device__ __forceinline__ void row_allsum3(float& a, float& b, float& c) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        : "+v"(a), "+v"(b), "+v"(c));
+}
+
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
     return v;
 }
 
-#define ACC_STRIDE 9
+#define ACC_STRIDE 12  // 9 partial sums + 3 pad words (rows 1..3 park their unused third register there)
+#define ACC_VALS 9
 #define VT_STRIDE 12  // per-(record, tile) slot: 9 partial gradients (+3 pad) = 3 x 16 B; stamps live in a side array
 
 
+template <bool HAS_VA>  // v_alpha is NULL in the train step (the reference's loss ignores render_alpha, gs.py:126)
 __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
                                                    const int32_t* __restrict__ offsets,
@@ -324,14 +346,13 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     if (g.inside) {
         T_final = 1.0f - out_alpha[p];
         vr = v_rgb[3 * p]; vg = v_rgb[3 * p + 1]; vb = v_rgb[3 * p + 2];
-        if (v_alpha) va = v_alpha[p];
+        if (HAS_VA) va = v_alpha[p];
         bin_final = last_ids[p];
     }
     float T = T_final;
     // gsplat keeps buffer[k] = sum of the colours blended behind the current record; only its dot product
     // with the pixel's v_rgb is ever used, so one scalar replaces the three components
     float bv = 0.f;
-    const bool has_va = v_alpha != nullptr;
     const int64_t mbase = mask_base(g.lb, g.start);
     const uint64_t* wmask = cmask + (int64_t)w * cmask_words + mbase;
     // row (16 lanes) r of the folded registers holds: k0 -> slot {0,2,1,3}[r], k1 -> {4,6,5,7}[r], k2 -> 8 (row 0)
@@ -351,13 +372,13 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
 #pragma unroll
         for (int k = 0; k < ACC_STRIDE; ++k) sAcc[threadIdx.x * ACC_STRIDE + k] = 0.f;
         __syncthreads();
-#pragma unroll 1
+#pragma unroll
         for (int jj = 3; jj >= 0; --jj) {
             uint64_t m = uniform_u64(wmask[bt * 4 + jj]);
             while (m) {
                 const int bit = 63 - __builtin_clzll(m);
                 m &= ~(1ull << bit);
-                const int t = __builtin_amdgcn_readfirstlane(jj * 64 + bit);
+                const int t = jj * 64 + bit;
                 const float4 a = sA[t];
                 const float4 q = sB[t];
                 const float cb_ = sC[t];
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                 const float fac = alpha * T;
                 const float cv = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
                 float v_al = cv * T - bv * ra;
-                if (has_va) v_al += T_final * ra * va;
+                if (HAS_VA) v_al += T_final * ra * va;
                 // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
                 const float vis_u = (ov <= 0.999f) ? vis : 0.f;
                 const float g_o = vis_u * v_al;
@@ -394,14 +415,15 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                 // 9 values x 64 lanes -> halving butterfly
                 float k0, k1, k2;
                 reduce9(g_x, g_y, g_o, g_ca, g_cb, g_cc, g_r, g_g, g_b, k0, k1, k2);
-                k0 = row_allsum(k0); k1 = row_allsum(k1); k2 = row_allsum(k2);
+                row_allsum3(k0, k1, k2);
                 if (row_leader) {
-                    // slot2 is written lane-dependent on purpose (a uniform address makes hipcc wrap the
-                    // single-lane atomic in its wave-reduction loop)
+                    // all four row leaders add their third register at a lane-dependent address (rows 1..3 into
+                    // the pad words): a single-lane atomic at a wave-uniform address makes hipcc wrap it in its
+                    // scalar wave-reduction loop, ~12 extra instructions per record
                     float* acc = sAcc + t * ACC_STRIDE;
                     atomicAdd(acc + slot0, k0);
                     atomicAdd(acc + 4 + slot0, k1);
-                    if (row == 0) atomicAdd(acc + 8 + row, k2);
+                    atomicAdd(acc + 8 + row, k2);
                 }
             }
         }
@@ -410,7 +432,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             const float* acc = sAcc + threadIdx.x * ACC_STRIDE;
             bool any = false;
 #pragma unroll
-            for (int k = 0; k < ACC_STRIDE; ++k) any |= (acc[k] != 0.f);
+            for (int k = 0; k < ACC_VALS; ++k) any |= (acc[k] != 0.f);
             if (any) {
                 // slot of this (record, tile) pair in emission order: u = cum_excl[pid] + index of this
                 // tile inside the record's tile rectangle (same float ops as k_isect_emit => same ints)
@@ -444,9 +466,9 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
     if (pid >= n_pairs) return;
     const int end = cum[pid];
     const int start = pid == 0 ? 0 : cum[pid - 1];
-    float acc[ACC_STRIDE];
+    float acc[ACC_VALS];
 #pragma unroll
-    for (int k = 0; k < ACC_STRIDE; ++k) acc[k] = 0.f;
+    for (int k = 0; k < ACC_VALS; ++k) acc[k] = 0.f;
     for (int u = start; u < end; ++u) {
         if (vstamp[u] == stamp) {  // the payload is only fetched for slots written by this backward call
             const float4* src = reinterpret_cast<const float4*>(vtile + (int64_t)u * VT_STRIDE);
@@ -486,9 +508,14 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     int32_t* vstamp = (int32_t*)p;
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
-    hipLaunchKernelGGL(k_blend_bwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask, words, tile_nb, cum, tight,
-                       vtile, vstamp, stamp);
+    if (v_alpha)
+        hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
+                           (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask,
+                           words, tile_nb, cum, tight, vtile, vstamp, stamp);
+    else
+        hipLaunchKernelGGL(k_blend_bwd<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
+                           (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask,
+                           words, tile_nb, cum, tight, vtile, vstamp, stamp);
     LAUNCH_CHECK();
     if (v_splats) {
         hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, vstamp, stamp,
