@@ -92,16 +92,22 @@ __device__ __forceinline__ int stage_record(const float4* __restrict__ splats, i
     sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
     sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
     sC[t] = c.x;
-    // influence box of {opacity*exp(-sigma) >= 1/255}: |dx| <= sqrt(2 tau cov_xx), tau = ln(255 o)
-    float ex, ey;
-    if (!influence_extent(a.z, a.w, b.x, b.y, 0.02f, &ex, &ey)) return 0;
-    // pixel centres of quadrant (qx,qy): tx0 + 8qx + [0.5, 7.5]
-    const float rx = a.x - ((float)tx0 + 0.5f), ry = a.y - ((float)ty0 + 0.5f);
-    const bool x0 = (rx + ex >= 0.0f) && (rx - ex <= 7.0f);
-    const bool x1 = (rx + ex >= 8.0f) && (rx - ex <= 15.0f);
-    const bool y0 = (ry + ey >= 0.0f) && (ry - ey <= 7.0f);
-    const bool y1 = (ry + ey >= 8.0f) && (ry - ey <= 15.0f);
-    return (int)(x0 && y0) | ((int)(x1 && y0) << 1) | ((int)(x0 && y1) << 2) | ((int)(x1 && y1) << 3);
+    // A quadrant (8x8 pixel centres) is relevant iff the ellipse {sigma(p) <= tau}, tau = ln(255 opacity), reaches
+    // it: either the mean lies inside, or the minimum of sigma over one of its four edges is <= tau (sigma is
+    // convex, so the minimum over the square sits on the boundary when the mean is outside).  tau is inflated
+    // (2e-4 relative + 2e-4) so that every pixel of a quadrant declared irrelevant fails the alpha test of the
+    // blend loop in float arithmetic as well.  Costs ~150 instructions per RECORD (one lane), and removes a
+    // quarter of the per-(record, quadrant) wave iterations of the axis-aligned-box test it replaces.
+    EllipseTest et;
+    if (!ellipse_prepare(a.z, a.w, b.x, b.y, &et)) return 0;
+    const float rx = ((float)tx0 + 0.5f) - a.x, ry = ((float)ty0 + 0.5f) - a.y;  // first pixel centre - mean
+    int rel = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float dx0 = rx + (float)((q & 1) * 8), dy0 = ry + (float)((q >> 1) * 8);
+        rel |= ellipse_hits_square(et, dx0, dx0 + 7.0f, dy0, dy0 + 7.0f) ? (1 << q) : 0;
+    }
+    return rel;
 }
 
 // word index of the first 64-record chunk of tile lb in the contribution-mask arrays
@@ -158,10 +164,11 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                 const float cb = sC[t];
                 const float dx = a.x - g.px, dy = a.y - g.py;
                 const float P = dx * (a.w * dx + q.x * dy) + q.y * dy * dy;
-                float al = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
-                al = (P > 0.f) ? 0.f : al;               // sigma < 0: skipped
-                al = (al < 1.f / 255.f) ? 0.f : al;      // below the visibility threshold: skipped
-                al *= live;                              // saturated pixel: skipped
+                const float al0 = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
+                // skipped: sigma < 0, below the visibility threshold, or a saturated pixel -- three independent
+                // compares and one select instead of a chain of selects
+                const bool ok = !(P > 0.f) && !(al0 < 1.f / 255.f) && (live != 0.0f);
+                float al = ok ? al0 : 0.f;
                 const float nT = T * (1.0f - al);        // == T exactly when al == 0
                 const bool stop = nT <= 1e-4f;           // only a live pixel with al > 0 can get here (T > 1e-4 otherwise)
                 live = stop ? 0.0f : live;
