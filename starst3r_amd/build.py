@@ -23,6 +23,10 @@ PER_FILE = {
     "gs_project.hip": ["-ffp-contract=off"],
     "gs_isect.hip": ["-ffp-contract=off"],
 }
+# Measured on MI355X: a v_pk_{mul,fma,add}_f32 costs two issue slots and the register pairing it needs costs extra
+# v_mov, so hipcc's packed-fp32 vectorisation slows the VALU-bound loops down (blend forward -12 %, backward -5 %
+# with it switched off).  No kernel here wants it.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def sources():
@@ -40,7 +44,7 @@ def _compile(src, force, verbose):
     srcp = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + COMMON + PER_FILE.get(src, []) + ["-c", srcp, "-o", obj]
+    cmd = [HIPCC] + COMMON + NO_PACKED_F32 + PER_FILE.get(src, []) + ["-c", srcp, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
