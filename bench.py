@@ -153,6 +153,21 @@ def align_bench(device, with_cpu=True, views=8):
     return out
 
 
+# HBM bytes per launch from the PMC passes committed in profiles/r1f_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# in separate runs; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md).  They belong to the default
+# single-GPU SYNTH-1M workload only; any other configuration reports null (counters cannot be read from inside
+# the benchmark process).
+PMC_TRAFFIC_SYNTH1M = {"blend_bwd": 6.34e9 + 1.62e9,   # k_blend_bwd + k_gather_vtile (one stage)
+                       "blend_fwd": 1.90e9, "loss": 1.20e9 + 1.44e9, "project": 0.72e9, "project_bwd": 1.06e9,
+                       "adam": 0.78e9, "emit": 1.61e9}
+
+
+def pmc_traffic(stage, N, views, W, H, world):
+    if (N, views, W, H, world) == (1_000_000, 8, 1920, 1080, 1):
+        return PMC_TRAFFIC_SYNTH1M.get(stage)
+    return None
+
+
 def matching_bench(device):
     """Path A: seeded nearest-neighbour query of fast_reciprocal_NNs (starster/reconstruct.py:97) at the
     reference's size: 3072 seeds against the 512x384 descriptors (D = 24) of the other image -- the only dense
@@ -284,7 +299,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, N, args.views, W, H, world),
                 "algorithmic_bytes_per_launch": ab[dom], "launch_ms": dom_ms,
                 "whole_iter": {"algorithmic_bytes": iter_bytes,
                                "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9,
