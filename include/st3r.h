@@ -285,6 +285,27 @@ int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, float* means, 
                        float opac_fac, float scale_fac, float* grads, float* m, float* v, double lr, double beta1,
                        double beta2, double eps, int step, float* loss_out, int64_t* stats_host);
 
+/* ----------------------------------------------------------------------------------
+ * Dense point extraction between alignment and 3DGS seeding: what
+ * starster/scene.py:148 takes from `scene.get_dense_pts3d(clean_depth=True)` (Mast3r SparseGA [U]).
+ * Views are concatenated; view v owns the dense pixels [view_start[v], view_start[v+1]) in raster order.
+ *   cam          [C,24]  the per-view rows st3r_align_run writes (R(9) T(3) f cx cy A B ...), i.e. the optimised
+ *                        cam2w / intrinsics and depthmap_v = A + B * core_depth[v]
+ *   core_depth   [C,G]   normalised core depths (the alignment's input/output), idxs index into a view's row
+ *   pixels [n,2], idxs int32 [n], offsets [n]: every dense pixel as an anchor of its view's core depthmap
+ * st3r_dense_unproject -> pts_out [n,3] world points, zcam_out [n] depth in the own camera.
+ * st3r_dense_clean (dust3r clean_pointcloud [U], tol = 0.001, bad_conf = 0 upstream): conf [n] is lowered in
+ *   place, view by view in the reference's order, for points that project inside another view, lie in front of
+ *   that view's depth by more than tol (relative) and are less confident than the pixel they land on.
+ *   sizes_hw int32 [C,2] = (H, W) of every view; max_view_pixels = largest H*W.
+ * ---------------------------------------------------------------------------------- */
+int st3r_dense_unproject(st3r_ctx* ctx, void* stream, int C, int G, int n, const int32_t* view_start,
+                         const float* pixels, const int32_t* idxs, const float* offsets, const float* core_depth,
+                         const float* cam, const float* base_focals, float* pts_out, float* zcam_out);
+int st3r_dense_clean(st3r_ctx* ctx, void* stream, int C, int max_view_pixels, const int32_t* view_start,
+                     const int32_t* sizes_hw, const float* cam, const float* pts, const float* zcam, float tol,
+                     float bad_conf, float* conf);
+
 #ifdef __cplusplus
 }
 #endif

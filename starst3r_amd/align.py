@@ -77,6 +77,7 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
     cam2w[:, :3, :3] = cam[:, :9].reshape(Cn, 3, 3); cam2w[:, :3, 3] = cam[:, 9:12]; cam2w[:, 3, 3] = 1
     depth = cam[:, 15:16] + cam[:, 16:17] * core
     res = dict(intrinsics=K, cam2w=cam2w, depthmaps=depth, pts3d=pts, losses=losses[:niter1 + niter2],
+               _cam_rows=cam, _core=core, _base_focals=base_focals,
                _adam_m=work[:11 * Cn].clone())  # first moments, order pps|log_focals|quats|trans|log_sizes (tests)
     params = dict(P)
     params["core_depth"] = core

@@ -213,6 +213,27 @@ def train_step(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fac, 
     return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
 
 
+def dense_unproject(ctx, view_start, pixels, idxs, offsets, core, cam_rows, base_focals):
+    """All dense pixels of all views (concatenated) -> world points [n,3] and own-camera depth [n]."""
+    n, Cn, G = pixels.shape[0], cam_rows.shape[0], core.shape[1]
+    pts = torch.empty((n, 3), dtype=torch.float32, device=cam_rows.device)
+    z = torch.empty((n,), dtype=torch.float32, device=cam_rows.device)
+    _lib.check(_lib.lib().st3r_dense_unproject(ctx.handle, _stream(), Cn, G, n, _p(view_start, torch.int32), _p(pixels),
+                                               _p(idxs, torch.int32), _p(offsets), _p(core), _p(cam_rows),
+                                               _p(base_focals), _p(pts), _p(z)))
+    return pts, z
+
+
+def dense_clean(ctx, view_start, sizes_hw, cam_rows, pts, zcam, conf, tol=0.001, bad_conf=0.0):
+    """dust3r clean_pointcloud on the concatenated views; returns the cleaned confidences (new tensor)."""
+    out = conf.clone()
+    mx = int((sizes_hw[:, 0].long() * sizes_hw[:, 1].long()).max())
+    _lib.check(_lib.lib().st3r_dense_clean(ctx.handle, _stream(), cam_rows.shape[0], mx, _p(view_start, torch.int32),
+                                           _p(sizes_hw, torch.int32), _p(cam_rows), _p(pts), _p(zcam), tol, bad_conf,
+                                           _p(out)))
+    return out
+
+
 def mcmc_relocate(ctx, params, m, v, min_opacity, seed, step, want_count=True):
     """In place on params (means, quats, scales, opacities, sh0 or None, shN) and on the fused Adam moments
     m, v ([23N] blocks, or None).  Returns the number of relocated Gaussians (None if not wanted: no sync)."""

@@ -40,28 +40,35 @@ class SparseGAResult:
         self.depthmaps = res["depthmaps"]
         self.pts3d = res["pts3d"]
         self.losses = res["losses"]
+        self._res = res
         self._dense = dense
 
     def get_dense_pts3d(self, clean_depth=True):
-        """Dense unprojection with the OPTIMISED cameras and depthmaps (Mast3r SparseGA.get_dense_pts3d): every
+        """Dense unprojection with the OPTIMISED cameras and depthmaps (Mast3r SparseGA.get_dense_pts3d [U]): every
         dense pixel is treated like an anchor -- depth = depthmap[idx] * offset' -- so the points live in the
-        optimiser's gauge (App. A.5 make_pts3d).  `clean_depth` is accepted for API compatibility."""
+        optimiser's gauge (App. A.5 make_pts3d); with clean_depth the confidences of points floating in front of
+        another view's surface are lowered (dust3r clean_pointcloud [U]).  Runs in libst3r_hip.so
+        (st3r_dense_unproject / st3r_dense_clean).  Returns (pts list, depthmaps list, confs list) per view."""
         if self._dense is None:
             raise NotImplementedError("dense unprojection needs the model's dense pixel table (SURVEY.md 8(f) #3)")
+        from . import ops
         dev = self.cam2w.device
-        pts, confs = [], []
-        for i, d in enumerate(self._dense):
-            pix = torch.as_tensor(d["pixels"], dtype=torch.float32, device=dev)
-            idx = torch.as_tensor(d["idxs"], dtype=torch.int64, device=dev)
-            off = torch.as_tensor(d["offsets"], dtype=torch.float32, device=dev)
-            K, T = self.intrinsics[i], self.cam2w[i]
-            f = K[0, 0]
-            offp = 1 + (off - 1) * (float(d["base_focal"]) / f)
-            z = self.depthmaps[i][idx] * offp
-            pc = torch.stack(((pix[:, 0] - K[0, 2]) / f * z, (pix[:, 1] - K[1, 2]) / f * z, z), dim=-1)
-            pts.append(pc @ T[:3, :3].T + T[:3, 3])
-            confs.append(torch.as_tensor(d["confs"], dtype=torch.float32))
-        return pts, list(self.depthmaps), confs
+        ctx = ops.get_context(dev)
+        counts = [len(d["idxs"]) for d in self._dense]
+        start = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32, device=dev)
+        cat = lambda key, dt: torch.cat([torch.as_tensor(np.asarray(d[key]), dtype=dt) for d in self._dense]).to(dev).contiguous()
+        pix, idx, off, conf = cat("pixels", torch.float32), cat("idxs", torch.int32), cat("offsets", torch.float32), \
+            cat("confs", torch.float32)
+        pts, z = ops.dense_unproject(ctx, start, pix, idx, off, self._res["_core"], self._res["_cam_rows"],
+                                     self._res["_base_focals"])
+        if clean_depth:
+            sizes = torch.tensor([list(np.asarray(im).shape[:2]) for im in self.imgs], dtype=torch.int32, device=dev)
+            assert all(int(h) * int(w) == c for (h, w), c in zip(sizes.tolist(), counts)), \
+                "clean_depth needs one dense entry per pixel, in raster order"
+            conf = ops.dense_clean(ctx, start, sizes, self._res["_cam_rows"], pts, z, conf)
+        bounds = start.tolist()
+        sl = [slice(bounds[i], bounds[i + 1]) for i in range(len(counts))]
+        return [pts[s_] for s_ in sl], list(self.depthmaps), [conf[s_].cpu() for s_ in sl]
 
 
 def run_sparse_ga(condensed, device="cuda", optim_params=None, lr1=0.07, niter1=500, lr2=0.014, niter2=200, **kw):
