@@ -12,8 +12,7 @@ def process_image(img: torch.Tensor, size: int = 224) -> torch.Tensor:
     """(3,H,W) float image in [0,1] -> resized so the long side is `size`, centre-cropped to multiples of 16,
     normalised to [-1,1] (reference image.py:43-76)."""
     C, H, W = img.shape
-    scale = size / max(H, W)
-    nh, nw = max(16, round(H * scale)), max(16, round(W * scale))
+    nh, nw = (int(x * size / max(H, W)) for x in (H, W))   # truncation, as the reference (image.py:62)
     out = torch.nn.functional.interpolate(img[None].float(), size=(nh, nw), mode="bicubic", align_corners=False,
                                           antialias=True)[0]
     ch, cw = (nh // 16) * 16, (nw // 16) * 16
@@ -22,9 +21,19 @@ def process_image(img: torch.Tensor, size: int = 224) -> torch.Tensor:
     return out * 2 - 1
 
 
+def make_pair_indices(n: int, symmetric: bool = True):
+    """All index pairs of the fully connected graph (reference image.py:24-40): (i, j) for j < i, then the
+    mirrored pairs when symmetric."""
+    pairs = [(i, j) for i in range(n) for j in range(i)]
+    if symmetric:
+        pairs += [(j, i) for (i, j) in pairs]
+    return pairs
+
+
 def load_image(path: str, size: int = 224) -> torch.Tensor:
     from PIL import Image
-    arr = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+    from PIL.ImageOps import exif_transpose
+    arr = np.asarray(exif_transpose(Image.open(path)).convert("RGB"), dtype=np.float32) / 255.0
     return process_image(torch.from_numpy(arr).permute(2, 0, 1), size)
 
 

@@ -1,0 +1,34 @@
+"""Host-side image preprocessing keeps the reference's size rules (starster/image.py:43-76, 24-40)."""
+import numpy as np
+import pytest
+import torch
+
+from starst3r_amd import image
+
+
+@pytest.mark.parametrize("H,W,size", [(300, 451, 224), (480, 640, 512), (1080, 1920, 512), (97, 33, 224), (224, 224, 224)])
+def test_process_image_size_rules(H, W, size):
+    x = torch.rand(3, H, W)
+    y = image.process_image(x, size)
+    nh, nw = int(H * size / max(H, W)), int(W * size / max(H, W))       # image.py:62 (truncation)
+    cy, cx = nh // 2, nw // 2                                             # image.py:65-66
+    assert y.shape == (3, 2 * ((cy // 8) * 8), 2 * ((cx // 8) * 8))       # image.py:69-73: multiples of 16
+    assert y.dtype == torch.float32 and float(y.min()) >= -1.3 and float(y.max()) <= 1.3   # Normalize(0.5, 0.5)
+
+
+def test_process_image_is_centre_crop_of_the_resize():
+    x = torch.rand(3, 130, 210)
+    y = image.process_image(x, 200)
+    full = torch.nn.functional.interpolate(x[None], size=(int(130 * 200 / 210), 200), mode="bicubic",
+                                           align_corners=False, antialias=True)[0] * 2 - 1
+    nh, nw = full.shape[1:]
+    cy, cx = nh // 2, nw // 2
+    hh, wh = (cy // 8) * 8, (cx // 8) * 8
+    assert torch.equal(y, full[:, cy - hh:cy + hh, cx - wh:cx + wh])
+
+
+def test_pair_indices_and_mast3r_dicts():
+    assert image.make_pair_indices(3, symmetric=False) == [(1, 0), (2, 0), (2, 1)]
+    assert image.make_pair_indices(3) == [(1, 0), (2, 0), (2, 1), (0, 1), (0, 2), (1, 2)]
+    d = image.prepare_images_for_mast3r([torch.zeros(3, 32, 48), torch.zeros(3, 16, 16)])
+    assert d[1]["img"].shape == (1, 3, 16, 16) and d[0]["true_shape"].tolist() == [[32, 48]] and d[1]["instance"] == "1"
