@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi-gpu", choices=("auto", "replicated", "gaussian-sharded"), default="auto",
+                    help="how N > 1 GPUs are used (DESIGN.md section 5); auto = gaussian-sharded when <= 2 views per GPU")
     ap.add_argument("--cpu-sample-div", type=int, default=2,
                     help="CPU baseline sample: 1 view at (W/div)x(H/div), N/div^2 gaussians, same density")
     return ap.parse_args()
@@ -223,26 +225,44 @@ def main():
     N, W, H = args.gaussians, args.width, args.height
     assert args.views % world == 0, "views must divide evenly over the GPUs"
     g_np, w2c_np, Ks_np = synth.make_scene(N, args.views, W, H)
-    views = list(range(rank, args.views, world))  # this rank's views
-    C_local = len(views)
-    P = {k: torch.tensor(v, device=device) for k, v in g_np.items()}
-    w2c = torch.tensor(w2c_np[views], device=device)
-    Ks = torch.tensor(Ks_np[views], device=device)
-    campos = ops.camera_positions(w2c)
-    gt = make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device)
-
-    grads = torch.empty(23 * N, device=device)
-    m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+    C_local = args.views // world
+    # Two ways to use N GPUs.  With one or two views per GPU the Gaussians are sharded as well
+    # (two all-to-alls of splat records instead of the gradient all-reduce, no replicated Adam); with more views per
+    # GPU the records would outweigh the gradients, so the views are sharded and the parameters replicated.
+    mode = args.multi_gpu
+    if mode == "auto":
+        mode = "gaussian-sharded" if (world > 1 and C_local <= 2 and N % world == 0) else "replicated"
     total = args.warmup + args.steps
     losses = torch.zeros(total, device=device)
     stats = {}
+    if mode == "gaussian-sharded":
+        from starst3r_amd import dist as sdist
+        views = sdist.shard_views_contiguous(args.views, rank, world)
+        lo, hi = sdist.shard_gaussians(N, rank, world)
+        w2c_all = torch.tensor(w2c_np, device=device); Ks_all = torch.tensor(Ks_np, device=device)
+        w2c = w2c_all[views].contiguous(); Ks = Ks_all[views].contiguous()
+        gt = make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device)
+        P = {k: torch.tensor(np.ascontiguousarray(v[lo:hi]), device=device) for k, v in g_np.items()}
+        trainer = sdist.ShardedTrainer(ctx, P, N, w2c_all, Ks_all, gt, W, H, rank, world)
 
-    def step(it):
-        st = ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1])
-        if world > 1:
-            dist.all_reduce(grads)          # RCCL sum over ranks (views are sharded, loss is a sum over views)
-        ops.adam_step(ctx, P, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1)
-        return st
+        def step(it):
+            return trainer.step(losses[it:it + 1])
+    else:
+        views = list(range(rank, args.views, world))  # this rank's views
+        P = {k: torch.tensor(v, device=device) for k, v in g_np.items()}
+        w2c = torch.tensor(w2c_np[views], device=device)
+        Ks = torch.tensor(Ks_np[views], device=device)
+        campos = ops.camera_positions(w2c)
+        gt = make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device)
+        grads = torch.empty(23 * N, device=device)
+        m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+
+        def step(it):
+            st = ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1])
+            if world > 1:
+                dist.all_reduce(grads)          # RCCL sum over ranks (views are sharded, loss is a sum over views)
+            ops.adam_step(ctx, P, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1)
+            return st
 
     for it in range(args.warmup):
         stats = step(it)
@@ -260,6 +280,8 @@ def main():
     dt = time.perf_counter() - t0
     stage = ops.stage_ms(ctx)
     ops.set_profiling(ctx, False)
+    if mode == "gaussian-sharded":   # counts of the own Gaussians over all views ~ those of the own views over all Gaussians
+        stats["n_visible"] = int(trainer.reg[2].item()); stats["n_isects_ref"] = int(trainer.reg[3].item())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,9 +311,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"SYNTH-1M (BASELINE.json configs[2]): {N} gaussians, {args.views} views {W}x{H}, "
-                            f"3DGS train only; views sharded {C_local}/GPU, gaussians replicated",
+                            f"3DGS train only; views sharded {C_local}/GPU, gaussians "
+                            + ("sharded" if mode == "gaussian-sharded" else "replicated"),
                 "gaussians": N, "views": args.views, "width": W, "height": H, "views_per_gpu": C_local,
-                "parallelism": f"view-dp{world}", "n_visible_pairs": V, "n_isects": I, "n_isects_kept_after_exact_culling": I_kept,
+                "parallelism": (f"gaussians+views sharded x{world} (2 all-to-all of splat records / iteration)"
+                                if mode == "gaussian-sharded" else f"view-dp{world} (gradient all-reduce)"), "n_visible_pairs": V, "n_isects": I, "n_isects_kept_after_exact_culling": I_kept,
                 "sort_key_bits": keybits,
                 "mean_tiles_per_visible_gaussian": (I / V) if V else 0.0,
                 "mean_gaussians_per_tile": I / (C_local * tw * th),

@@ -306,6 +306,23 @@ int st3r_dense_clean(st3r_ctx* ctx, void* stream, int C, int max_view_pixels, co
                      const int32_t* sizes_hw, const float* cam, const float* pts, const float* zcam, float tol,
                      float bad_conf, float* conf);
 
+/* ----------------------------------------------------------------------------------
+ * Gaussian-sharded multi-GPU mode (an alternative to the gradient all-reduce when every rank owns one or two
+ * views): rank r owns the Gaussians [r N/w, (r+1) N/w) -- parameters and Adam state are NOT replicated -- and
+ * the views [r C, (r+1) C).  Per iteration:
+ *   1. st3r_gs_project_sh on the own Gaussians for ALL views          -> records [V, N/w, 12]
+ *   2. all-to-all: every rank receives the records of all Gaussians for its views -> [C, N, 12]
+ *   3. st3r_gs_raster_train(N, C, records, gt, ...)                   -> v_records [C, N, 12], image loss
+ *   4. all-to-all back: owners receive [V, N/w, 12]
+ *   5. st3r_gs_project_sh_bwd on the own Gaussians (pass opac_fac, scale_fac scaled by (N/w)/N so that the
+ *      regularisers stay means over all N) and st3r_adam_step on the shard.
+ * Exchanged per rank and iteration: 2 (w-1)/w C (N/w)... = 2 x 48 B x C x N (w-1)/w, against 2 x 92 B x N (w-1)/w
+ * for the all-reduce; no replicated optimiser work.  starst3r_amd/dist.py holds the two exchanges.
+ * ---------------------------------------------------------------------------------- */
+int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, const float* records, const float* gt_images,
+                         int width, int height, float ssim_fac, float* v_records, float* loss_out,
+                         int64_t* stats_host);
+
 #ifdef __cplusplus
 }
 #endif

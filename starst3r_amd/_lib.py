@@ -58,6 +58,7 @@ SIGNATURES = {
     "st3r_recip_nn": [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "st3r_dense_unproject": [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "st3r_dense_clean": [vp, vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp],
+    "st3r_gs_raster_train": [vp, vp, i32, i32, vp, vp, i32, i32, f32, vp, vp, C.POINTER(i64)],
     "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],
 }
 _RESTYPES = {"st3r_last_error": C.c_char_p, "st3r_stage_name": C.c_char_p, "st3r_ctx_arena_bytes": i64}

@@ -175,6 +175,8 @@ int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, con
 int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
                                 const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h, int tight,
                                 uint32_t* tile_keys, int32_t* vals);
+int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
+                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals);
 int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
                               int32_t* offsets);
 int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint64_t* keys_in, int32_t* vals_in,
@@ -210,11 +212,17 @@ struct RasterOut {
 static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats,
                            const float* scales, const float* opacities, const float* sh, int sh_stride,
                            const float* viewmats, const float* Ks, const float* campos, int W, int H,
-                           double* reg_sums, int tight, RasterOut* o) {
+                           double* reg_sums, int tight, const float* records_in, RasterOut* o) {
+    // records_in != NULL: the splat records were projected elsewhere (Gaussian-sharded mode); the projection is
+    // replaced by k_records_prepare and the records are used in place
     const int tile = 16;
     const int tile_w = (W + tile - 1) / tile, tile_h = (H + tile - 1) / tile;
     const int64_t n_pairs = (int64_t)N * C;
-    GET(SLOT_SPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, splats);
+    float* splats = const_cast<float*>(records_in);
+    if (!records_in) {
+        GET(SLOT_SPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, own);
+        splats = own;
+    }
     GET(SLOT_TILES, int32_t, n_pairs, tiles);
     GET(SLOT_CUM, int32_t, n_pairs, cum);
     GET(SLOT_OFFSETS, int32_t, (int64_t)C * tile_w * tile_h, offsets);
@@ -227,8 +235,11 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_DVALS_B, int32_t, n_pairs, perm);
     GET(SLOT_CUM_D, int32_t, n_pairs, cum_d);
     st3r_prof_begin(ctx, s, STG_PROJECT);
-    int rc = st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                               tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums, dkeys_a, dvals_a, tight);
+    int rc = records_in
+                 ? st3r_records_prepare_impl(s, N, C, splats, tile, tile_w, tile_h, tight, tiles, dkeys_a, dvals_a)
+                 : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
+                                     W, H, tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums, dkeys_a, dvals_a,
+                                     tight);
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
@@ -307,7 +318,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     st3r_prof_next_step(ctx);
     RasterOut ro;
     int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                             reg_sums, 1, &ro);
+                             reg_sums, 1, nullptr, &ro);
     if (rc) return rc;
     GET(SLOT_RGB, float, n_px * 3, rgb);
     GET(SLOT_ALPHA, float, n_px, alpha);
@@ -346,6 +357,54 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     return ST3R_OK;
 }
 
+// Gaussian-sharded multi-GPU mode, middle phase: this rank owns C views and received the splat records of ALL
+// Gaussians for them (projected by the ranks that own the Gaussians).  Sort, blend, loss, blend backward; the
+// per-record gradients go back to the owners, which run the projection backward and Adam on their shard.
+ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, const float* records,
+                                     const float* gt_images, int width, int height, float ssim_fac,
+                                     float* v_records, float* loss_out, int64_t* stats_host) {
+    ARG_CHECK(ctx && N > 0 && C > 0 && width > 0 && height > 0 && records && gt_images && v_records && loss_out);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = width, H = height;
+    const int64_t n_pairs = (int64_t)N * C, n_px = (int64_t)C * H * W;
+    GET(SLOT_SMALL, double, 2 * (size_t)C + 8, small);
+    double* sums = small;
+    double* reg_sums = small + 2 * C;
+    HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 4, s));  // stays zero: the regularisers belong to the owners
+    st3r_prof_next_step(ctx);
+    RasterOut ro;
+    int rc = rasterize_front(ctx, s, N, C, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, W,
+                             H, nullptr, 1, records, &ro);
+    if (rc) return rc;
+    GET(SLOT_RGB, float, n_px * 3, rgb);
+    GET(SLOT_ALPHA, float, n_px, alpha);
+    GET(SLOT_LAST, int32_t, n_px, last);
+    GET(SLOT_VRENDER, float, n_px * 3, v_rgb);
+    st3r_prof_begin(ctx, s, STG_BLEND_FWD);
+    rc = st3r_blend_fwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb,
+                             alpha, last, true);
+    st3r_prof_end(ctx, s, STG_BLEND_FWD);
+    if (rc) return rc;
+    st3r_prof_begin(ctx, s, STG_LOSS);
+    rc = st3r_loss_impl(ctx, s, C, H, W, rgb, gt_images, 1.0f - ssim_fac, ssim_fac, sums, v_rgb);
+    st3r_prof_end(ctx, s, STG_LOSS);
+    if (rc) return rc;
+    st3r_prof_begin(ctx, s, STG_BLEND_BWD);
+    rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
+                             last, v_rgb, nullptr, ro.cum, 1, n_pairs, v_records);
+    st3r_prof_end(ctx, s, STG_BLEND_BWD);
+    if (rc) return rc;
+    const int Hi = H - 10, Wi = W - 10;
+    const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
+    hipLaunchKernelGGL(k_finalize_loss, dim3(1), dim3(64), 0, s, C, sums, reg_sums, 1.0 / ((double)H * W * 3),
+                       cnt > 0 ? 1.0 / cnt : 0.0, (double)(1.0f - ssim_fac), (double)ssim_fac, 0.0, 0.0, 0.0, loss_out);
+    LAUNCH_CHECK();
+    if (stats_host) {
+        stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = -1;
+    }
+    return ST3R_OK;
+}
+
 ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,
                                const float* scales, const float* opacities, const float* sh, int sh_stride,
                                const float* viewmats, const float* Ks, const float* campos, int width, int height,
@@ -355,7 +414,7 @@ ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const 
     hipStream_t s = (hipStream_t)stream;
     RasterOut ro;
     int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width,
-                             height, nullptr, 0, &ro);
+                             height, nullptr, 0, nullptr, &ro);
     if (rc) return rc;
     GET(SLOT_LAST, int32_t, (int64_t)C * height * width, last);
     rc = st3r_blend_fwd_impl(ctx, s, C, width, height, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat,

@@ -37,10 +37,17 @@
 #define BLK 256
 #define LOG2E 1.4426950408889634f
 
-__device__ __forceinline__ int xcd_remap(int bid, int total) {
-    const int q = total >> 3, r = total & 7;
+// Workgroup b runs on XCD b % 8 (each XCD has its own L2).  Tiles are handed out in groups of G consecutive
+// tiles per XCD, the groups round-robin over the XCDs: neighbouring tiles (which share Gaussians) meet in one L2.
+// With C a multiple of 8 a group is a whole camera (one camera per XCD); otherwise a group is one tile row, so
+// that the dense image centre and the sparse borders are spread over all XCDs (a single view cut into 8
+// contiguous bands left the XCDs of the borders idle: blend bwd 0.65 -> see DESIGN.md).
+__device__ __forceinline__ int xcd_remap(int bid, int total, int G) {
+    const int n_full = (total / (8 * G)) * (8 * G);
+    if (bid >= n_full) return bid;
     const int xcd = bid & 7, k = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int round = k / G, within = k - round * G;
+    return (round * 8 + xcd) * G + within;
 }
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
@@ -68,7 +75,7 @@ __device__ __forceinline__ TileGeom tile_geom(int C, int W, int H, int tile_w, i
                                               const int32_t* __restrict__ offsets, int n_isects) {
     TileGeom g;
     const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-    g.lb = xcd_remap(blockIdx.x, total);
+    g.lb = xcd_remap(blockIdx.x, total, (C & 7) == 0 ? (C >> 3) * n_tiles : tile_w);
     g.cam = g.lb / n_tiles;
     const int tile = g.lb - g.cam * n_tiles;
     const int ty = tile / tile_w, tx = tile - ty * tile_w;

@@ -318,3 +318,42 @@ int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* k
     LAUNCH_CHECK();
     return ST3R_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Rasterizing from records that another rank projected (Gaussian-sharded multi-GPU mode): rebuild what
+// k_project_sh_fwd would have written next to them -- the tile count (same rectangle code) and the
+// (camera | depth bits) key of the two-level sort.  A record with radius 0 is a culled pair.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs, const float4* __restrict__ splats,
+                                                         int tile_size, int tile_w, int tile_h, int tight,
+                                                         int32_t* __restrict__ tiles, uint64_t* __restrict__ depth_keys,
+                                                         int32_t* __restrict__ depth_vals) {
+    const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= n_pairs) return;
+    const float4 r2 = splats[pid * 3 + 2];
+    const int radius = __float_as_int(r2.z);
+    int ntiles = 0;
+    if (radius > 0) {
+        const float4 r0 = splats[pid * 3 + 0];
+        TileRect tr = ref_tile_rect(r0.x, r0.y, (float)radius, tile_size, tile_w, tile_h);
+        if (tight) {
+            const float4 r1 = splats[pid * 3 + 1];
+            tr = tight_tile_rect(tr, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
+        }
+        ntiles = (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
+    }
+    tiles[pid] = ntiles;
+    const uint32_t dbits = radius > 0 ? (uint32_t)__float_as_int(r2.y) : 0xFFFFFFFFu;
+    depth_keys[pid] = ((uint64_t)(pid / N) << 32) | dbits;
+    depth_vals[pid] = (int32_t)pid;
+}
+
+int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
+                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals) {
+    const int64_t n_pairs = (int64_t)N * C;
+    if (n_pairs == 0) return ST3R_OK;
+    hipLaunchKernelGGL(k_records_prepare, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs,
+                       (const float4*)splats, tile_size, tile_w, tile_h, tight, tiles, depth_keys, depth_vals);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}

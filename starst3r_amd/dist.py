@@ -67,3 +67,100 @@ def detach_native_comm(ctx):
     from . import _lib
     _lib.check(_lib.lib().st3r_comm_destroy(ctx.handle))
     ctx.native_comm = False
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Gaussian-sharded mode (include/st3r.h, "Gaussian-sharded multi-GPU mode"): rank r owns Gaussians
+# [r N/w, (r+1) N/w) and views [r C, (r+1) C).  Two all-to-alls per iteration move splat records to the views'
+# owners and their gradients back; nothing is replicated and nothing is all-reduced except the reported loss.
+# ----------------------------------------------------------------------------------------------------------
+
+def shard_gaussians(N, rank, world):
+    if N % world:
+        raise ValueError(f"the Gaussian-sharded mode needs N ({N}) divisible by the number of ranks ({world})")
+    n = N // world
+    return rank * n, (rank + 1) * n
+
+
+def shard_views_contiguous(n_views, rank, world):
+    if n_views % world:
+        raise ValueError(f"the Gaussian-sharded mode needs the views ({n_views}) divisible by the ranks ({world})")
+    c = n_views // world
+    return list(range(rank * c, (rank + 1) * c))
+
+
+def _all_to_all(recv, send):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_to_all_single(recv, send)
+    else:
+        recv.copy_(send)
+
+
+def records_to_view_owners(records_local, world, a2a=_all_to_all):
+    """records_local [V, n, K] (own Gaussians, all V = world*C views) -> [C, world*n, K]: all Gaussians (global order)
+    for the C views this rank owns.  Chunk r of the send buffer = views of rank r."""
+    V, n, K = records_local.shape
+    C = V // world
+    send = records_local.reshape(world, C, n, K)
+    recv = torch.empty_like(send)                       # [source rank, C, n, K]
+    a2a(recv.reshape(-1), send.reshape(-1))
+    if C == 1:
+        return recv.reshape(1, world * n, K)
+    return recv.permute(1, 0, 2, 3).reshape(C, world * n, K).contiguous()
+
+
+def records_to_gaussian_owners(v_records, world, a2a=_all_to_all):
+    """v_records [C, world*n, K] (own views, all Gaussians) -> [V, n, K]: all views for the own Gaussians."""
+    C, N, K = v_records.shape
+    n = N // world
+    send = v_records.reshape(C, world, n, K)
+    send = send.reshape(world, n, K) if C == 1 else send.permute(1, 0, 2, 3).contiguous()   # [dest rank, C, n, K]
+    recv = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)    # [source = view owner, C, n, K]
+    a2a(recv.reshape(-1), send.reshape(-1))
+    return recv.reshape(world * C, n, K)
+
+
+class ShardedTrainer:
+    """One rank of the Gaussian-sharded train loop.  `params` hold only this rank's Gaussians
+    (means/quats/scales/opacities/shN rows [lo, hi)); w2c/Ks describe ALL V views; gt holds the images of the
+    views this rank owns (shard_views_contiguous)."""
+
+    def __init__(self, ctx, params, n_total, w2c_all, Ks_all, gt_local, W, H, rank, world, lr=1e-3,
+                 ssim_fac=0.2, opac_fac=0.01, scale_fac=0.01, a2a=_all_to_all):
+        from . import ops
+        self.ops, self.ctx, self.P, self.N, self.W, self.H = ops, ctx, params, n_total, W, H
+        self.rank, self.world, self.a2a = rank, world, a2a
+        self.w2c, self.Ks, self.gt = w2c_all.contiguous(), Ks_all.contiguous(), gt_local
+        self.campos = ops.camera_positions(self.w2c)
+        self.V = self.w2c.shape[0]
+        self.C = self.V // world
+        self.n = params["means"].shape[0]
+        assert self.n * world == n_total and self.C * world == self.V and gt_local.shape[0] == self.C
+        dev = params["means"].device
+        self.grads = torch.empty(23 * self.n, device=dev)
+        self.m = torch.zeros_like(self.grads); self.v = torch.zeros_like(self.grads)
+        self.v_records = torch.empty((self.C * n_total, 12), device=dev)
+        self.reg = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.lr, self.ssim_fac, self.opac_fac, self.scale_fac, self.t = lr, ssim_fac, opac_fac, scale_fac, 0
+
+    def step(self, loss_out):
+        """loss_out[0] receives this rank's part of the loss (sum over ranks = the reference's loss)."""
+        ops, P = self.ops, self.P
+        self.reg.zero_()
+        rec, _ = ops.project_sh(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
+                                self.Ks, self.campos, self.W, self.H, reg_sums=self.reg)
+        mine = records_to_view_owners(rec.reshape(self.V, self.n, 12), self.world, self.a2a)
+        st = ops.raster_train(self.ctx, mine.reshape(-1, 12), self.N, self.C, self.gt, self.W, self.H, self.ssim_fac,
+                              self.v_records, loss_out)
+        back = records_to_gaussian_owners(self.v_records.reshape(self.C, self.N, 12), self.world, self.a2a)
+        frac = self.n / self.N    # the regularisers are means over ALL N Gaussians (starster/gs.py:132,134)
+        g = ops.project_sh_bwd(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
+                               self.Ks, self.campos, self.W, self.H, rec, back.reshape(-1, 12),
+                               reg_views=float(self.V), opac_fac=self.opac_fac * frac, scale_fac=self.scale_fac * frac)
+        self.grads = g
+        # regulariser part of the loss for the own Gaussians, added once per view like the reference (gs.py:150-152)
+        loss_out += (self.V * (self.opac_fac * self.reg[0] / self.N + self.scale_fac * self.reg[1] / (3 * self.N))).float()
+        self.t += 1
+        ops.adam_step(self.ctx, P, self.grads, self.m, self.v, self.lr, 0.9, 0.999, 1e-8, self.t)
+        return st

@@ -234,6 +234,15 @@ def dense_clean(ctx, view_start, sizes_hw, cam_rows, pts, zcam, conf, tol=0.001,
     return out
 
 
+def raster_train(ctx, records, N, Cn, gt, W, H, ssim_fac, v_records, loss_out):
+    """Middle phase of the Gaussian-sharded mode: records [Cn*N,12] of ALL Gaussians for this rank's views ->
+    v_records (same shape), this rank's image loss."""
+    stats = (C.c_int64 * 4)()
+    _lib.check(_lib.lib().st3r_gs_raster_train(ctx.handle, _stream(), N, Cn, _p(records), _p(gt), W, H, ssim_fac,
+                                               _p(v_records), _p(loss_out), stats))
+    return dict(n_isects=int(stats[1]), arena_bytes=int(stats[2]))
+
+
 def mcmc_relocate(ctx, params, m, v, min_opacity, seed, step, want_count=True):
     """In place on params (means, quats, scales, opacities, sh0 or None, shN) and on the fused Adam moments
     m, v ([23N] blocks, or None).  Returns the number of relocated Gaussians (None if not wanted: no sync)."""

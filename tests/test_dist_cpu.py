@@ -88,3 +88,37 @@ def test_shard_views_partitions_and_rejects_idle_ranks():
     with pytest.raises(ValueError):
         sdist.shard_views(2, 3, 4)
     assert sdist.rank_world() == (0, 1)
+
+
+# ---- Gaussian-sharded mode: the two all-to-all exchanges (layout logic) on gloo, world size 2 ----
+
+def _label(rank_of_gaussian, view, g_local, K=3):
+    return torch.tensor([float(rank_of_gaussian), float(view), float(g_local)])[:K]
+
+
+def _a2a_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    V, n, K = 4, 5, 3                                   # 4 views -> C = 2 per rank; 5 Gaussians per rank
+    C = V // world
+    assert sdist.shard_gaussians(n * world, rank, world) == (rank * n, (rank + 1) * n)
+    assert sdist.shard_views_contiguous(V, rank, world) == list(range(rank * C, (rank + 1) * C))
+    local = torch.stack([torch.stack([_label(rank, v, i) for i in range(n)]) for v in range(V)])     # [V, n, K]
+    mine = sdist.records_to_view_owners(local, world)                                                  # [C, world*n, K]
+    ok = mine.shape == (C, world * n, K)
+    for c in range(C):
+        for g in range(world * n):
+            ok &= bool(torch.equal(mine[c, g], _label(g // n, rank * C + c, g % n)))
+    back = sdist.records_to_gaussian_owners(mine * 2.0, world)                                         # [V, n, K]
+    ok &= bool(torch.equal(back, local * 2.0))
+    with open(f"{out}.{rank}", "w") as f:
+        f.write("ok" if ok else "bad")
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_exchanges_world2(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = str(tmp_path / "a2a")
+    mp.spawn(_a2a_worker, args=(2, port, out), nprocs=2, join=True)
+    assert [open(f"{out}.{r}").read() for r in range(2)] == ["ok", "ok"]
