@@ -316,8 +316,8 @@ int st3r_dense_clean(st3r_ctx* ctx, void* stream, int C, int max_view_pixels, co
  *   4. all-to-all back: owners receive [V, N/w, 12]
  *   5. st3r_gs_project_sh_bwd on the own Gaussians (pass opac_fac, scale_fac scaled by (N/w)/N so that the
  *      regularisers stay means over all N) and st3r_adam_step on the shard.
- * Exchanged per rank and iteration: 2 (w-1)/w C (N/w)... = 2 x 48 B x C x N (w-1)/w, against 2 x 92 B x N (w-1)/w
- * for the all-reduce; no replicated optimiser work.  starst3r_amd/dist.py holds the two exchanges.
+ * Exchanged per rank and iteration: 2 x 48 B x C x N (w-1)/w, against 2 x 92 B x N (w-1)/w for the gradient
+ * all-reduce; no replicated optimiser work.  starst3r_amd/dist.py holds the two exchanges.
  * ---------------------------------------------------------------------------------- */
 int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, const float* records, const float* gt_images,
                          int width, int height, float ssim_fac, float* v_records, float* loss_out,
