@@ -18,7 +18,7 @@
 
 #define LW 64                 // strip width in pixels
 #define LT (LW * 3)           // threads per workgroup: one per (column, channel)
-#define LH 64                 // output rows per workgroup
+#define LH_MAX 64             // output rows per workgroup (32 when the launch would otherwise leave CUs idle)
 #define HALO 5
 #define KS 11
 #define SEG ((LW + 2 * HALO) * 3)   // floats per staged row segment of an image (222)
@@ -45,7 +45,7 @@ __device__ __forceinline__ float block_sum_192(float v, float* red) {
     return t;
 }
 
-__global__ __launch_bounds__(LT) void k_ssim_fwd(int H, int W, const float* __restrict__ render,
+__global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const float* __restrict__ render,
                                                  const float* __restrict__ gt, Win win,
                                                  double* __restrict__ sums, float* __restrict__ D) {
     __shared__ float sx[2][SEG];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int H, int W, const float* __re
     }
 }
 
-__global__ __launch_bounds__(LT) void k_ssim_bwd(int H, int W, const float* __restrict__ render,
+__global__ __launch_bounds__(LT) void k_ssim_bwd(int LH, int H, int W, const float* __restrict__ render,
                                                  const float* __restrict__ gt, const float* __restrict__ D,
                                                  Win win, float k_l1, float k_ss,
                                                  float* __restrict__ v_render) {
@@ -263,15 +263,18 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
         if (rc) return rc;
         D = (float*)p;
     }
+    // 64-row strips re-read 16 % halo rows, 32-row strips 31 %: take the short ones only when the long ones
+    // would give fewer than ~4 workgroups per CU (one or two views per GPU)
+    const int LH = (ceil_div(W, LW) * ceil_div(H, LH_MAX) * C >= 1024) ? LH_MAX : LH_MAX / 2;
     dim3 grid(ceil_div(W, LW), ceil_div(H, LH), C);
-    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(LT), 0, s, H, W, render, gt, win, sums, D);
+    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(LT), 0, s, LH, H, W, render, gt, win, sums, D);
     LAUNCH_CHECK();
     if (v_render) {
         const int Hi = H - 2 * HALO, Wi = W - 2 * HALO;
         const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
         const float k_l1 = (float)((double)w_l1 / ((double)H * W * 3));
         const float k_ss = cnt > 0 ? (float)(-(double)w_ssim / cnt) : 0.f;
-        hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(LT), 0, s, H, W, render, gt, D, win, k_l1, k_ss, v_render);
+        hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(LT), 0, s, LH, H, W, render, gt, D, win, k_l1, k_ss, v_render);
         LAUNCH_CHECK();
     }
     return ST3R_OK;
