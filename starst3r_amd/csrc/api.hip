@@ -169,18 +169,20 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals, int tight);
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base);
 int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
                               const int32_t* perm, int32_t* cum, int32_t** total_dev_out);
 int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
                                 const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h, int tight,
                                 uint32_t* tile_keys, int32_t* vals);
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
-                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals);
+                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base);
 int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
                               int32_t* offsets);
 int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint64_t* keys_in, int32_t* vals_in,
                          uint64_t* keys_out, int32_t* vals_out);
+int st3r_sort_depth32_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
+                           uint32_t* keys_out, int32_t* vals_out);
 int st3r_sort_tile_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
                         uint32_t* keys_out, int32_t* vals_out);
 int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
@@ -229,22 +231,40 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     // Two-level sort (see gs_isect.hip): pairs by (camera | depth) first, then the emitted records by
     // their 32-bit (camera, tile) key with a stable sort -- the same final order as gsplat's single
     // 64-bit (camera | tile | depth) sort at roughly a quarter of the sort traffic.
-    GET(SLOT_DKEYS_A, uint64_t, n_pairs, dkeys_a);
-    GET(SLOT_DKEYS_B, uint64_t, n_pairs, dkeys_b);
-    GET(SLOT_DVALS_A, int32_t, n_pairs, dvals_a);
-    GET(SLOT_DVALS_B, int32_t, n_pairs, perm);
+    // Level-1 keys.  Up to 8 local views: one 32-bit word, camera (3 bits) | depth bits minus those of the near plane
+    // (the reference's near = 0.01 and far = 1e10 span < 2^29 float codes) -- the same order as (camera | depth) at
+    // 8 instead of 12 bytes per pair and one radix pass less.  More views: 64-bit (camera << 32 | depth bits).
+    // rocPRIM sorts <= 2^20 items with a merge sort that is slower than its radix path: short inputs are padded
+    // with maximal keys (they stay behind everything, the sort being stable).
+    const float near_plane = 0.01f, far_plane = 1e10f;
+    uint32_t near_bits, far_bits;
+    memcpy(&near_bits, &near_plane, 4); memcpy(&far_bits, &far_plane, 4);
+    const bool key32 = (C <= 8) && (far_bits - near_bits < 0x1FFFFFFFu);
+    const int64_t n_sort = n_pairs <= (1 << 20) ? (1 << 20) + 1 : n_pairs;
+    GET(SLOT_DKEYS_A, uint64_t, n_sort, dkeys_a);
+    GET(SLOT_DKEYS_B, uint64_t, n_sort, dkeys_b);
+    GET(SLOT_DVALS_A, int32_t, n_sort, dvals_a);
+    GET(SLOT_DVALS_B, int32_t, n_sort, perm);
     GET(SLOT_CUM_D, int32_t, n_pairs, cum_d);
     st3r_prof_begin(ctx, s, STG_PROJECT);
+    const uint32_t key_base = key32 ? near_bits : 0u;
     int rc = records_in
-                 ? st3r_records_prepare_impl(s, N, C, splats, tile, tile_w, tile_h, tight, tiles, dkeys_a, dvals_a)
+                 ? st3r_records_prepare_impl(s, N, C, splats, tile, tile_w, tile_h, tight, tiles, dkeys_a, dvals_a,
+                                             key_base)
                  : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
-                                     W, H, tile, 0.3f, 0.01f, 1e10f, 0.0f, splats, tiles, reg_sums, dkeys_a, dvals_a,
-                                     tight);
+                                     W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, tiles, reg_sums, dkeys_a,
+                                     dvals_a, tight, key_base);
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
-    rc = st3r_sort_depth_impl(ctx, s, n_pairs, 32 + bit_length_u32((uint32_t)(C - 1)), dkeys_a, dvals_a, dkeys_b,
-                              perm);
+    if (n_sort > n_pairs) {
+        const size_t ksz = key32 ? 4 : 8;
+        HIP_TRY(hipMemsetAsync((char*)dkeys_a + ksz * (size_t)n_pairs, 0xFF, ksz * (size_t)(n_sort - n_pairs), s));
+    }
+    const int cam_bits = bit_length_u32((uint32_t)(C - 1));
+    rc = key32 ? st3r_sort_depth32_impl(ctx, s, n_sort, 29 + cam_bits, (uint32_t*)dkeys_a, dvals_a, (uint32_t*)dkeys_b,
+                                        perm)
+               : st3r_sort_depth_impl(ctx, s, n_sort, 32 + cam_bits, dkeys_a, dvals_a, dkeys_b, perm);
     st3r_prof_end(ctx, s, STG_SORT_DEPTH);
     if (rc) return rc;
     int64_t n_isects = 0;

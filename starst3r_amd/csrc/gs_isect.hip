@@ -327,7 +327,7 @@ int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* k
 __global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs, const float4* __restrict__ splats,
                                                          int tile_size, int tile_w, int tile_h, int tight,
                                                          int32_t* __restrict__ tiles, uint64_t* __restrict__ depth_keys,
-                                                         int32_t* __restrict__ depth_vals) {
+                                                         int32_t* __restrict__ depth_vals, uint32_t key_base) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= n_pairs) return;
     const float4 r2 = splats[pid * 3 + 2];
@@ -344,16 +344,20 @@ __global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs,
     }
     tiles[pid] = ntiles;
     const uint32_t dbits = radius > 0 ? (uint32_t)__float_as_int(r2.y) : 0xFFFFFFFFu;
-    depth_keys[pid] = ((uint64_t)(pid / N) << 32) | dbits;
+    if (key_base)   // same packed key as k_project_sh_fwd
+        reinterpret_cast<uint32_t*>(depth_keys)[pid] =
+            ((uint32_t)(pid / N) << 29) | (radius > 0 ? dbits - key_base : 0x1FFFFFFFu);
+    else
+        depth_keys[pid] = ((uint64_t)(pid / N) << 32) | dbits;
     depth_vals[pid] = (int32_t)pid;
 }
 
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
-                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals) {
+                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
     hipLaunchKernelGGL(k_records_prepare, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs,
-                       (const float4*)splats, tile_size, tile_w, tile_h, tight, tiles, depth_keys, depth_vals);
+                       (const float4*)splats, tile_size, tile_w, tile_h, tight, tiles, depth_keys, depth_vals, key_base);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

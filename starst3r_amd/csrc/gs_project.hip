@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
     const float* __restrict__ campos, int W, int H, int tile_size, int tile_w, int tile_h, float eps2d,
     float near_plane, float far_plane, float radius_clip, float4* __restrict__ splats,
     int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_part,
-    uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals, int tight) {
+    uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals, int tight, uint32_t key_base) {
     extern __shared__ float cam[];
     __shared__ float red[8];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         tiles_per_gauss[pid] = ntiles;
         if (depth_keys) {  // (camera | depth bits) key of the two-level sort; culled pairs sort last
             const uint32_t dbits = valid ? (uint32_t)__float_as_int(z) : 0xFFFFFFFFu;
-            depth_keys[pid] = ((uint64_t)c << 32) | dbits;
+            if (key_base)   // packed 32-bit key: camera (<= 8) | depth bits above those of the near plane (29 bits)
+                reinterpret_cast<uint32_t*>(depth_keys)[pid] = ((uint32_t)c << 29) | (valid ? dbits - key_base : 0x1FFFFFFFu);
+            else
+                depth_keys[pid] = ((uint64_t)c << 32) | dbits;
             depth_vals[pid] = (int32_t)pid;
         }
         n_vis += valid ? 1 : 0;
@@ -228,7 +231,7 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals, int tight) {
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base) {
     if (N == 0) return ST3R_OK;
     int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
     dim3 grid(ceil_div(N, 256)), block(256);
@@ -242,7 +245,7 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
     }
     hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
                        viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
-                       radius_clip, (float4*)splats, tiles_per_gauss, reg_part, depth_keys, depth_vals, tight);
+                       radius_clip, (float4*)splats, tiles_per_gauss, reg_part, depth_keys, depth_vals, tight, key_base);
     if (reg_sums) hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(256), 0, s, (int)grid.x, reg_part, reg_sums);
     LAUNCH_CHECK();
     return ST3R_OK;
@@ -258,5 +261,5 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
     return st3r_project_impl(ctx, (hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
                              campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,
-                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0);
+                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0, 0u);
 }

@@ -41,6 +41,21 @@ int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, u
     return ST3R_OK;
 }
 
+// packed 32-bit (camera | depth - near) keys of the level-1 sort (C <= 8)
+int st3r_sort_depth32_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
+                           uint32_t* keys_out, int32_t* vals_out) {
+    if (n == 0) return ST3R_OK;
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                      (unsigned)end_bit, s));
+    void* tmp;
+    int rc = st3r_arena_get(ctx, SLOT_SORT_TMP, tmp_bytes, &tmp);
+    if (rc) return rc;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit,
+                                      s));
+    return ST3R_OK;
+}
+
 // 32-bit (camera, tile) keys, stable: keeps the depth order established by the first level
 int st3r_sort_tile_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
                         uint32_t* keys_out, int32_t* vals_out) {
