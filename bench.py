@@ -198,6 +198,7 @@ def matching_bench(device, with_cpu=True):
     for _ in range(5):
         i1, _ = matching.fast_reciprocal_NNs(A3, B3, 8, ret_xy=False, device=device)
     torch.cuda.synchronize()
+    recip_ms = (time.perf_counter() - t0) / 5 * 1e3
     cpu = None
     if with_cpu:   # the numpy restatement (oracle/nn_oracle.py: blocked fp32 matmul + arg-max) on the host cores
         from oracle import nn_oracle
@@ -211,7 +212,7 @@ def matching_bench(device, with_cpu=True):
     return {"query": f"{n} seeds x {H * W} descriptors, D={D}", "query_ms": ms, "cpu_baseline": cpu,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": tflops / 157.3,
                          "note": "fp32 v_mfma_f32_32x32x2_f32; flops = 2*n*m*D, score matrix never written"},
-            "fast_reciprocal_NNs_ms": (time.perf_counter() - t0) / 5 * 1e3, "matches": int(i1.numel()),
+            "fast_reciprocal_NNs_ms": recip_ms, "matches": int(i1.numel()),
             "loop": "device resident (st3r_recip_nn), 10 reciprocal iterations, no host sync"}
 
 
