@@ -169,14 +169,16 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base);
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, uint64_t* rects);
 int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
-                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out);
-int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
-                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h, int tight,
-                                uint32_t* tile_keys, int32_t* vals);
+                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out, const uint64_t* rects,
+                              uint64_t* rects_sorted);
+int st3r_isect_emit_rects_impl(hipStream_t s, int N, int C, const int32_t* perm, const int32_t* cum_sorted,
+                               const uint64_t* rects_sorted, int tile_w, int tile_h, uint32_t* tile_keys,
+                               int32_t* vals);
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
-                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base);
+                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base,
+                              uint64_t* rects);
 int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
                               int32_t* offsets);
 int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint64_t* keys_in, int32_t* vals_in,
@@ -246,14 +248,16 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_DVALS_A, int32_t, n_sort, dvals_a);
     GET(SLOT_DVALS_B, int32_t, n_sort, perm);
     GET(SLOT_CUM_D, int32_t, n_pairs, cum_d);
+    GET(SLOT_RECTS, uint64_t, n_pairs, rects);       // packed tile rectangle of every pair (pair-id order)
+    GET(SLOT_RECTS_D, uint64_t, n_pairs, rects_d);   // the same in depth order, written by the depth-order scan
     st3r_prof_begin(ctx, s, STG_PROJECT);
     const uint32_t key_base = key32 ? near_bits : 0u;
     int rc = records_in
                  ? st3r_records_prepare_impl(s, N, C, splats, tile, tile_w, tile_h, tight, tiles, dkeys_a, dvals_a,
-                                             key_base)
+                                             key_base, rects)
                  : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
                                      W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, tiles, reg_sums, dkeys_a,
-                                     dvals_a, tight, key_base);
+                                     dvals_a, tight, key_base, rects);
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
@@ -274,7 +278,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     if (rc) return rc;
     // depth order scan: write positions of the emit kernel
     int32_t* total_dev = nullptr;
-    rc = st3r_isect_scan_perm_impl(ctx, s, n_pairs, tiles, perm, cum_d, &total_dev);
+    rc = st3r_isect_scan_perm_impl(ctx, s, n_pairs, tiles, perm, cum_d, &total_dev, rects, rects_d);
     st3r_prof_end(ctx, s, STG_SCAN);
     if (rc) return rc;
     {   // read back the intersection count (and the visible-pair count) -- the one host sync per step
@@ -291,7 +295,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
     if (n_isects > 0) {
         st3r_prof_begin(ctx, s, STG_EMIT);
-        rc = st3r_isect_emit_sorted_impl(s, N, C, splats, perm, cum_d, tile, tile_w, tile_h, tight, tkeys_a, vals_a);
+        rc = st3r_isect_emit_rects_impl(s, N, C, perm, cum_d, rects_d, tile_w, tile_h, tkeys_a, vals_a);
         st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
         const int end_bit = bit_length_u32((uint32_t)((int64_t)C * tile_w * tile_h - 1));

@@ -66,6 +66,8 @@ enum ArenaSlot {
     SLOT_MCMC_SAMPLED,
     SLOT_MCMC_BINOMS,
     SLOT_REG_PART,
+    SLOT_RECTS,
+    SLOT_RECTS_D,
     SLOT_COUNT
 };
 

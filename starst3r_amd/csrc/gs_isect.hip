@@ -39,10 +39,14 @@ __device__ __forceinline__ int block_incl_scan(int v, int* total) {
 }
 
 // `perm` (optional): scan in[perm[idx]] instead of in[idx] (tile counts visited in depth order)
+// `rects` (optional, with perm): packed tile rectangles (x0 | y0 << 16 | w << 32 | h << 48) instead of counts; the
+// gathered rectangles are stored in depth order (rects_sorted) for the emit kernel, which then streams.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int32_t* __restrict__ in,
                                                               const int32_t* __restrict__ perm, int64_t n,
                                                               int32_t* __restrict__ block_sums,
-                                                              int32_t* __restrict__ gathered) {
+                                                              int32_t* __restrict__ gathered,
+                                                              const uint64_t* __restrict__ rects,
+                                                              uint64_t* __restrict__ rects_sorted) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
     int s = 0;
 #pragma unroll
@@ -50,7 +54,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int32_t* __r
         int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
         if (idx < n) {
             int v;
-            if (perm) { v = in[perm[idx]]; gathered[idx] = v; }  // the downsweep then reads contiguously
+            if (rects) {
+                const uint64_t r = rects[perm[idx]];
+                rects_sorted[idx] = r;
+                v = (int)((r >> 32) & 0xFFFF) * (int)(r >> 48);
+                gathered[idx] = v;
+            } else if (perm) { v = in[perm[idx]]; gathered[idx] = v; }  // the downsweep then reads contiguously
             else v = in[idx];
             s += v;
         }
@@ -102,14 +111,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, c
 
 // out = inclusive scan(in); the grand total is left in the SLOT_SCAN_TMP buffer at [nblocks]
 int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, const int32_t* perm, int32_t* out,
-                            int64_t n, int32_t** total_dev) {
+                            int64_t n, int32_t** total_dev, const uint64_t* rects = nullptr,
+                            uint64_t* rects_sorted = nullptr) {
     int nblocks = ceil_div(n, SCAN_TILE);
     void* tmp;
     int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, sizeof(int32_t) * (size_t)(nblocks + 4), &tmp);
     if (rc) return rc;
     int32_t* bs = (int32_t*)tmp;
     // with a permutation the gathered values are parked in `out` by the reduce pass and scanned in place
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, perm, n, bs, out);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, perm, n, bs, out, rects, rects_sorted);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_THREADS), 0, s, bs, nblocks, bs + nblocks);
     hipLaunchKernelGGL(k_scan_down, dim3(nblocks), dim3(SCAN_THREADS), 0, s, perm ? out : in,
                        (const int32_t*)nullptr, n, bs, out);
@@ -120,9 +130,10 @@ int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, con
 
 // inclusive scan of tiles[perm[.]] (perm may be NULL); optional synchronous read-back of the total
 int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
-                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out) {
+                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out, const uint64_t* rects,
+                              uint64_t* rects_sorted) {
     if (n_pairs == 0) return ST3R_OK;
-    return st3r_scan_inclusive_i32(ctx, s, tiles, perm, cum, n_pairs, total_dev_out);
+    return st3r_scan_inclusive_i32(ctx, s, tiles, perm, cum, n_pairs, total_dev_out, rects, rects_sorted);
 }
 
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
@@ -246,49 +257,6 @@ ST3R_EXPORT int st3r_gs_offsets(st3r_ctx* ctx, void* stream, int64_t n_isects, c
 // Ties (same camera, tile, depth bits) keep pair-id order in both schemes: step 1 is stable
 // on pair id, steps 2/3 preserve it.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_isect_emit_sorted(int N, int64_t n_pairs,
-                                                           const float4* __restrict__ splats,
-                                                           const int32_t* __restrict__ perm,
-                                                           const int32_t* __restrict__ cum_sorted, int tile_size,
-                                                           int tile_w, int tile_h, int tight,
-                                                           uint32_t* __restrict__ tile_keys,
-                                                           int32_t* __restrict__ vals) {
-    const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx >= n_pairs) return;
-    const int end = cum_sorted[sidx];
-    const int start = sidx == 0 ? 0 : cum_sorted[sidx - 1];
-    if (end == start) return;
-    const int64_t pid = perm[sidx];
-    const float4 r0 = splats[pid * 3 + 0];
-    const float4 r2 = splats[pid * 3 + 2];
-    const float radius = (float)__float_as_int(r2.z);
-    TileRect tr = ref_tile_rect(r0.x, r0.y, radius, tile_size, tile_w, tile_h);
-    if (tight) {
-        const float4 r1 = splats[pid * 3 + 1];
-        tr = tight_tile_rect(tr, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
-    }
-    const int x0 = tr.x0, y0 = tr.y0, x1 = tr.x1, y1 = tr.y1;
-    const uint32_t cam_base = (uint32_t)(pid / N) * (uint32_t)(tile_w * tile_h);
-    int cur = start;
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            tile_keys[cur] = cam_base + (uint32_t)(ty * tile_w + tx);
-            vals[cur] = (int32_t)pid;
-            ++cur;
-        }
-}
-
-int st3r_isect_emit_sorted_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* perm,
-                                const int32_t* cum_sorted, int tile_size, int tile_w, int tile_h, int tight,
-                                uint32_t* tile_keys, int32_t* vals) {
-    const int64_t n_pairs = (int64_t)N * C;
-    if (n_pairs == 0) return ST3R_OK;
-    hipLaunchKernelGGL(k_isect_emit_sorted, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs,
-                       (const float4*)splats, perm, cum_sorted, tile_size, tile_w, tile_h, tight, tile_keys, vals);
-    LAUNCH_CHECK();
-    return ST3R_OK;
-}
-
 // offsets[k] = first sorted position whose 32-bit (camera, tile) key is >= k
 __global__ __launch_bounds__(256) void k_isect_offsets32(int64_t n_isects, const uint32_t* __restrict__ keys,
                                                          int64_t total, int32_t* __restrict__ offsets) {
@@ -327,12 +295,14 @@ int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* k
 __global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs, const float4* __restrict__ splats,
                                                          int tile_size, int tile_w, int tile_h, int tight,
                                                          int32_t* __restrict__ tiles, uint64_t* __restrict__ depth_keys,
-                                                         int32_t* __restrict__ depth_vals, uint32_t key_base) {
+                                                         int32_t* __restrict__ depth_vals, uint32_t key_base,
+                                                         uint64_t* __restrict__ rects) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= n_pairs) return;
     const float4 r2 = splats[pid * 3 + 2];
     const int radius = __float_as_int(r2.z);
     int ntiles = 0;
+    uint64_t rect = 0;
     if (radius > 0) {
         const float4 r0 = splats[pid * 3 + 0];
         TileRect tr = ref_tile_rect(r0.x, r0.y, (float)radius, tile_size, tile_w, tile_h);
@@ -341,8 +311,10 @@ __global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs,
             tr = tight_tile_rect(tr, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
         }
         ntiles = (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
+        rect = pack_rect(tr);
     }
     tiles[pid] = ntiles;
+    if (rects) rects[pid] = rect;
     const uint32_t dbits = radius > 0 ? (uint32_t)__float_as_int(r2.y) : 0xFFFFFFFFu;
     if (key_base)   // same packed key as k_project_sh_fwd
         reinterpret_cast<uint32_t*>(depth_keys)[pid] =
@@ -353,11 +325,48 @@ __global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs,
 }
 
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
-                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base) {
+                              int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base,
+                              uint64_t* rects) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
     hipLaunchKernelGGL(k_records_prepare, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs,
-                       (const float4*)splats, tile_size, tile_w, tile_h, tight, tiles, depth_keys, depth_vals, key_base);
+                       (const float4*)splats, tile_size, tile_w, tile_h, tight, tiles, depth_keys, depth_vals, key_base,
+                       rects);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+// Emission from the depth-ordered packed rectangles (written by the depth-order scan): everything this kernel
+// reads is sequential -- no gather of 48-byte records, no floating point.
+__global__ __launch_bounds__(256) void k_isect_emit_rects(int N, int64_t n_pairs, const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ cum_sorted,
+                                                          const uint64_t* __restrict__ rects_sorted, int tile_w,
+                                                          int tile_h, uint32_t* __restrict__ tile_keys,
+                                                          int32_t* __restrict__ vals) {
+    const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= n_pairs) return;
+    const uint64_t r = rects_sorted[sidx];
+    const int w = (int)((r >> 32) & 0xFFFF), h = (int)(r >> 48);
+    if (w == 0 || h == 0) return;
+    const int x0 = (int)(r & 0xFFFF), y0 = (int)((r >> 16) & 0xFFFF);
+    const int32_t pid = perm[sidx];
+    int cur = sidx == 0 ? 0 : cum_sorted[sidx - 1];
+    const uint32_t cam_base = (uint32_t)(pid / N) * (uint32_t)(tile_w * tile_h);
+    for (int ty = y0; ty < y0 + h; ++ty)
+        for (int tx = x0; tx < x0 + w; ++tx) {
+            tile_keys[cur] = cam_base + (uint32_t)(ty * tile_w + tx);
+            vals[cur] = pid;
+            ++cur;
+        }
+}
+
+int st3r_isect_emit_rects_impl(hipStream_t s, int N, int C, const int32_t* perm, const int32_t* cum_sorted,
+                               const uint64_t* rects_sorted, int tile_w, int tile_h, uint32_t* tile_keys,
+                               int32_t* vals) {
+    const int64_t n_pairs = (int64_t)N * C;
+    if (n_pairs == 0) return ST3R_OK;
+    hipLaunchKernelGGL(k_isect_emit_rects, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs, perm, cum_sorted,
+                       rects_sorted, tile_w, tile_h, tile_keys, vals);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

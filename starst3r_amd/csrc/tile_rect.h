@@ -63,6 +63,13 @@ __device__ __forceinline__ TileRect tight_tile_rect(TileRect r, float x, float y
     return r;
 }
 
+// x0 | y0 << 16 | width << 32 | height << 48 (all < 65536 tiles); 0 for an empty rectangle
+__device__ __forceinline__ uint64_t pack_rect(TileRect r) {
+    const uint64_t w = (uint64_t)(r.x1 - r.x0), h = (uint64_t)(r.y1 - r.y0);
+    if (w == 0 || h == 0) return 0;
+    return (uint64_t)r.x0 | ((uint64_t)r.y0 << 16) | (w << 32) | (h << 48);
+}
+
 // ---- exact culling: does the ellipse {sigma(p - mean) <= tau} reach a square of pixel centres? ----
 // sigma(d) = (A dx^2 + C dy^2)/2 + B dx dy with the conic (A, B, C).  sigma is convex, so when the mean lies
 // outside the square its minimum over the square sits on one of the four edges; on an edge it is a 1-D quadratic
