@@ -33,6 +33,7 @@ SCENES = {
     "ragged": (1500, 2, 101, 75, 21, 0.01, 0.12),     # image not a multiple of the tile size
     "medium": (20000, 4, 320, 240, 5, 0.004, 0.03),
     "one": (1, 1, 48, 32, 1, 0.05, 0.06),
+    "many": (800, 9, 64, 48, 3, 0.01, 0.08),          # > 8 views: 64-bit level-1 keys, row-interleaved XCD map
 }
 
 
@@ -71,7 +72,7 @@ def test_projection_tiles_sort_offsets_bit_exact(ctx, name):
     assert meta["isect_ids"].size > 0
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one"])
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "many"])
 def test_fused_two_level_sort_matches_reference_order(ctx, name):
     """The fused render/train path sorts in two levels ((camera|depth) then a stable (camera,tile)
     pass); its sorted pair ids and tile offsets must equal the oracle's single 64-bit-key sort."""
@@ -230,7 +231,7 @@ def test_empty_and_culled(ctx):
     assert float(rgb.abs().max()) == 0.0 or meta["isect_ids"].size > 0
 
 
-@pytest.mark.parametrize("name", ["small", "medium"])
+@pytest.mark.parametrize("name", ["small", "medium", "many"])
 def test_fused_train_gradients_equal_stage_path(ctx, name):
     """The fused train step culls (record, tile) pairs whose alpha >= 1/255 box misses the tile and sorts in
     two levels; its gradients must equal the reference-exact stage path's (the dropped pairs fail the alpha
