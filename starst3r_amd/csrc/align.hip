@@ -124,8 +124,6 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 const Pt p1 = anchor_point(P, S.cam, a1), p2 = anchor_point(P, S.cam, a2);
                 const float ex = p1.pw[0] - p2.pw[0], ey = p1.pw[1] - p2.pw[1], ez = p1.pw[2] - p2.pw[2];
                 const float d = sqrtf(ex * ex + ey * ey + ez * ez);
-                const float off = 0.8717937f;  // (1/1.1)^(1/0.1) ... computed exactly below
-                (void)off;
                 float rho;
                 const float o11 = __powf(1.0f / 1.1f, 10.0f);
                 const float rp = rho_prime(d, 1.1f, o11, &rho);

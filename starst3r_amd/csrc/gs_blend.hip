@@ -257,11 +257,6 @@ ST3R_EXPORT int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width,
 // ------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
 // (a, b) -> a + b after exchanging halves: lanes 0-31 end up with sum_{l, l+32} a, lanes 32-63 with that of b.
 // Inline asm on purpose: with hipcc 7.2 the second element returned by
 // __builtin_amdgcn_permlane32_swap / permlane16_swap came back equal to the first (measured, see
@@ -292,16 +287,7 @@ __device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, 
         : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(z1));
     k0 = h0 + h1; k1 = h2 + h3; k2 = h4 + z1;
 }
-// every lane of a 16-lane row receives the row sum
-__device__ __forceinline__ float row_allsum(float v) {
-    v += dpp_f<0x128>(v);  // row_ror:8
-    v += dpp_f<0x124>(v);  // row_ror:4
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
-    return v;
-}
-
-// row_allsum of three registers, interleaved so that consecutive DPP reads of one register are three
+// 16-lane row sums (every lane of a row receives the row total) of three registers, interleaved so that consecutive DPP reads of one register are three
 // instructions apart (no wait states needed) and the adds stay fused with their DPP operand
 __device__ __forceinline__ void row_allsum3(float& a, float& b, float& c) {
     asm volatile(
@@ -319,12 +305,6 @@ __device__ __forceinline__ void row_allsum3(float& a, float& b, float& c) {
         "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
         "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
         : "+v"(a), "+v"(b), "+v"(c));
-}
-
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
 }
 
 #define ACC_STRIDE 12  // 9 partial sums + 3 pad words (rows 1..3 park their unused third register there)
