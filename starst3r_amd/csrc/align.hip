@@ -80,17 +80,28 @@ __device__ __forceinline__ Pt anchor_point(const AlignProblem& P, const float* _
     return r;
 }
 
-// push dL/d(pw) of an anchor point back to its camera's 17 accumulators (LDS)
+// One row contributes to at most two cameras: 17 numbers each (vR[9] vT[3] vf vcx vcy vA vB), collected in
+// registers and handed to the LDS accumulators once, outside all divergent control flow (flush_camera).
+struct CamGrad { int img; float g[17]; };
+
+__device__ __forceinline__ void cam_clear(CamGrad& c) {
+    c.img = -1;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) c.g[k] = 0.f;
+}
+
+// dL/d(pw) of an anchor point -> its camera's 17 numbers
 __device__ __forceinline__ void point_bwd(const AlignProblem& P, const float* __restrict__ cam, int a, const Pt& r,
-                                          const float vp[3], float* sacc) {
+                                          const float vp[3], CamGrad& out) {
     const float* c = cam + r.img * CAM_STRIDE;
-    float* g = sacc + r.img * ACC_STRIDE;
+    float* g = out.g;
+    out.img = r.img;
     const float f = c[12], bf = c[17];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) atomicAdd(&g[i * 3 + j], vp[i] * r.pc[j]);
-        atomicAdd(&g[9 + i], vp[i]);
+        for (int j = 0; j < 3; ++j) g[i * 3 + j] += vp[i] * r.pc[j];
+        g[9 + i] += vp[i];
     }
     const float vpc0 = c[0] * vp[0] + c[3] * vp[1] + c[6] * vp[2];
     const float vpc1 = c[1] * vp[0] + c[4] * vp[1] + c[7] * vp[2];
@@ -99,13 +110,37 @@ __device__ __forceinline__ void point_bwd(const AlignProblem& P, const float* __
     const float vz = vpc0 * r.dx + vpc1 * r.dy + vpc2;
     const float vdx = vpc0 * z, vdy = vpc1 * z;
     float vf = -(vdx * r.dx + vdy * r.dy) / f;
-    atomicAdd(&g[13], -vdx / f);
-    atomicAdd(&g[14], -vdy / f);
+    g[13] += -vdx / f;
+    g[14] += -vdy / f;
     const float vD = vz * r.offp;
-    atomicAdd(&g[15], vD);
-    atomicAdd(&g[16], vD * r.core);
+    g[15] += vD;
+    g[16] += vD * r.core;
     vf += vz * r.D * (-(P.anchor_off[a] - 1.0f) * bf / (f * f));
-    atomicAdd(&g[12], vf);
+    g[12] += vf;
+}
+
+// Rows arrive grouped by image pair, so a wave's 64 rows almost always feed the same camera: 64 lanes adding to the
+// same 17 LDS words serialise badly (it was ~2/3 of the kernel).  When the wave agrees on the camera the 17 numbers
+// are summed across the wave with shuffles and one lane adds them; otherwise every lane adds its own.
+__device__ __forceinline__ void flush_camera(const CamGrad& c, float* sacc) {
+    const uint64_t has = __ballot(c.img >= 0);
+    if (has == 0) return;
+    const int ref = __shfl(c.img, __builtin_ctzll(has));
+    const bool uniform = __ballot(c.img >= 0 && c.img != ref) == 0;
+    if (uniform) {
+        float* g = sacc + ref * ACC_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            float v = c.g[k];   // lanes without a contribution hold zeros
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if ((threadIdx.x & 63) == k) atomicAdd(&g[k], v);   // lane k owns word k: 17 distinct addresses
+        }
+    } else if (c.img >= 0) {
+        float* g = sacc + c.img * ACC_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) atomicAdd(&g[k], c.g[k]);
+    }
 }
 
 // stage: 1 = loss_3d rows + dust rows, 2 = loss_2d rows + dust rows
@@ -114,10 +149,12 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
     const int nacc = P.C * ACC_STRIDE + 1;
     for (int i = threadIdx.x; i < nacc; i += blockDim.x) sacc[i] = 0.f;
     __syncthreads();
+    CamGrad ca, cb;
+    cam_clear(ca); cam_clear(cb);
+    float lsum = 0.f;
     if (S.acc[P.C * ACC_STRIDE + 1] == 0.f) {  // not stopped by a NaN loss
         const int n_main = stage == 1 ? P.n_corr : P.n_c2d;
         const int row = blockIdx.x * blockDim.x + threadIdx.x;
-        float lsum = 0.f;
         if (row < n_main) {
             if (stage == 1) {
                 const int a1 = P.corr_a1[row], a2 = P.corr_a2[row];
@@ -132,8 +169,8 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 if (d > 1e-20f) {
                     const float k = w * rp / d;
                     const float v1[3] = {k * ex, k * ey, k * ez}, v2[3] = {-k * ex, -k * ey, -k * ez};
-                    point_bwd(P, S.cam, a1, p1, v1, sacc);
-                    point_bwd(P, S.cam, a2, p2, v2, sacc);
+                    point_bwd(P, S.cam, a1, p1, v1, ca);
+                    point_bwd(P, S.cam, a2, p2, v2, cb);
                 }
             } else {
                 const int a2 = P.c2d_a2[row], i1 = P.c2d_img1[row];
@@ -162,23 +199,24 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                     const float vu = uclip ? 0.f : -k * du, vv = vclip ? 0.f : -k * dv;
                     const float vrx = vu / zc, vry = vv / zc;
                     const float vrz = zclip ? 0.f : -(vu * rx + vv * ry) / (zc * zc);
-                    float* g = sacc + i1 * ACC_STRIDE;
-                    atomicAdd(&g[12], vrx * qx + vry * qy);
-                    atomicAdd(&g[13], vrx * qz);
-                    atomicAdd(&g[14], vry * qz);
+                    float* g = ca.g;
+                    ca.img = i1;
+                    g[12] += vrx * qx + vry * qy;
+                    g[13] += vrx * qz;
+                    g[14] += vry * qz;
                     const float vq0 = f * vrx, vq1 = f * vry, vq2 = cx * vrx + cy * vry + vrz;
                     // q = R1^T e : vR1[m][k] += e_m vq_k ; ve = R1 vq ; vT1 -= ve ; vp += ve
                     const float e[3] = {e0, e1, e2}, vq[3] = {vq0, vq1, vq2};
 #pragma unroll
                     for (int m = 0; m < 3; ++m)
 #pragma unroll
-                        for (int kk = 0; kk < 3; ++kk) atomicAdd(&g[m * 3 + kk], e[m] * vq[kk]);
+                        for (int kk = 0; kk < 3; ++kk) g[m * 3 + kk] += e[m] * vq[kk];
                     float ve[3];
 #pragma unroll
                     for (int m = 0; m < 3; ++m) ve[m] = c[m * 3] * vq0 + c[m * 3 + 1] * vq1 + c[m * 3 + 2] * vq2;
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) atomicAdd(&g[9 + m], -ve[m]);
-                    point_bwd(P, S.cam, a2, p2, ve, sacc);
+                    for (int m = 0; m < 3; ++m) g[9 + m] += -ve[m];
+                    point_bwd(P, S.cam, a2, p2, ve, cb);
                 }
             }
         } else if (row - n_main < P.n_dust) {
@@ -201,18 +239,27 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
             if (d > 1e-20f) {
                 const float k = w * rp / d;
                 const float v1[3] = {k * ex, k * ey, k * ez};
-                point_bwd(P, S.cam, a1, p1, v1, sacc);
-                float* g = sacc + i2 * ACC_STRIDE;
+                point_bwd(P, S.cam, a1, p1, v1, ca);
+                float* g = cb.g;
+                cb.img = i2;
                 const float tg[3] = {t0, t1, t2};
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
 #pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) atomicAdd(&g[m * 3 + kk], -v1[m] * tg[kk]);
-                    atomicAdd(&g[9 + m], -v1[m]);
+                    for (int kk = 0; kk < 3; ++kk) g[m * 3 + kk] += -v1[m] * tg[kk];
+                    g[9 + m] += -v1[m];
                 }
             }
         }
-        if (lsum != 0.f) atomicAdd(&sacc[P.C * ACC_STRIDE], lsum);
+    }
+    // converged again: wave-level hand-over to the LDS accumulators
+    flush_camera(ca, sacc);
+    flush_camera(cb, sacc);
+    {
+        float v = lsum;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&sacc[P.C * ACC_STRIDE], v);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nacc; i += blockDim.x)
