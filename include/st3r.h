@@ -51,6 +51,7 @@ extern "C" {
 #define ST3R_ERR_NOMEM (-4)
 
 #define ST3R_SPLAT_STRIDE 12
+#define ST3R_MAX_VIEWS 256    /* views per call (the camera table lives in LDS: 128 B per view) */
 #define ST3R_GRAD_PER_GAUSSIAN 23
 
 typedef struct st3r_ctx st3r_ctx;

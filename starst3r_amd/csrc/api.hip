@@ -286,6 +286,10 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
         if (reg_sums) HIP_TRY(hipMemcpyAsync(ctx->pinned + 1, reg_sums + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         n_isects = (int64_t)((int32_t*)ctx->pinned)[0];
+        if (n_isects < 0) {   // the tile counts are summed in int32
+            st3r_set_error("more than 2^31 tile intersections in one call: split the views over more calls / GPUs");
+            return ST3R_ERR_INVALID;
+        }
         o->n_visible = reg_sums ? (int64_t)((double*)ctx->pinned)[1] : -1;
         o->n_isects_ref = reg_sums ? (int64_t)((double*)ctx->pinned)[2] : n_isects;
     }
@@ -330,7 +334,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
                                       const float* campos, const float* gt_images, int width, int height,
                                       float ssim_fac, float opac_fac, float scale_fac, float* grads,
                                       float* loss_out, int64_t* stats_host) {
-    ARG_CHECK(ctx && N > 0 && C > 0 && width > 0 && height > 0 && sh_stride >= 12);
+    ARG_CHECK(ctx && N > 0 && C > 0 && C <= ST3R_MAX_VIEWS && width > 0 && height > 0 && sh_stride >= 12);
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && gt_images && grads && loss_out);
     hipStream_t s = (hipStream_t)stream;
     const int W = width, H = height;

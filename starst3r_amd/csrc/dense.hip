@@ -94,7 +94,7 @@ ST3R_EXPORT int st3r_dense_unproject(st3r_ctx* ctx, void* stream, int C, int G, 
 ST3R_EXPORT int st3r_dense_clean(st3r_ctx* ctx, void* stream, int C, int max_view_pixels, const int32_t* view_start,
                                  const int32_t* sizes_hw, const float* cam, const float* pts, const float* zcam,
                                  float tol, float bad_conf, float* conf) {
-    ARG_CHECK(ctx && C > 0 && C <= 1024 && max_view_pixels >= 0 && view_start && sizes_hw && cam);
+    ARG_CHECK(ctx && C > 0 && C <= 512 && max_view_pixels >= 0 && view_start && sizes_hw && cam);
     if (max_view_pixels == 0) return ST3R_OK;
     ARG_CHECK(pts && zcam && conf);
     const size_t shmem = sizeof(float) * CAM_STRIDE * (size_t)C;

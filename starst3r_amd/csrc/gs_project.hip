@@ -262,7 +262,7 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
                                    const float* campos, int width, int height, int tile_size, float eps2d,
                                    float near_plane, float far_plane, float radius_clip, float* splats,
                                    int32_t* tiles_per_gauss, double* reg_sums) {
-    ARG_CHECK(ctx && N >= 0 && C > 0 && C <= 1024 && sh_stride >= 12 && width > 0 && height > 0 && tile_size > 0);
+    ARG_CHECK(ctx && N >= 0 && C > 0 && C <= ST3R_MAX_VIEWS && sh_stride >= 12 && width > 0 && height > 0 && tile_size > 0);
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
     return st3r_project_impl(ctx, (hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
                              campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,

@@ -238,7 +238,7 @@ ST3R_EXPORT int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C
                                        const float* campos, int width, int height, float eps2d,
                                        const float* splats, const float* v_splats, float reg_views,
                                        float opac_fac, float scale_fac, float* grads) {
-    ARG_CHECK(ctx && N >= 0 && C > 0 && C <= 1024 && sh_stride >= 12);
+    ARG_CHECK(ctx && N >= 0 && C > 0 && C <= ST3R_MAX_VIEWS && sh_stride >= 12);
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && v_splats && grads);
     if (N == 0) return ST3R_OK;
     hipStream_t s = (hipStream_t)stream;
