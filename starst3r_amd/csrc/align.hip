@@ -285,14 +285,39 @@ struct UpdateArgs {
     int reset_moments; // first step of a stage: fresh optimiser (reconstruct.py:374)
 };
 
+// kinematic chain over the MST (reconstruct.py:233-238): Rt_b = Rt_a Rr_b, tt_b = Rt_a tr_b + tt_a, one thread.
+// Operands are pulled into registers before anything is stored: one LDS round trip per edge instead of one per
+// term (the compiler cannot reorder loads around stores of aliasing float arrays).
+__device__ __forceinline__ void chain_forward(int n_edges, const int* sedge, const float* sRr, const float* strans,
+                                              float* sRt, float* stt) {
+    for (int e = 0; e < n_edges; ++e) {
+        const int a = sedge[2 * e], b = sedge[2 * e + 1];
+        float Rta[9], Rrb[9], trb[3], tta[3];
+        for (int k = 0; k < 9; ++k) { Rta[k] = sRt[9 * a + k]; Rrb[k] = sRr[9 * b + k]; }
+        for (int k = 0; k < 3; ++k) { trb[k] = strans[3 * b + k]; tta[k] = stt[3 * a + k]; }
+        float Rtb[9], ttb[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c)
+                Rtb[3 * r + c] = Rta[3 * r] * Rrb[c] + Rta[3 * r + 1] * Rrb[3 + c] + Rta[3 * r + 2] * Rrb[6 + c];
+            ttb[r] = Rta[3 * r] * trb[0] + Rta[3 * r + 1] * trb[1] + Rta[3 * r + 2] * trb[2] + tta[r];
+        }
+        for (int k = 0; k < 9; ++k) sRt[9 * b + k] = Rtb[k];
+        for (int k = 0; k < 3; ++k) stt[3 * b + k] = ttb[k];
+    }
+}
+
 // single workgroup; thread i < C owns view i for the element-wise parts, thread 0 walks the chain
 __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState S, UpdateArgs U) {
     __shared__ float sRr[MAXC * 9], sRt[MAXC * 9], stt[MAXC * 3];        // relative / chained rotations, chained translation
     __shared__ float svRt[MAXC * 9], svtt[MAXC * 3];                      // their gradients
     __shared__ float ssize[MAXC];
+    __shared__ float strans[MAXC * 3];   // relative translations and the MST edges, staged once: the three serial chain
+    __shared__ int sedge[MAXC * 2];      // walks below are done by one thread and must not wait on global memory
     __shared__ float s_gs, s_vgs, s_min; __shared__ int s_argmin;
     const int i = threadIdx.x;
     const int C = P.C;
+    for (int k = i; k < 3 * C; k += blockDim.x) strans[k] = S.trans[k];
+    for (int k = i; k < 2 * P.n_edges; k += blockDim.x) sedge[k] = P.edges[k];
     float* flags = S.acc + C * ACC_STRIDE;
     if (U.do_backward && flags[1] != 0.f) return;  // stopped earlier by a NaN loss
     if (U.do_backward && i == 0) {
@@ -333,23 +358,15 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
             s_gs = 1.0f / mn; s_argmin = ties; s_vgs = 0.f; s_min = mn;
             // forward chain (rotations + translations)
             for (int k = 0; k < 9; ++k) sRt[9 * P.root + k] = sRr[9 * P.root + k];
-            for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = S.trans[3 * P.root + k];
-            for (int e = 0; e < P.n_edges; ++e) {
-                const int a = P.edges[2 * e], b = P.edges[2 * e + 1];
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c)
-                        sRt[9 * b + 3 * r + c] = sRt[9 * a + 3 * r] * sRr[9 * b + c] + sRt[9 * a + 3 * r + 1] * sRr[9 * b + 3 + c] +
-                                                 sRt[9 * a + 3 * r + 2] * sRr[9 * b + 6 + c];
-                    stt[3 * b + r] = sRt[9 * a + 3 * r] * S.trans[3 * b] + sRt[9 * a + 3 * r + 1] * S.trans[3 * b + 1] +
-                                     sRt[9 * a + 3 * r + 2] * S.trans[3 * b + 2] + stt[3 * a + r];
-                }
-            }
+            for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = strans[3 * P.root + k];
+            chain_forward(P.n_edges, sedge, sRr, strans, sRt, stt);
         }
         __syncthreads();
         const float gs = s_gs;
         float v_f = 0, v_ppx = 0, v_ppy = 0, v_s = 0, vgs_part = 0;
         if (i < C) {
-            const float* g = S.acc + i * ACC_STRIDE;
+            float g[17];
+            for (int k = 0; k < 17; ++k) g[k] = S.acc[i * ACC_STRIDE + k];
             const float* Rt = sRt + 9 * i;
             const float vT[3] = {g[9], g[10], g[11]};
             const float vA = g[15], vB = g[16];
@@ -377,21 +394,25 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
         if (i == 0) {
             // reverse chain
             for (int e = P.n_edges - 1; e >= 0; --e) {
-                const int a = P.edges[2 * e], b = P.edges[2 * e + 1];
+                const int a = sedge[2 * e], b = sedge[2 * e + 1];
+                // operands into registers first: one LDS round trip per edge instead of one per term (the compiler
+                // cannot reorder the loads around the stores of aliasing float arrays)
+                float Rta[9], Rrb[9], vRtb[9], vRta[9], vttb[3], trb[3], vtta[3];
+                for (int k = 0; k < 9; ++k) { Rta[k] = sRt[9 * a + k]; Rrb[k] = sRr[9 * b + k]; vRtb[k] = svRt[9 * b + k]; vRta[k] = svRt[9 * a + k]; }
+                for (int k = 0; k < 3; ++k) { vttb[k] = svtt[3 * b + k]; trb[k] = strans[3 * b + k]; vtta[k] = svtt[3 * a + k]; }
                 float vRr[9], vtr[3];
                 for (int r = 0; r < 3; ++r) {
                     for (int c = 0; c < 3; ++c) {
                         // Rt_b = Rt_a Rr_b : vRt_a += vRt_b Rr_b^T ; vRr_b = Rt_a^T vRt_b
-                        svRt[9 * a + 3 * r + c] += svRt[9 * b + 3 * r] * sRr[9 * b + 3 * c] + svRt[9 * b + 3 * r + 1] * sRr[9 * b + 3 * c + 1] +
-                                                   svRt[9 * b + 3 * r + 2] * sRr[9 * b + 3 * c + 2];
-                        vRr[3 * r + c] = sRt[9 * a + r] * svRt[9 * b + c] + sRt[9 * a + 3 + r] * svRt[9 * b + 3 + c] +
-                                         sRt[9 * a + 6 + r] * svRt[9 * b + 6 + c];
+                        vRta[3 * r + c] += vRtb[3 * r] * Rrb[3 * c] + vRtb[3 * r + 1] * Rrb[3 * c + 1] + vRtb[3 * r + 2] * Rrb[3 * c + 2];
+                        vRr[3 * r + c] = Rta[r] * vRtb[c] + Rta[3 + r] * vRtb[3 + c] + Rta[6 + r] * vRtb[6 + c];
                         // tt_b = Rt_a tr_b + tt_a : vRt_a += vtt_b (x) tr_b
-                        svRt[9 * a + 3 * r + c] += svtt[3 * b + r] * S.trans[3 * b + c];
+                        vRta[3 * r + c] += vttb[r] * trb[c];
                     }
-                    vtr[r] = sRt[9 * a + r] * svtt[3 * b] + sRt[9 * a + 3 + r] * svtt[3 * b + 1] + sRt[9 * a + 6 + r] * svtt[3 * b + 2];
+                    vtr[r] = Rta[r] * vttb[0] + Rta[3 + r] * vttb[1] + Rta[6 + r] * vttb[2];
                 }
-                for (int r = 0; r < 3; ++r) svtt[3 * a + r] += svtt[3 * b + r];
+                for (int k = 0; k < 9; ++k) svRt[9 * a + k] = vRta[k];
+                for (int r = 0; r < 3; ++r) svtt[3 * a + r] = vtta[r] + vttb[r];
                 // from here on svRt[b] / svtt[b] hold the gradients of the RELATIVE pose of view b
                 for (int k = 0; k < 9; ++k) svRt[9 * b + k] = vRr[k];
                 for (int k = 0; k < 3; ++k) svtt[3 * b + k] = vtr[k];
@@ -441,6 +462,7 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
             float* q = S.quats + 4 * i;
             const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
             q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+            for (int k = 0; k < 3; ++k) strans[3 * i + k] = S.trans[3 * i + k];   // own writes: visible to this thread
         }
         __syncthreads();
     }
@@ -458,17 +480,8 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
         for (int k = 1; k < C; ++k) mn = fminf(mn, ssize[k]);
         s_gs = 1.0f / mn;
         for (int k = 0; k < 9; ++k) sRt[9 * P.root + k] = sRr[9 * P.root + k];
-        for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = S.trans[3 * P.root + k];
-        for (int e = 0; e < P.n_edges; ++e) {
-            const int a = P.edges[2 * e], b = P.edges[2 * e + 1];
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c)
-                    sRt[9 * b + 3 * r + c] = sRt[9 * a + 3 * r] * sRr[9 * b + c] + sRt[9 * a + 3 * r + 1] * sRr[9 * b + 3 + c] +
-                                             sRt[9 * a + 3 * r + 2] * sRr[9 * b + 6 + c];
-                stt[3 * b + r] = sRt[9 * a + 3 * r] * S.trans[3 * b] + sRt[9 * a + 3 * r + 1] * S.trans[3 * b + 1] +
-                                 sRt[9 * a + 3 * r + 2] * S.trans[3 * b + 2] + stt[3 * a + r];
-            }
-        }
+        for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = strans[3 * P.root + k];
+        chain_forward(P.n_edges, sedge, sRr, strans, sRt, stt);
     }
     __syncthreads();
     if (i < C) {
