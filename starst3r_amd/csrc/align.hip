@@ -41,6 +41,7 @@ struct AlignProblem {
     int n_dust; const int32_t* dust_a1; const float* dust_tgt; const int32_t* dust_img2; const float* dust_w;
     int root; int n_edges; const int32_t* edges;  // [n_edges,2] in chain order
     const float* min_focals; const float* max_focals;
+    const float4* anchor_pack;  // [A,2] packed once per run: (u, v, core value, offset) | (img as int bits, 0, 0, 0)
 };
 
 struct AlignState {
@@ -60,24 +61,38 @@ __device__ __forceinline__ float rho_prime(float d, float gamma, float off, floa
 }
 
 // 3-D point of anchor a in world coordinates; also returns the pieces the backward pass needs
-struct Pt { float pw[3]; float pc[3]; float dx, dy, D, offp, core; int img; };
+struct Pt { float pw[3]; float pc[3]; float dx, dy, D, offp, core, off, inv_f; int img; };
 
 __device__ __forceinline__ Pt anchor_point(const AlignProblem& P, const float* __restrict__ cam, int a) {
     Pt r;
-    r.img = P.anchor_img[a];
+    // one dependent load level: everything constant about the anchor was packed up front (k_align_pack_anchors)
+    const float4 p0 = P.anchor_pack[2 * a], p1 = P.anchor_pack[2 * a + 1];
+    r.img = __float_as_int(p1.x);
     const float* c = cam + r.img * CAM_STRIDE;
     const float f = c[12], cx = c[13], cy = c[14], A = c[15], B = c[16], bf = c[17];
-    const float u = P.anchor_pix[2 * a], v = P.anchor_pix[2 * a + 1];
-    r.core = P.core[(int64_t)r.img * P.G + P.anchor_idx[a]];
+    const float u = p0.x, v = p0.y;
+    r.core = p0.z;
     r.D = A + B * r.core;
-    r.offp = 1.0f + (P.anchor_off[a] - 1.0f) * (bf / f);
+    r.off = p0.w;
+    r.inv_f = 1.0f / f;   // one division per point; the kernel runs one wave per SIMD, so instruction count is time
+    r.offp = 1.0f + (p0.w - 1.0f) * (bf * r.inv_f);
     const float z = r.D * r.offp;
-    r.dx = (u - cx) / f; r.dy = (v - cy) / f;
+    r.dx = (u - cx) * r.inv_f; r.dy = (v - cy) * r.inv_f;
     r.pc[0] = z * r.dx; r.pc[1] = z * r.dy; r.pc[2] = z;
     r.pw[0] = c[0] * r.pc[0] + c[1] * r.pc[1] + c[2] * r.pc[2] + c[9];
     r.pw[1] = c[3] * r.pc[0] + c[4] * r.pc[1] + c[5] * r.pc[2] + c[10];
     r.pw[2] = c[6] * r.pc[0] + c[7] * r.pc[1] + c[8] * r.pc[2] + c[11];
     return r;
+}
+
+__global__ void k_align_pack_anchors(int n, const float* __restrict__ pix, const int32_t* __restrict__ idx,
+                                     const float* __restrict__ off, const int32_t* __restrict__ img,
+                                     const float* __restrict__ core, int G, float4* __restrict__ pack) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const int im = img[a];
+    pack[2 * a] = make_float4(pix[2 * a], pix[2 * a + 1], core[(int64_t)im * G + idx[a]], off[a]);
+    pack[2 * a + 1] = make_float4(__int_as_float(im), 0.f, 0.f, 0.f);
 }
 
 // One row contributes to at most two cameras: 17 numbers each (vR[9] vT[3] vf vcx vcy vA vB), collected in
@@ -96,7 +111,7 @@ __device__ __forceinline__ void point_bwd(const AlignProblem& P, const float* __
     const float* c = cam + r.img * CAM_STRIDE;
     float* g = out.g;
     out.img = r.img;
-    const float f = c[12], bf = c[17];
+    const float bf = c[17];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -109,32 +124,46 @@ __device__ __forceinline__ void point_bwd(const AlignProblem& P, const float* __
     const float z = r.pc[2];
     const float vz = vpc0 * r.dx + vpc1 * r.dy + vpc2;
     const float vdx = vpc0 * z, vdy = vpc1 * z;
-    float vf = -(vdx * r.dx + vdy * r.dy) / f;
-    g[13] += -vdx / f;
-    g[14] += -vdy / f;
+    float vf = -(vdx * r.dx + vdy * r.dy) * r.inv_f;
+    g[13] += -vdx * r.inv_f;
+    g[14] += -vdy * r.inv_f;
     const float vD = vz * r.offp;
     g[15] += vD;
     g[16] += vD * r.core;
-    vf += vz * r.D * (-(P.anchor_off[a] - 1.0f) * bf / (f * f));
+    vf += vz * r.D * (-(r.off - 1.0f) * bf * (r.inv_f * r.inv_f));
     g[12] += vf;
 }
 
 // Rows arrive grouped by image pair, so a wave's 64 rows almost always feed the same camera: 64 lanes adding to the
 // same 17 LDS words serialise badly (it was ~2/3 of the kernel).  When the wave agrees on the camera the 17 numbers
 // are summed across the wave with shuffles and one lane adds them; otherwise every lane adds its own.
+// Sum over the 64 lanes with DPP only (four steps inside the 16-lane rows, then row_bcast:15 / row_bcast:31 chain
+// the rows): the total ends up in every lane of row 3 (lanes 48..63).  All lanes must be active.  __shfl_xor would
+// go through ds_bpermute -- an LDS round trip per step, ~60 ns each in this one-wave-per-SIMD kernel.
+__device__ __forceinline__ float wave_sum_row3(float v) {
+    asm volatile(
+        "s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ void flush_camera(const CamGrad& c, float* sacc) {
     const uint64_t has = __ballot(c.img >= 0);
     if (has == 0) return;
-    const int ref = __shfl(c.img, __builtin_ctzll(has));
+    const int ref = __builtin_amdgcn_readlane(c.img, __builtin_ctzll(has));
     const bool uniform = __ballot(c.img >= 0 && c.img != ref) == 0;
     if (uniform) {
         float* g = sacc + ref * ACC_STRIDE;
+        const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 17; ++k) {
-            float v = c.g[k];   // lanes without a contribution hold zeros
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-            if ((threadIdx.x & 63) == k) atomicAdd(&g[k], v);   // lane k owns word k: 17 distinct addresses
+            const float v = wave_sum_row3(c.g[k]);   // lanes without a contribution hold zeros
+            if (lane == 48 + (k & 15)) atomicAdd(&g[k], v);   // row 3 holds the totals: 17 distinct addresses
         }
     } else if (c.img >= 0) {
         float* g = sacc + c.img * ACC_STRIDE;
@@ -145,9 +174,11 @@ __device__ __forceinline__ void flush_camera(const CamGrad& c, float* sacc) {
 
 // stage: 1 = loss_3d rows + dust rows, 2 = loss_2d rows + dust rows
 __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState S, int stage, float dust_w) {
-    extern __shared__ float sacc[];  // [C*ACC_STRIDE + 1]
+    extern __shared__ float sacc[];  // [C*ACC_STRIDE + 1] accumulators, then the camera table [C*CAM_STRIDE]
     const int nacc = P.C * ACC_STRIDE + 1;
+    float* scam = sacc + nacc;
     for (int i = threadIdx.x; i < nacc; i += blockDim.x) sacc[i] = 0.f;
+    for (int i = threadIdx.x; i < P.C * CAM_STRIDE; i += blockDim.x) scam[i] = S.cam[i];   // overlaps the row index loads
     __syncthreads();
     CamGrad ca, cb;
     cam_clear(ca); cam_clear(cb);
@@ -158,7 +189,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
         if (row < n_main) {
             if (stage == 1) {
                 const int a1 = P.corr_a1[row], a2 = P.corr_a2[row];
-                const Pt p1 = anchor_point(P, S.cam, a1), p2 = anchor_point(P, S.cam, a2);
+                const Pt p1 = anchor_point(P, scam, a1), p2 = anchor_point(P, scam, a2);
                 const float ex = p1.pw[0] - p2.pw[0], ey = p1.pw[1] - p2.pw[1], ez = p1.pw[2] - p2.pw[2];
                 const float d = sqrtf(ex * ex + ey * ey + ez * ez);
                 float rho;
@@ -169,13 +200,13 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 if (d > 1e-20f) {
                     const float k = w * rp / d;
                     const float v1[3] = {k * ex, k * ey, k * ez}, v2[3] = {-k * ex, -k * ey, -k * ez};
-                    point_bwd(P, S.cam, a1, p1, v1, ca);
-                    point_bwd(P, S.cam, a2, p2, v2, cb);
+                    point_bwd(P, scam, a1, p1, v1, ca);
+                    point_bwd(P, scam, a2, p2, v2, cb);
                 }
             } else {
                 const int a2 = P.c2d_a2[row], i1 = P.c2d_img1[row];
-                const Pt p2 = anchor_point(P, S.cam, a2);
-                const float* c = S.cam + i1 * CAM_STRIDE;
+                const Pt p2 = anchor_point(P, scam, a2);
+                const float* c = scam + i1 * CAM_STRIDE;
                 const float f = c[12], cx = c[13], cy = c[14];
                 const float e0 = p2.pw[0] - c[9], e1 = p2.pw[1] - c[10], e2 = p2.pw[2] - c[11];
                 const float qx = c[0] * e0 + c[3] * e1 + c[6] * e2;   // R1^T (p - T1)
@@ -184,7 +215,8 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 const float rx = f * qx + cx * qz, ry = f * qy + cy * qz, rz = qz;
                 const bool zclip = !(rz >= 1e-3f);
                 const float zc = zclip ? 1e-3f : rz;
-                float u = rx / zc, v = ry / zc;
+                const float inv_zc = 1.0f / zc;
+                float u = rx * inv_zc, v = ry * inv_zc;
                 const bool uclip = (u < -1000.f) || (u > 2000.f), vclip = (v < -1000.f) || (v > 2000.f);
                 u = fminf(fmaxf(u, -1000.f), 2000.f); v = fminf(fmaxf(v, -1000.f), 2000.f);
                 const float du = P.c2d_pix[2 * row] - u, dv = P.c2d_pix[2 * row + 1] - v;
@@ -197,8 +229,8 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 if (d > 1e-20f) {
                     const float k = w * rp / d;
                     const float vu = uclip ? 0.f : -k * du, vv = vclip ? 0.f : -k * dv;
-                    const float vrx = vu / zc, vry = vv / zc;
-                    const float vrz = zclip ? 0.f : -(vu * rx + vv * ry) / (zc * zc);
+                    const float vrx = vu * inv_zc, vry = vv * inv_zc;
+                    const float vrz = zclip ? 0.f : -(vu * rx + vv * ry) * (inv_zc * inv_zc);
                     float* g = ca.g;
                     ca.img = i1;
                     g[12] += vrx * qx + vry * qy;
@@ -216,15 +248,15 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                     for (int m = 0; m < 3; ++m) ve[m] = c[m * 3] * vq0 + c[m * 3 + 1] * vq1 + c[m * 3 + 2] * vq2;
 #pragma unroll
                     for (int m = 0; m < 3; ++m) g[9 + m] += -ve[m];
-                    point_bwd(P, S.cam, a2, p2, ve, cb);
+                    point_bwd(P, scam, a2, p2, ve, cb);
                 }
             }
         } else if (row - n_main < P.n_dust) {
             // DUSt3R regression fallback for pairs that failed the matching gate (reconstruct.py:311-323)
             const int r = row - n_main;
             const int a1 = P.dust_a1[r], i2 = P.dust_img2[r];
-            const Pt p1 = anchor_point(P, S.cam, a1);
-            const float* c = S.cam + i2 * CAM_STRIDE;
+            const Pt p1 = anchor_point(P, scam, a1);
+            const float* c = scam + i2 * CAM_STRIDE;
             const float t0 = P.dust_tgt[3 * r], t1 = P.dust_tgt[3 * r + 1], t2 = P.dust_tgt[3 * r + 2];
             const float gx = c[0] * t0 + c[1] * t1 + c[2] * t2 + c[9];
             const float gy = c[3] * t0 + c[4] * t1 + c[5] * t2 + c[10];
@@ -239,7 +271,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
             if (d > 1e-20f) {
                 const float k = w * rp / d;
                 const float v1[3] = {k * ex, k * ey, k * ez};
-                point_bwd(P, S.cam, a1, p1, v1, ca);
+                point_bwd(P, scam, a1, p1, v1, ca);
                 float* g = cb.g;
                 cb.img = i2;
                 const float tg[3] = {t0, t1, t2};
@@ -256,10 +288,8 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
     flush_camera(ca, sacc);
     flush_camera(cb, sacc);
     {
-        float v = lsum;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&sacc[P.C * ACC_STRIDE], v);
+        const float v = wave_sum_row3(lsum);
+        if ((threadIdx.x & 63) == 63 && v != 0.f) atomicAdd(&sacc[P.C * ACC_STRIDE], v);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nacc; i += blockDim.x)
@@ -542,7 +572,16 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
     S.m = work; S.v = work + 11 * C; S.cam = work + 22 * C; S.acc = S.cam + (int64_t)C * CAM_STRIDE;
     S.losses = losses_out;
     HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (size_t)need, s));
-    const size_t sh = sizeof(float) * ((size_t)C * ACC_STRIDE + 1);
+    const size_t sh = sizeof(float) * ((size_t)C * ACC_STRIDE + 1 + (size_t)C * CAM_STRIDE);
+    {   // constants of every anchor, packed once so that the residual kernel has a single dependent load level
+        void* pk;
+        int rc = st3r_arena_get(ctx, SLOT_NN_PART, sizeof(float4) * 2 * (size_t)(n_anchors > 0 ? n_anchors : 1), &pk);
+        if (rc) return rc;
+        P.anchor_pack = (const float4*)pk;
+        if (n_anchors > 0)
+            hipLaunchKernelGGL(k_align_pack_anchors, dim3(ceil_div(n_anchors, 256)), dim3(256), 0, s, n_anchors, anchor_pix,
+                               anchor_idx, anchor_off, anchor_img, core, G, (float4*)pk);
+    }
     UpdateArgs U0 = {0, 1, 0.f, 0, 0, 0};
     hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U0);
     // The reference returns K / cam2w / depthmaps / pts3d as computed at the START of the last iteration,
