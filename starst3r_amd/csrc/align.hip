@@ -315,24 +315,68 @@ struct UpdateArgs {
     int reset_moments; // first step of a stage: fresh optimiser (reconstruct.py:374)
 };
 
-// kinematic chain over the MST (reconstruct.py:233-238): Rt_b = Rt_a Rr_b, tt_b = Rt_a tr_b + tt_a, one thread.
-// Operands are pulled into registers before anything is stored: one LDS round trip per edge instead of one per
-// term (the compiler cannot reorder loads around stores of aliasing float arrays).
-__device__ __forceinline__ void chain_forward(int n_edges, const int* sedge, const float* sRr, const float* strans,
-                                              float* sRt, float* stt) {
+// The chain walks are sequential over the MST edges, but the 12 (forward) / 24 (reverse) numbers of one edge are
+// independent: the lanes of wave 0 compute one each, so an edge costs one LDS round trip instead of ~150 dependent
+// instructions of a single thread (this kernel is one workgroup: its time is its longest dependent chain).
+// LDS operations of one wave complete in order; the wave barrier only stops the compiler from reordering them.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// kinematic chain over the MST (reconstruct.py:233-238): Rt_b = Rt_a Rr_b, tt_b = Rt_a tr_b + tt_a.
+// Called by the 64 lanes of wave 0.
+__device__ __forceinline__ void chain_forward_wave(int lane, int root, int n_edges, const int* sedge, const float* sRr,
+                                                   const float* strans, float* sRt, float* stt) {
+    if (lane < 9) sRt[9 * root + lane] = sRr[9 * root + lane];
+    else if (lane < 12) stt[3 * root + lane - 9] = strans[3 * root + lane - 9];
+    wave_lds_sync();
     for (int e = 0; e < n_edges; ++e) {
         const int a = sedge[2 * e], b = sedge[2 * e + 1];
-        float Rta[9], Rrb[9], trb[3], tta[3];
-        for (int k = 0; k < 9; ++k) { Rta[k] = sRt[9 * a + k]; Rrb[k] = sRr[9 * b + k]; }
-        for (int k = 0; k < 3; ++k) { trb[k] = strans[3 * b + k]; tta[k] = stt[3 * a + k]; }
-        float Rtb[9], ttb[3];
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c)
-                Rtb[3 * r + c] = Rta[3 * r] * Rrb[c] + Rta[3 * r + 1] * Rrb[3 + c] + Rta[3 * r + 2] * Rrb[6 + c];
-            ttb[r] = Rta[3 * r] * trb[0] + Rta[3 * r + 1] * trb[1] + Rta[3 * r + 2] * trb[2] + tta[r];
+        float val = 0.f;
+        if (lane < 9) {
+            const int r = lane / 3, c = lane - 3 * r;
+            val = sRt[9 * a + 3 * r] * sRr[9 * b + c] + sRt[9 * a + 3 * r + 1] * sRr[9 * b + 3 + c] +
+                  sRt[9 * a + 3 * r + 2] * sRr[9 * b + 6 + c];
+        } else if (lane < 12) {
+            const int r = lane - 9;
+            val = sRt[9 * a + 3 * r] * strans[3 * b] + sRt[9 * a + 3 * r + 1] * strans[3 * b + 1] +
+                  sRt[9 * a + 3 * r + 2] * strans[3 * b + 2] + stt[3 * a + r];
         }
-        for (int k = 0; k < 9; ++k) sRt[9 * b + k] = Rtb[k];
-        for (int k = 0; k < 3; ++k) stt[3 * b + k] = ttb[k];
+        wave_lds_sync();
+        if (lane < 9) sRt[9 * b + lane] = val;
+        else if (lane < 12) stt[3 * b + lane - 9] = val;
+        wave_lds_sync();
+    }
+}
+
+// reverse walk: gradients of the chained poses -> gradients of the relative poses (in place in svRt / svtt)
+__device__ __forceinline__ void chain_reverse_wave(int lane, int n_edges, const int* sedge, const float* sRr,
+                                                   const float* strans, const float* sRt, float* svRt, float* svtt) {
+    for (int e = n_edges - 1; e >= 0; --e) {
+        const int a = sedge[2 * e], b = sedge[2 * e + 1];
+        float val = 0.f;
+        if (lane < 9) {            // Rt_b = Rt_a Rr_b : vRt_a += vRt_b Rr_b^T ; tt_b = Rt_a tr_b + tt_a : vRt_a += vtt_b (x) tr_b
+            const int r = lane / 3, c = lane - 3 * r;
+            val = svRt[9 * a + lane] + svRt[9 * b + 3 * r] * sRr[9 * b + 3 * c] + svRt[9 * b + 3 * r + 1] * sRr[9 * b + 3 * c + 1] +
+                  svRt[9 * b + 3 * r + 2] * sRr[9 * b + 3 * c + 2];
+            val += svtt[3 * b + r] * strans[3 * b + c];
+        } else if (lane < 18) {    // vRr_b = Rt_a^T vRt_b
+            const int k = lane - 9, r = k / 3, c = k - 3 * r;
+            val = sRt[9 * a + r] * svRt[9 * b + c] + sRt[9 * a + 3 + r] * svRt[9 * b + 3 + c] + sRt[9 * a + 6 + r] * svRt[9 * b + 6 + c];
+        } else if (lane < 21) {    // vtr_b = Rt_a^T vtt_b
+            const int r = lane - 18;
+            val = sRt[9 * a + r] * svtt[3 * b] + sRt[9 * a + 3 + r] * svtt[3 * b + 1] + sRt[9 * a + 6 + r] * svtt[3 * b + 2];
+        } else if (lane < 24) {    // vtt_a += vtt_b
+            const int r = lane - 21;
+            val = svtt[3 * a + r] + svtt[3 * b + r];
+        }
+        wave_lds_sync();           // every lane has read its inputs before anything is overwritten
+        if (lane < 9) svRt[9 * a + lane] = val;
+        else if (lane < 18) svRt[9 * b + lane - 9] = val;   // from here on svRt[b] / svtt[b] belong to the RELATIVE pose of b
+        else if (lane < 21) svtt[3 * b + lane - 18] = val;
+        else if (lane < 24) svtt[3 * a + lane - 21] = val;
+        wave_lds_sync();
     }
 }
 
@@ -386,11 +430,8 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
             int ties = 0;
             for (int k = 0; k < C; ++k) ties += (ssize[k] == mn) ? 1 : 0;
             s_gs = 1.0f / mn; s_argmin = ties; s_vgs = 0.f; s_min = mn;
-            // forward chain (rotations + translations)
-            for (int k = 0; k < 9; ++k) sRt[9 * P.root + k] = sRr[9 * P.root + k];
-            for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = strans[3 * P.root + k];
-            chain_forward(P.n_edges, sedge, sRr, strans, sRt, stt);
         }
+        if (i < 64) chain_forward_wave(i, P.root, P.n_edges, sedge, sRr, strans, sRt, stt);   // rotations + translations
         __syncthreads();
         const float gs = s_gs;
         float v_f = 0, v_ppx = 0, v_ppy = 0, v_s = 0, vgs_part = 0;
@@ -421,33 +462,7 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
             atomicAdd(&s_vgs, vgs_part);
         }
         __syncthreads();
-        if (i == 0) {
-            // reverse chain
-            for (int e = P.n_edges - 1; e >= 0; --e) {
-                const int a = sedge[2 * e], b = sedge[2 * e + 1];
-                // operands into registers first: one LDS round trip per edge instead of one per term (the compiler
-                // cannot reorder the loads around the stores of aliasing float arrays)
-                float Rta[9], Rrb[9], vRtb[9], vRta[9], vttb[3], trb[3], vtta[3];
-                for (int k = 0; k < 9; ++k) { Rta[k] = sRt[9 * a + k]; Rrb[k] = sRr[9 * b + k]; vRtb[k] = svRt[9 * b + k]; vRta[k] = svRt[9 * a + k]; }
-                for (int k = 0; k < 3; ++k) { vttb[k] = svtt[3 * b + k]; trb[k] = strans[3 * b + k]; vtta[k] = svtt[3 * a + k]; }
-                float vRr[9], vtr[3];
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c) {
-                        // Rt_b = Rt_a Rr_b : vRt_a += vRt_b Rr_b^T ; vRr_b = Rt_a^T vRt_b
-                        vRta[3 * r + c] += vRtb[3 * r] * Rrb[3 * c] + vRtb[3 * r + 1] * Rrb[3 * c + 1] + vRtb[3 * r + 2] * Rrb[3 * c + 2];
-                        vRr[3 * r + c] = Rta[r] * vRtb[c] + Rta[3 + r] * vRtb[3 + c] + Rta[6 + r] * vRtb[6 + c];
-                        // tt_b = Rt_a tr_b + tt_a : vRt_a += vtt_b (x) tr_b
-                        vRta[3 * r + c] += vttb[r] * trb[c];
-                    }
-                    vtr[r] = Rta[r] * vttb[0] + Rta[3 + r] * vttb[1] + Rta[6 + r] * vttb[2];
-                }
-                for (int k = 0; k < 9; ++k) svRt[9 * a + k] = vRta[k];
-                for (int r = 0; r < 3; ++r) svtt[3 * a + r] = vtta[r] + vttb[r];
-                // from here on svRt[b] / svtt[b] hold the gradients of the RELATIVE pose of view b
-                for (int k = 0; k < 9; ++k) svRt[9 * b + k] = vRr[k];
-                for (int k = 0; k < 3; ++k) svtt[3 * b + k] = vtr[k];
-            }
-        }
+        if (i < 64) chain_reverse_wave(i, P.n_edges, sedge, sRr, strans, sRt, svRt, svtt);
         __syncthreads();
         if (i < C) {
             if (s == s_min) v_s += s_vgs * (-gs * gs) / (float)s_argmin;  // gs = 1/min(s); s_argmin = tie count
@@ -509,10 +524,8 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
         float mn = ssize[0];
         for (int k = 1; k < C; ++k) mn = fminf(mn, ssize[k]);
         s_gs = 1.0f / mn;
-        for (int k = 0; k < 9; ++k) sRt[9 * P.root + k] = sRr[9 * P.root + k];
-        for (int k = 0; k < 3; ++k) stt[3 * P.root + k] = strans[3 * P.root + k];
-        chain_forward(P.n_edges, sedge, sRr, strans, sRt, stt);
     }
+    if (i < 64) chain_forward_wave(i, P.root, P.n_edges, sedge, sRr, strans, sRt, stt);
     __syncthreads();
     if (i < C) {
         const float gs = s_gs;
