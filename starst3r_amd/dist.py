@@ -91,7 +91,7 @@ def shard_views_contiguous(n_views, rank, world):
 
 def _all_to_all(recv, send):
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():   # also with a single rank: the same RCCL call path
         dist.all_to_all_single(recv, send)
     else:
         recv.copy_(send)

@@ -102,3 +102,37 @@ def test_sharded_equals_replicated(world, V):
         got = torch.cat([shards[r][k] for r in range(world)])
         d = (got - A[k]).abs()
         assert float(d.max()) <= 2.5e-3 and float((d > 1e-5).float().mean()) < 0.01, k
+
+
+def test_sharded_step_through_rccl_single_rank():
+    """The exchange as the multi-GPU run issues it -- torch.distributed.all_to_all_single on the nccl (= RCCL) backend
+    -- with the one rank a single-GPU box can host: same numbers as the copy-based exchange."""
+    import os
+    import torch.distributed as dist
+    from starst3r_amd import dist as sdist, ops
+    N, V, W, H = 4000, 2, 128, 96
+    g, w2c_np, Ks_np = synth.make_scene(N, V, W, H, seed=4, scale_lo=0.01, scale_hi=0.05)
+    P0 = {k: torch.from_numpy(g[k]).to(DEV) for k in ("means", "quats", "scales", "opacities", "shN")}
+    w2c = torch.from_numpy(w2c_np).to(DEV); Ks = torch.from_numpy(Ks_np).to(DEV)
+    ctx = ops.get_context(DEV)
+    gt = torch.rand((V, H, W, 3), device=DEV)
+
+    def run(a2a):
+        P = {k: v.clone() for k, v in P0.items()}
+        tr = sdist.ShardedTrainer(ctx, P, N, w2c, Ks, gt, W, H, 0, 1, a2a=a2a)
+        L = torch.zeros(3, device=DEV)
+        for t in range(3):
+            tr.step(L[t:t + 1])
+        torch.cuda.synchronize()
+        return P, L
+
+    ref_P, ref_L = run(lambda recv, send: recv.copy_(send))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        got_P, got_L = run(sdist._all_to_all)
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_allclose(got_L.cpu().numpy(), ref_L.cpu().numpy(), rtol=1e-6)
+    for k in ref_P:
+        assert float((got_P[k] - ref_P[k]).abs().max()) <= 2.5e-3 and float(((got_P[k] - ref_P[k]).abs() > 1e-5).float().mean()) < 0.01
