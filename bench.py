@@ -348,6 +348,10 @@ def main():
             out["cpu_baseline"] = None
         if world == 1:
             out["align"] = align_bench(device, with_cpu=not args.no_cpu_baseline)
+            # the synthetic condensed problems at 2 / 8 / 32 views (HIP seconds for 500+200 iterations)
+            out["align"]["hip_seconds_by_views"] = {str(c): align_bench(device, with_cpu=False, views=c)["hip_seconds"]
+                                                    for c in (2, 32)}
+            out["align"]["hip_seconds_by_views"]["8"] = out["align"]["hip_seconds"]
             out["matching"] = matching_bench(device, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
