@@ -225,9 +225,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # under torch.distributed.run the RCCL path is taken even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from starst3r_amd import ops, synth
@@ -354,7 +355,7 @@ def main():
             out["align"]["hip_seconds_by_views"]["8"] = out["align"]["hip_seconds"]
             out["matching"] = matching_bench(device, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
