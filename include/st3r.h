@@ -75,6 +75,10 @@ int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t byt
  * blend_bwd, project_bwd, adam, sort_depth (names from st3r_stage_name). */
 #define ST3R_NUM_STAGES 11
 int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
+/* test hook. bit 0: the blend forward walks every staged record in every wave (no per-quadrant relevance test):
+ * images must come out bit-identical, which is how the culling is validated at full size.
+ * st3r_ctx_peek(which = 8 / 9): rgb [C,H,W,3] / alpha [C,H,W] of the last st3r_gs_train_fwd_bwd call. */
+int st3r_ctx_set_debug(st3r_ctx* ctx, int flags);
 int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* counts_out);
 const char* st3r_stage_name(int stage);
 

@@ -87,9 +87,10 @@ int st3r_arena_get2(st3r_ctx* ctx, int slot, size_t bytes, void** out, int* grow
 // which: 0 = sorted pair ids ("flatten ids", int32 [n_isects]), 1 = tile offsets (int32 [C*tiles]),
 //        2 = splat records (float [C*N*12]), 3 = inclusive tile scan in pair-id order (int32 [C*N])
 ST3R_EXPORT int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t bytes) {
-    ARG_CHECK(ctx && dst && bytes >= 0 && which >= 0 && which <= 7);
-    static const int slots[8] = {SLOT_VALS_B, SLOT_OFFSETS, SLOT_SPLATS, SLOT_CUM,
-                                 SLOT_MCMC_CUM, SLOT_MCMC_DEAD, SLOT_MCMC_SAMPLED, SLOT_MCMC_COUNT};
+    ARG_CHECK(ctx && dst && bytes >= 0 && which >= 0 && which <= 9);
+    static const int slots[10] = {SLOT_VALS_B, SLOT_OFFSETS, SLOT_SPLATS, SLOT_CUM,
+                                  SLOT_MCMC_CUM, SLOT_MCMC_DEAD, SLOT_MCMC_SAMPLED, SLOT_MCMC_COUNT,
+                                  SLOT_RGB, SLOT_ALPHA};
     ARG_CHECK((size_t)bytes <= ctx->slot_bytes[slots[which]]);
     HIP_TRY(hipMemcpyAsync(dst, ctx->slot_ptr[slots[which]], (size_t)bytes, hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
@@ -131,6 +132,12 @@ void st3r_prof_next_step(st3r_ctx* ctx) {
     if (!ctx->prof_enabled) return;
     ctx->prof_slot = (ctx->prof_slot + 1) % PROF_RING;
     prof_harvest_slot(ctx, ctx->prof_slot);  // events from PROF_RING steps ago: long finished
+}
+
+ST3R_EXPORT int st3r_ctx_set_debug(st3r_ctx* ctx, int flags) {
+    ARG_CHECK(ctx);
+    ctx->debug_flags = flags;
+    return ST3R_OK;
 }
 
 ST3R_EXPORT int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable) {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                                                    float* __restrict__ out_rgb, float* __restrict__ out_alpha,
                                                    int32_t* __restrict__ last_ids,
                                                    uint64_t* __restrict__ cmask, int64_t cmask_words,
-                                                   int32_t* __restrict__ tile_nb) {
+                                                   int32_t* __restrict__ tile_nb, int no_cull) {
     __shared__ float4 sA[BLK];  // x y opacity qa
     __shared__ float4 sB[BLK];  // qb qc r g
     __shared__ float sC[BLK];   // b
@@ -150,7 +150,10 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
         if (__syncthreads_and(live == 0.0f)) break;
         const int idx = bs + threadIdx.x;
         int rel = 0;
-        if (idx < g.end) rel = stage_record(splats, flat[idx], threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
+        if (idx < g.end) {
+            rel = stage_record(splats, flat[idx], threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
+            if (no_cull) rel = 0xF;   // test hook: every staged record is walked by every wave
+        }
         const uint64_t m0 = __ballot(rel & 1), m1 = __ballot(rel & 2), m2 = __ballot(rel & 4), m3 = __ballot(rel & 8);
         if (lane == 0) { sMask[0][w] = m0; sMask[1][w] = m1; sMask[2][w] = m2; sMask[3][w] = m3; }
 #ifdef ST3R_STATS
@@ -237,7 +240,7 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_blend_fwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, (int)n_isects, rgb, alpha, last_ids, cmask, words, tile_nb);
+                       offsets, flat, (int)n_isects, rgb, alpha, last_ids, cmask, words, tile_nb, ctx->debug_flags & 1);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

@@ -279,6 +279,11 @@ def peek(ctx, which, count, dtype=torch.int32):
     return out
 
 
+def set_debug(ctx, flags):
+    """bit 0: blend forward without the per-quadrant relevance test (tests only)."""
+    _lib.check(_lib.lib().st3r_ctx_set_debug(ctx.handle, int(flags)))
+
+
 def set_profiling(ctx, enable):
     _lib.check(_lib.lib().st3r_ctx_set_profiling(ctx.handle, 1 if enable else 0))
 

@@ -109,6 +109,27 @@ def test_blend_properties_and_render_equals_fused_image(S):
     assert torch.equal(r2, rgb) and torch.equal(a2, alpha)
 
 
+def test_culling_changes_nothing_at_full_size(S):
+    """Both culling levels only drop work whose alpha is below 1/255 everywhere, so the images must be bit-identical:
+    (a) per-quadrant relevance test off vs on (st3r_ctx_set_debug), (b) the fused path's exact tile culling vs the
+    reference rectangles of the staged path."""
+    from starst3r_amd import ops
+    ctx = S["ctx"]
+    ops.set_debug(ctx, 1)
+    try:
+        r_all, a_all, _ = ops.render(ctx, S["P"], S["w2c"], S["Ks"], S["campos"], W, H)
+    finally:
+        ops.set_debug(ctx, 0)
+    assert torch.equal(r_all, S["rgb"]) and torch.equal(a_all, S["alpha"])
+    gt = torch.zeros((V, H, W, 3), device=DEV)
+    grads = torch.empty(23 * N, device=DEV); loss = torch.zeros(1, device=DEV)
+    st = ops.train_fwd_bwd(ctx, S["P"], S["w2c"], S["Ks"], S["campos"], gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+    assert st["n_isects"] < st["n_isects_ref"]
+    fused_rgb = ops.peek(ctx, 8, V * H * W * 3, torch.float32).reshape(V, H, W, 3)
+    fused_alpha = ops.peek(ctx, 9, V * H * W, torch.float32).reshape(V, H, W, 1)
+    assert torch.equal(fused_rgb, S["rgb"]) and torch.equal(fused_alpha, S["alpha"])
+
+
 def test_backward_is_linear_in_v_rgb(S):
     from starst3r_amd import ops
     ctx, info = S["ctx"], S["info"]
