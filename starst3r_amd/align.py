@@ -52,10 +52,20 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
     if prev_params is not None:
         for k in PARAM_KEYS:
             prev = prev_params[k]
+            if isinstance(prev, (list, tuple)):   # the reference's format: a list of per-view nn.Parameters
+                prev = torch.stack([torch.as_tensor(x).detach().reshape(-1) for x in prev])
             prev = prev.detach() if torch.is_tensor(prev) else torch.as_tensor(np.asarray(prev))
             prev = prev.to(dev, torch.float32)
             n = min(prev.shape[0], Cn)
             P[k][:n] = prev[:n].reshape(P[k][:n].shape)
+        if prev_params.get("core_depth") is not None:   # reconstruct.py:414: the old views keep their core depth
+            prev = prev_params["core_depth"]
+            if isinstance(prev, (list, tuple)):
+                prev = torch.stack([torch.as_tensor(x).reshape(-1) for x in prev])
+            prev = (prev.detach() if torch.is_tensor(prev) else torch.as_tensor(np.asarray(prev))).to(dev, torch.float32)
+            n = min(prev.shape[0], Cn)
+            if prev.shape[1] == core.shape[1]:
+                core[:n] = prev[:n]
     work = torch.zeros(66 * Cn + 8, device=dev)
     cam = torch.empty(Cn, 24, device=dev)
     A = anchor_idx.numel()

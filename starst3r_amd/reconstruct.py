@@ -19,7 +19,8 @@ returning the condensed problem in starst3r_amd.synth_align.flatten() layout plu
                pixels as anchors of the view's core depthmap (dense unprojection).
 starst3r_amd.synth_model.SyntheticPairwiseModel implements it on synthetic scenes (BASELINE configs[0]).
 """
-__all__ = ("reconstruct_scene", "reconstruct")
+__all__ = ("reconstruct_scene", "reconstruct", "run_sparse_ga", "sparse_scene_optimizer_slam",
+           "flatten_reference_inputs")
 
 import tempfile
 
@@ -71,26 +72,159 @@ class SparseGAResult:
         return [pts[s_] for s_ in sl], list(self.depthmaps), [conf[s_].cpu() for s_ in sl]
 
 
-def run_sparse_ga(condensed, device="cuda", optim_params=None, lr1=0.07, niter1=500, lr2=0.014, niter2=200, **kw):
-    """Global alignment of an already condensed problem (reference run_sparse_ga, reconstruct.py:75-113, from
-    the condense_data output onwards) with the reference's schedule (reconstruct.py:61-69)."""
-    res, params = align.run(condensed, lr1=lr1, niter1=niter1, lr2=lr2, niter2=niter2, prev_params=optim_params,
-                            device=device)
-    return SparseGAResult(condensed.get("imgs"), res, condensed.get("dense")), params
+def flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21, mst,
+                             matching_conf_thr=5.0):
+    """The set-up block of the reference optimiser (starster/reconstruct.py:148-207, 263-309) restated as array
+    plumbing: takes the SAME objects `sparse_scene_optimizer_slam` receives from Mast3r's condense_data and returns
+    the flat layout the C ABI consumes (starst3r_amd.synth_align.flatten documents it).
+
+      anchors   {img index: (pixels [n,2], idxs [n], offsets [n])}
+      corres    (_, _, imgs_slices) with .img1 .slice1 .img2 .slice2 .confs per ORDERED pair
+      corres2d  [(img1, pix1 [m,2], confs [m], confsum, [(img2, slice2), ...]), ...]
+      preds_21  {name of img2: {name of img1: (pts [k,3] in cam2, conf [k])}}  (regression fallback)
+      mst       (root, [(i, j), ...])
+
+    A pair passes the matching gate when `confs.max() > matching_conf_thr` (:283); its rows feed loss_3d / loss_2d
+    (:325-369), the others the DUSt3R regression (:311-323)."""
+    def npy(x, dt):
+        x = x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+        return np.ascontiguousarray(x).astype(dt)
+
+    C = len(imgs)
+    counts = [len(anchors[v][1]) for v in range(C)]
+    anchor_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rng = lambda sl, n: np.arange(n)[sl]
+    out = dict(n_views=np.int64(C), imsizes=npy(imsizes, np.int64), pps=npy(torch.stack(list(pps)) if isinstance(pps, (list, tuple)) else pps, np.float32),
+               base_focals=npy(torch.stack([torch.as_tensor(f).reshape(()) for f in base_focals]) if isinstance(base_focals, (list, tuple)) else base_focals, np.float32).reshape(-1),
+               core_depth=np.stack([npy(d, np.float32).reshape(-1) for d in core_depth]), anchor_off=anchor_off,
+               anchor_pix=np.concatenate([npy(anchors[v][0], np.float32) for v in range(C)]),
+               anchor_idx=np.concatenate([npy(anchors[v][1], np.int64) for v in range(C)]),
+               anchor_offset=np.concatenate([npy(anchors[v][2], np.float32) for v in range(C)]),
+               anchor_img=np.concatenate([np.full(counts[v], v, np.int32) for v in range(C)]),
+               mst_root=np.int64(mst[0]), mst_edges=np.array(mst[1], np.int64).reshape(-1, 2))
+    _, _, imgs_slices = corres
+    ok = {(s.img1, s.img2): bool(npy(s.confs, np.float32).max() > matching_conf_thr) for s in imgs_slices}
+    a1, a2, cf = [], [], []
+    d_a1, d_tgt, d_img2, d_conf = [], [], [], []
+    for s in imgs_slices:
+        if ok[s.img1, s.img2]:                                   # loss3d_slices (:290)
+            a1.append(anchor_off[s.img1] + rng(s.slice1, counts[s.img1]))
+            a2.append(anchor_off[s.img2] + rng(s.slice2, counts[s.img2]))
+            cf.append(npy(s.confs, np.float32))
+        else:                                                    # dust3r_slices (:289, 315-322)
+            tgt, tc = preds_21[imgs[s.img2]][imgs[s.img1]]
+            tc = npy(tc, np.float32)
+            d_a1.append(anchor_off[s.img1] + np.arange(len(tc))); d_tgt.append(npy(tgt, np.float32))
+            d_img2.append(np.full(len(tc), s.img2, np.int32)); d_conf.append(tc)
+    c_pix, c_a2, c_conf, c_img1 = [], [], [], []
+    for (img1, pix1, confs, _confsum, slices) in corres2d:      # cleaned_corres2d (:291-309)
+        pix1 = npy(pix1, np.float32); confs = npy(confs, np.float32)
+        cur = 0
+        for img2, slice2 in slices:
+            idx2 = rng(slice2, counts[img2])
+            n = len(idx2)
+            if ok[img1, img2]:
+                c_pix.append(pix1[cur:cur + n]); c_conf.append(confs[cur:cur + n]); c_a2.append(anchor_off[img2] + idx2)
+                c_img1.append(np.full(n, img1, np.int32))
+            cur += n
+    cat = lambda xs, dt, shape=(0,): np.concatenate(xs).astype(dt) if xs else np.zeros(shape, dt)
+    out.update(corr_a1=cat(a1, np.int64), corr_a2=cat(a2, np.int64), corr_conf=cat(cf, np.float32),
+               c2d_pix=cat(c_pix, np.float32, (0, 2)), c2d_a2=cat(c_a2, np.int64), c2d_conf=cat(c_conf, np.float32),
+               c2d_img1=cat(c_img1, np.int32), dust_a1=cat(d_a1, np.int64), dust_tgt=cat(d_tgt, np.float32, (0, 3)),
+               dust_img2=cat(d_img2, np.int32), dust_conf=cat(d_conf, np.float32))
+    return out
+
+
+def sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d,
+                                preds_21, canonical_paths, mst, cache_path=None, lr1=0.2, niter1=500, loss1=None,
+                                lr2=0.02, niter2=500, loss2=None, lossd=None, opt_pp=True, opt_depth=True,
+                                schedule=None, depth_mode="add", exp_depth=False, lora_depth=False,
+                                shared_intrinsics=False, init=None, device="cuda", dtype=torch.float32,
+                                matching_conf_thr=5.0, loss_dust3r_w=0.01, verbose=True, dbg=(), prev_params=None):
+    """Same signature and return value as the reference's optimiser (starster/reconstruct.py:116-457):
+    `(imgs, res_coarse, res_fine, params_ret)` with `res = dict(intrinsics, cam2w, depthmaps, pts3d)` and
+    `params_ret` the dict of per-view parameter lists a later call accepts as `prev_params`.  The optimisation
+    itself is st3r_align_run.  Implemented: the configuration the reference uses (:61-69, :118-126 defaults):
+    gamma losses 1.1 / 0.4 / 1.1, cosine schedule, opt_pp, depth_mode 'add', no shared intrinsics, no depth
+    optimisation; anything else raises.  The stage-1 result is not kept separately (the reference's only caller
+    takes `res_fine or res_coarse`, :113): `res_coarse` is `res_fine` when a second stage ran."""
+    if opt_depth or shared_intrinsics or exp_depth or lora_depth or depth_mode != "add" or not opt_pp or init:
+        raise NotImplementedError("only the reference's own configuration (opt_depth=False, shared_intrinsics=False, "
+                                  "depth_mode='add', opt_pp=True, no init) runs on the HIP path")
+    if loss1 is not None or loss2 is not None or lossd is not None or schedule is not None:
+        raise NotImplementedError("the robust losses (gamma 1.1 / 0.4 / 1.1) and the cosine schedule are built into the kernels")
+    flat = flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21,
+                                    mst, matching_conf_thr)
+    dev = "cuda:0" if str(device) == "cuda" else str(device)
+    res, params = align.run(flat, lr1=lr1, niter1=niter1, lr2=lr2, niter2=niter2, prev_params=prev_params,
+                            loss_dust3r_w=loss_dust3r_w, device=dev)
+    off = flat["anchor_off"]
+    C = len(imgs)
+    out = dict(intrinsics=res["intrinsics"], cam2w=res["cam2w"], depthmaps=[res["depthmaps"][v] for v in range(C)],
+               pts3d=[res["pts3d"][int(off[v]):int(off[v + 1])] for v in range(C)], losses=res["losses"], _res=res)
+    params_ret = {k: [params[k][v] for v in range(C)] for k in ("pps", "log_focals", "quats", "trans", "log_sizes",
+                                                                   "core_depth")}
+    return imgs, out, (out if niter2 else None), params_ret
+
+
+def run_sparse_ga(imgs, pairs_in=None, cache_path=None, model=None, subsample=8, desc_conf="desc_conf", device="cuda",
+                  dtype=torch.float32, shared_intrinsics=False, optim_params=None, **kw):
+    """Reference signature (starster/reconstruct.py:75-113): returns (scene, optim_params).
+
+    Two ways in:
+      * `imgs` is the condensed dict of the `model.condense()` protocol (module docstring): aligned directly;
+      * `imgs` is the reference's file list and `model` a Mast3r network: the pairwise inference, matching and
+        condensation are Mast3r's own functions (forward_mast3r, prepare_canonical_data, compute_min_spanning_tree,
+        condense_data), imported from the `mast3r` package when it is installed -- it is not vendored by the
+        reference (empty submodule) and cannot be fetched offline, so this branch is untested here."""
+    kw.setdefault("lr1", 0.07); kw.setdefault("niter1", 500); kw.setdefault("lr2", 0.014); kw.setdefault("niter2", 200)
+    if isinstance(imgs, dict):
+        condensed = imgs
+        res, params = align.run(condensed, lr1=kw["lr1"], niter1=kw["niter1"], lr2=kw["lr2"], niter2=kw["niter2"],
+                                prev_params=optim_params, device=device)
+        return SparseGAResult(condensed.get("imgs"), res, condensed.get("dense")), params
+    try:
+        from mast3r.cloud_opt.sparse_ga import (SparseGA, compute_min_spanning_tree, condense_data,
+                                                convert_dust3r_pairs_naming, forward_mast3r, prepare_canonical_data)
+    except ImportError as e:
+        raise ImportError("run_sparse_ga(filelist, pairs, cache, model) needs the `mast3r` package for the pairwise "
+                          "inference and condensation; without it pass a model that implements condense()") from e
+    pairs_in = convert_dust3r_pairs_naming(imgs, pairs_in)
+    pairs, cache_path = forward_mast3r(pairs_in, model, cache_path=cache_path, subsample=subsample, desc_conf=desc_conf,
+                                       device=device)
+    tmp_pairs, pairwise_scores, canonical_views, canonical_paths, preds_21 = prepare_canonical_data(
+        imgs, pairs, subsample, cache_path=cache_path, mode="avg-angle", device=device)
+    mst = compute_min_spanning_tree(pairwise_scores)
+    imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21 = condense_data(
+        imgs, tmp_pairs, canonical_views, preds_21, dtype)
+    kw.pop("opt_depth", None); kw.pop("matching_conf_thr", None)
+    imgs, res_coarse, res_fine, optim_params = sparse_scene_optimizer_slam(
+        imgs, subsample, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21, canonical_paths, mst,
+        shared_intrinsics=shared_intrinsics, cache_path=cache_path, device=device, dtype=dtype, opt_depth=False,
+        matching_conf_thr=5, prev_params=optim_params, **kw)
+    return SparseGA(imgs, pairs_in, res_fine or res_coarse, anchors, canonical_paths), optim_params
 
 
 def reconstruct_scene(model, imgs, filelist, device, optim_params=None, tmpdir=None):
     """Run the reconstruction pipeline: pairwise inference + matching (`model`), then global alignment.
 
-    Returns (scene, optim_params); pass optim_params back in to warm start after adding images."""
+    Returns (scene, optim_params); pass optim_params back in to warm start after adding images
+    (starster/reconstruct.py:19-72)."""
     if tmpdir is None:
         tmpdir = tempfile.mkdtemp()
-    if not hasattr(model, "condense"):
+    if hasattr(model, "condense"):
+        condensed = model.condense(imgs, filelist, device, tmpdir)
+        return run_sparse_ga(condensed, device=device, optim_params=optim_params)
+    # a Mast3r network: the reference's own call sequence (reconstruct.py:51-72), Mast3r's package doing its part
+    try:
+        from dust3r.image_pairs import make_pairs
+    except ImportError as e:
         raise NotImplementedError(
-            "reconstruct_scene needs a model that implements condense(imgs, filelist, device, cache_dir); the Mast3r "
-            "ViT front end (absent from the reference tree: empty submodule) is not bundled -- see the module docstring")
-    condensed = model.condense(imgs, filelist, device, tmpdir)
-    return run_sparse_ga(condensed, device=device, optim_params=optim_params)
+            "reconstruct_scene needs either a model that implements condense(imgs, filelist, device, cache_dir) or the "
+            "mast3r / dust3r packages for a Mast3r network (absent from the reference tree: empty submodule)") from e
+    from .image import prepare_images_for_mast3r
+    pairs = make_pairs(prepare_images_for_mast3r(imgs), scene_graph="complete", prefilter=None, symmetrize=True)
+    return run_sparse_ga(filelist, pairs, tmpdir, model, device=device, optim_params=optim_params)
 
 
 reconstruct = reconstruct_scene  # alias for the wording of BASELINE.json's north_star

@@ -163,3 +163,44 @@ def flatten(problem):
     out.update(dust_a1=cat(d_a1, np.int64), dust_tgt=cat(d_tgt, np.float32, (0, 3)), dust_img2=cat(d_img2, np.int32),
                dust_conf=cat(d_conf, np.float32))
     return out
+
+
+class Slice:
+    """One ordered image pair of the reference's `imgs_slices` (reconstruct.py:280-290): the correspondences of the
+    pair sit at anchors[img1][slice1] and anchors[img2][slice2]."""
+
+    def __init__(self, img1, slice1, img2, slice2, confs):
+        self.img1, self.slice1, self.img2, self.slice2, self.confs = img1, slice1, img2, slice2, confs
+
+
+def to_reference_inputs(P):
+    """Problem -> the argument objects of the reference's sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps,
+    base_focals, core_depth, anchors, corres, corres2d, preds_21, canonical_paths, mst, ...) as torch tensors
+    (the structure Mast3r's condense_data produces).  tools/gen_align_goldens.py feeds exactly
+    these objects to the reference's own function."""
+    import torch
+    C = P["n_views"]
+    imgs = [f"{i}.png" for i in range(C)]  # the reference feeds fake names (starster/scene.py:120)
+    t = torch.tensor
+    anchors = {v: (t(P["anchors"][v]["pixels"]), t(P["anchors"][v]["idxs"]), t(P["anchors"][v]["offsets"]))
+               for v in range(C)}
+    slices = []
+    c2d = {v: dict(pix=[], conf=[], sl=[]) for v in range(C)}
+    for (i, j, ai, aj, n, confs) in P["pairs"]:
+        cf = t(confs)
+        slices.append(Slice(i, slice(ai, ai + n), j, slice(aj, aj + n), cf))
+        slices.append(Slice(j, slice(aj, aj + n), i, slice(ai, ai + n), cf))
+        c2d[i]["pix"].append(anchors[i][0][ai:ai + n]); c2d[i]["conf"].append(cf); c2d[i]["sl"].append((j, slice(aj, aj + n)))
+        c2d[j]["pix"].append(anchors[j][0][aj:aj + n]); c2d[j]["conf"].append(cf); c2d[j]["sl"].append((i, slice(ai, ai + n)))
+    corres2d = []
+    for v in range(C):
+        pix = torch.cat(c2d[v]["pix"]); cf = torch.cat(c2d[v]["conf"])
+        corres2d.append((v, pix, cf, cf.sum(), c2d[v]["sl"]))
+    corres = (None, None, slices)
+    preds_21 = {}
+    for (i2, i1), (pts, cf) in P["preds_21"].items():
+        preds_21.setdefault(imgs[i2], {})[imgs[i1]] = (t(pts), t(cf))
+    core_depth = [t(P["core_depth"][v].copy()) for v in range(C)]
+    return dict(imgs=imgs, subsample=8, imsizes=t(P["imsizes"].copy()), pps=t(P["pps"].copy()),
+                base_focals=t(P["base_focals"].copy()), core_depth=core_depth, anchors=anchors, corres=corres,
+                corres2d=corres2d, preds_21=preds_21, canonical_paths=None, mst=P["mst"], cache_path=None)

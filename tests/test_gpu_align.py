@@ -120,3 +120,43 @@ def test_warm_start_splices_previous_params():
     np.testing.assert_allclose(par0["quats"][2], [0, 0, 0, 1], atol=1e-7)
     o_res, o_par = ao.run(f3, niter1=0, niter2=0, prev=p2)
     compare(res0, par0, o_res, o_par, 1e-5, "warm start forward")
+
+
+def test_reference_signature_optimiser_equals_flat_path_and_warm_starts():
+    """sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d,
+    preds_21, canonical_paths, mst, ...) -- the reference's call (reconstruct.py:108-110) with the objects
+    condense_data produces -- runs the same kernels on the same arrays as align.run(flatten(P)), returns the
+    reference's tuple, and accepts its own params_ret (lists of per-view tensors) as prev_params."""
+    import importlib
+    from starst3r_amd import synth_align as sa
+    rc = importlib.import_module("starst3r_amd.reconstruct")
+    P = sa.make_problem(n_views=4, n_corr=300, seed=5, bad_pair=True)
+    a = sa.to_reference_inputs(P)
+    imgs, coarse, fine, params = rc.sparse_scene_optimizer_slam(
+        a["imgs"], a["subsample"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"],
+        a["corres2d"], a["preds_21"], a["canonical_paths"], a["mst"], cache_path=None, lr1=0.07, niter1=20, lr2=0.014,
+        niter2=10, device="cuda", opt_depth=False, matching_conf_thr=5, shared_intrinsics=False)
+    res = fine or coarse
+    assert imgs == a["imgs"] and fine is not None
+    assert res["intrinsics"].shape == (4, 3, 3) and res["cam2w"].shape == (4, 4, 4)
+    assert len(res["depthmaps"]) == 4 and len(res["pts3d"]) == 4
+    assert [p.shape[0] for p in res["pts3d"]] == [len(P["anchors"][v]["idxs"]) for v in range(4)]
+    assert set(params) == {"pps", "log_focals", "quats", "trans", "log_sizes", "core_depth"}
+    assert all(len(params[k]) == 4 for k in params) and params["quats"][0].shape == (4,)
+    f_res, f_par = run_hip(sa.flatten(P), niter1=20, niter2=10)
+    n = lambda t: t.detach().cpu().numpy()
+    got_res = dict(intrinsics=n(res["intrinsics"]), cam2w=n(res["cam2w"]), depthmaps=np.stack([n(d) for d in res["depthmaps"]]),
+                   pts3d=np.concatenate([n(p) for p in res["pts3d"]]))
+    got_par = {k: np.stack([n(x).reshape(-1) for x in params[k]]) for k in ("pps", "log_focals", "quats", "trans", "log_sizes")}
+    compare(got_res, got_par, f_res, f_par, 1e-4, "reference signature vs flat")
+    # warm start: two more views, the first four keep parameters AND normalised core depth (reconstruct.py:408-415)
+    P6 = sa.make_problem(n_views=6, n_corr=300, seed=5)
+    a6 = sa.to_reference_inputs(P6)
+    _, c6, f6, p6 = rc.sparse_scene_optimizer_slam(
+        a6["imgs"], 8, a6["imsizes"], a6["pps"], a6["base_focals"], a6["core_depth"], a6["anchors"], a6["corres"],
+        a6["corres2d"], a6["preds_21"], None, a6["mst"], lr1=0.07, niter1=0, lr2=0.014, niter2=0, device="cuda",
+        opt_depth=False, prev_params=params)
+    for k in ("pps", "log_focals", "quats", "trans", "log_sizes", "core_depth"):
+        for v in range(4):
+            assert torch.equal(p6[k][v].reshape(-1).cpu(), params[k][v].reshape(-1).cpu()), (k, v)
+    assert not torch.equal(p6["core_depth"][4].cpu(), params["core_depth"][3].cpu())

@@ -1,0 +1,48 @@
+"""Host-side restatement of the reference optimiser's set-up block (starster/reconstruct.py:148-207, 263-309):
+the objects Mast3r's condense_data hands to sparse_scene_optimizer_slam -> the flat arrays of the C ABI.
+The reference-format objects are the ones tools/gen_align_goldens.py feeds to the reference's own function."""
+import importlib
+
+import numpy as np
+import pytest
+
+from starst3r_amd import synth_align as sa
+
+rc = importlib.import_module("starst3r_amd.reconstruct")
+
+
+@pytest.mark.parametrize("views,bad", [(2, False), (4, False), (4, True), (3, True)])
+def test_reference_structures_flatten_to_the_same_arrays(views, bad):
+    P = sa.make_problem(n_views=views, n_corr=150, seed=views, bad_pair=bad)
+    a = sa.to_reference_inputs(P)
+    got = rc.flatten_reference_inputs(a["imgs"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"],
+                                      a["corres"], a["corres2d"], a["preds_21"], a["mst"], matching_conf_thr=5)
+    want = sa.flatten(P)
+    assert set(got) == set(want)
+    for k in want:
+        x, y = np.asarray(got[k]), np.asarray(want[k])
+        assert x.shape == y.shape and np.array_equal(x, y), k
+    if bad:
+        assert got["dust_a1"].size > 0      # the pair that fails `confs.max() > 5` went to the regression fallback
+    else:
+        assert got["dust_a1"].size == 0
+
+
+def test_matching_gate_threshold_moves_pairs_between_losses():
+    P = sa.make_problem(n_views=3, n_corr=100, seed=1)
+    a = sa.to_reference_inputs(P)
+    # no preds_21 for good pairs: raising the gate above every confidence must fail loudly on the missing fallback data
+    with pytest.raises(KeyError):
+        rc.flatten_reference_inputs(a["imgs"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"],
+                                    a["corres"], a["corres2d"], a["preds_21"], a["mst"], matching_conf_thr=1e9)
+
+
+def test_unsupported_configurations_are_refused():
+    P = sa.make_problem(n_views=2, n_corr=50, seed=0)
+    a = sa.to_reference_inputs(P)
+    args = (a["imgs"], 8, a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"],
+            a["corres2d"], a["preds_21"], None, a["mst"])
+    with pytest.raises(NotImplementedError):
+        rc.sparse_scene_optimizer_slam(*args, opt_depth=True)
+    with pytest.raises(NotImplementedError):
+        rc.sparse_scene_optimizer_slam(*args, opt_depth=False, shared_intrinsics=True)
