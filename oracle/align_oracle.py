@@ -175,6 +175,11 @@ def optimize_loop(pb, p, trainable, stage, lr_base, niter, loss_dust3r_w=0.01, l
 def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev=None, dtype=torch.float32, losses=None):
     """-> (result dict, params dict) like the reference's (res_fine or res_coarse, params_ret)."""
     pb = Problem(flat, dtype)
+    if prev is not None and prev.get("core_depth") is not None:        # :414 -- the old views keep their core depth
+        pc = torch.as_tensor(np.asarray(prev["core_depth"]), dtype=dtype)
+        if pc.shape[1] == pb.core.shape[1]:
+            n = min(pc.shape[0], pb.core.shape[0])
+            pb.core = pb.core.clone(); pb.core[:n] = pc[:n]
     p = init_params(pb, prev)
     res = optimize_loop(pb, p, {"quats", "trans", "log_sizes"}, 1, lr1, niter1, losses=losses)      # :418-427
     if niter2:
