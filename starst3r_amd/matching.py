@@ -38,10 +38,13 @@ def merge_corres(idx1, idx2, shape1=None, shape2=None, ret_xy=True):
     return i1, i2
 
 
-def fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy=True, device="cuda", max_iter=10, **matcher_kw):
-    """pts1 [H1,W1,D], pts2 [H2,W2,D] float32 descriptors -> matched (xy1, xy2) or flat indices.
-    Only the reference's configuration is implemented: integer subsample, pixel_tol=0, dist='dot'."""
+def fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy=True, pixel_tol=0, ret_basin=False, device="cuda",
+                        max_iter=10, **matcher_kw):
+    """pts1 [H1,W1,D], pts2 [H2,W2,D] float32 descriptors -> matched (xy1, xy2) or flat indices (torch, on the device).
+    Only the reference's configuration is implemented: integer subsample, pixel_tol=0, ret_basin=False, dist='dot'."""
     assert matcher_kw.get("dist", "dot") == "dot", "only dist='dot' (the reference's choice) is implemented"
+    if pixel_tol != 0 or ret_basin or not isinstance(subsample_or_initxy1, (int, np.integer)):
+        raise NotImplementedError("fast_reciprocal_NNs: only integer subsample, pixel_tol=0, ret_basin=False run on the HIP path")
     ctx = ops.get_context(device)
     dev = ctx.device
     H1, W1, D1 = pts1.shape; H2, W2, D2 = pts2.shape
@@ -57,3 +60,26 @@ def fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy=True, device=
                                      ops._p(xy1, torch.int32), ops._p(xy2, torch.int32), ops._p(notyet, torch.int32)))
     converged = notyet == 0
     return merge_corres(xy1[converged], xy2[converged], (H1, W1), (H2, W2), ret_xy=ret_xy)
+
+
+def install_into_mast3r():
+    """Route Mast3r's own matching through the HIP kernels: replaces `fast_reciprocal_NNs` in `mast3r.fast_nn` and in
+    the modules that imported it by name, with a wrapper that returns numpy arrays like upstream.  For users who have
+    the `mast3r` package (the reference reaches it at starster/reconstruct.py:97); a no-op ImportError otherwise."""
+    import importlib
+    fast_nn = importlib.import_module("mast3r.fast_nn")
+
+    def patched(pts1, pts2, subsample_or_initxy1=8, ret_xy=True, pixel_tol=0, ret_basin=False, device="cuda", **kw):
+        a, b = fast_reciprocal_NNs(torch.as_tensor(pts1), torch.as_tensor(pts2), subsample_or_initxy1, ret_xy, pixel_tol,
+                                   ret_basin, device, **kw)
+        return a.cpu().numpy(), b.cpu().numpy()
+
+    fast_nn.fast_reciprocal_NNs = patched
+    for name in ("mast3r.cloud_opt.sparse_ga",):
+        try:
+            mod = importlib.import_module(name)
+            if hasattr(mod, "fast_reciprocal_NNs"):
+                mod.fast_reciprocal_NNs = patched
+        except ImportError:
+            pass
+    return patched
