@@ -3,14 +3,14 @@
 // starster/gs.py:153).
 //
 // Mapping.  One workgroup = one 16x16 tile = 4 wave64; wave w owns the 8x8 quadrant
-// (w&1, w>>1).  Workgroups are remapped so that each XCD (private 4 MiB L2) walks a
-// contiguous range of (camera, tile) ids: with 8 views on 8 XCDs every XCD owns one
-// camera's splat array.
+// (w&1, w>>1).  Workgroups are remapped so that each XCD (private 4 MiB L2) walks groups of
+// consecutive (camera, tile) ids: a whole camera per XCD when the views are a multiple of 8,
+// tile rows round-robin over the XCDs otherwise (see xcd_remap).
 //
 // Staging + wavefront compaction.  The tile's depth-sorted list is staged through LDS in
 // batches of 256 splat records (one record per thread, 3 x 16-byte loads).  The staging
-// thread also tests the record's exact influence box -- the bounding box of the ellipse
-// {alpha >= 1/255}, slightly inflated -- against the four quadrants; four wave ballots per
+// thread also tests the record's ellipse {alpha >= 1/255} (tau slightly inflated) exactly
+// against the four quadrants (tile_rect.h: ellipse_hits_square); four wave ballots per
 // 64 records give every wave a 256-bit "relevant" mask, and the wave then walks only the set
 // bits with scalar bit-scan instructions.  Records that cannot reach a quadrant cost that
 // wave nothing (in the reference they fail the alpha test on all 64 pixels).
@@ -23,9 +23,13 @@
 //
 // Backward reduction.  The 9 per-pixel partial gradients are summed over the wave's 64 pixels
 // with a halving butterfly: v_permlane32_swap and v_permlane16_swap pair registers so that each
-// step halves the live values (5 + 3 swap/add pairs), then 4 DPP row steps on 3 registers --
-// 28 instructions instead of 9 full 64-lane reductions.  The four waves' partial sums meet in
-// LDS (ds_add_f32), and one thread per record flushes them to HBM with float atomics.
+// step halves the live values (5 + 3 swap/add pairs), then 4 fused DPP row steps on 3 registers.
+// The four waves' partial sums meet in LDS (ds_add_f32 at lane-dependent addresses), and one
+// thread per record writes them to the record's stamped slot in HBM -- no global atomics;
+// k_gather_vtile sums the slots of a pair in order.
+//
+// Both kernels are VALU-issue bound: every instruction in the two inner
+// loops is there on purpose; the file is compiled without packed-fp32 code generation.
 //
 // Arithmetic note.  sigma is evaluated as P = dx*(qa*dx + qb*dy) + qc*dy*dy with
 // (qa,qb,qc) = -log2(e) * (a/2, b, c/2) folded at staging time, so exp(-sigma) = exp2(P) is
