@@ -97,26 +97,28 @@ def _all_to_all(recv, send):
         recv.copy_(send)
 
 
-def records_to_view_owners(records_local, world, a2a=_all_to_all):
+def records_to_view_owners(records_local, world, a2a=_all_to_all, recv=None):
     """records_local [V, n, K] (own Gaussians, all V = world*C views) -> [C, world*n, K]: all Gaussians (global order)
-    for the C views this rank owns.  Chunk r of the send buffer = views of rank r."""
+    for the C views this rank owns.  Chunk r of the send buffer = views of rank r.  recv: optional receive buffer."""
     V, n, K = records_local.shape
     C = V // world
     send = records_local.reshape(world, C, n, K)
-    recv = torch.empty_like(send)                       # [source rank, C, n, K]
+    recv = torch.empty_like(send) if recv is None else recv.reshape(world, C, n, K)   # [source rank, C, n, K]
     a2a(recv.reshape(-1), send.reshape(-1))
     if C == 1:
         return recv.reshape(1, world * n, K)
     return recv.permute(1, 0, 2, 3).reshape(C, world * n, K).contiguous()
 
 
-def records_to_gaussian_owners(v_records, world, a2a=_all_to_all):
+def records_to_gaussian_owners(v_records, world, a2a=_all_to_all, recv=None):
     """v_records [C, world*n, K] (own views, all Gaussians) -> [V, n, K]: all views for the own Gaussians."""
     C, N, K = v_records.shape
     n = N // world
     send = v_records.reshape(C, world, n, K)
     send = send.reshape(world, n, K) if C == 1 else send.permute(1, 0, 2, 3).contiguous()   # [dest rank, C, n, K]
-    recv = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)    # [source = view owner, C, n, K]
+    if recv is None:
+        recv = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)
+    recv = recv.reshape(world, C, n, K)                                                    # [source = view owner, C, n, K]
     a2a(recv.reshape(-1), send.reshape(-1))
     return recv.reshape(world * C, n, K)
 
@@ -141,7 +143,14 @@ class ShardedTrainer:
         self.grads = torch.empty(23 * self.n, device=dev)
         self.m = torch.zeros_like(self.grads); self.v = torch.zeros_like(self.grads)
         self.v_records = torch.empty((self.C * n_total, 12), device=dev)
+        # steady-state buffers: nothing is allocated inside step()
+        self.rec = torch.empty((self.V * self.n, 12), device=dev)
+        self.tiles = torch.empty((self.V * self.n,), dtype=torch.int32, device=dev)
+        self.recv_fwd = torch.empty((self.C * n_total, 12), device=dev)
+        self.recv_bwd = torch.empty((self.V * self.n, 12), device=dev)
         self.reg = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.kreg = torch.tensor([self.V * opac_fac / n_total, self.V * scale_fac / (3 * n_total)], dtype=torch.float64,
+                                 device=dev)
         self.lr, self.ssim_fac, self.opac_fac, self.scale_fac, self.t = lr, ssim_fac, opac_fac, scale_fac, 0
 
     def step(self, loss_out):
@@ -149,18 +158,18 @@ class ShardedTrainer:
         ops, P = self.ops, self.P
         self.reg.zero_()
         rec, _ = ops.project_sh(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
-                                self.Ks, self.campos, self.W, self.H, reg_sums=self.reg)
-        mine = records_to_view_owners(rec.reshape(self.V, self.n, 12), self.world, self.a2a)
+                                self.Ks, self.campos, self.W, self.H, reg_sums=self.reg, out=(self.rec, self.tiles))
+        mine = records_to_view_owners(rec.reshape(self.V, self.n, 12), self.world, self.a2a, recv=self.recv_fwd)
         st = ops.raster_train(self.ctx, mine.reshape(-1, 12), self.N, self.C, self.gt, self.W, self.H, self.ssim_fac,
                               self.v_records, loss_out)
-        back = records_to_gaussian_owners(self.v_records.reshape(self.C, self.N, 12), self.world, self.a2a)
+        back = records_to_gaussian_owners(self.v_records.reshape(self.C, self.N, 12), self.world, self.a2a,
+                                          recv=self.recv_bwd)
         frac = self.n / self.N    # the regularisers are means over ALL N Gaussians (starster/gs.py:132,134)
-        g = ops.project_sh_bwd(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
-                               self.Ks, self.campos, self.W, self.H, rec, back.reshape(-1, 12),
-                               reg_views=float(self.V), opac_fac=self.opac_fac * frac, scale_fac=self.scale_fac * frac)
-        self.grads = g
+        ops.project_sh_bwd(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
+                           self.Ks, self.campos, self.W, self.H, rec, back.reshape(-1, 12), reg_views=float(self.V),
+                           opac_fac=self.opac_fac * frac, scale_fac=self.scale_fac * frac, out=self.grads)
         # regulariser part of the loss for the own Gaussians, added once per view like the reference (gs.py:150-152)
-        loss_out += (self.V * (self.opac_fac * self.reg[0] / self.N + self.scale_fac * self.reg[1] / (3 * self.N))).float()
+        loss_out += (self.reg[:2] * self.kreg).sum().float()
         self.t += 1
         ops.adam_step(self.ctx, P, self.grads, self.m, self.v, self.lr, 0.9, 0.999, 1e-8, self.t)
         return st

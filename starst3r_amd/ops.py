@@ -88,10 +88,14 @@ def sh_stride_of(sh):
 
 
 def project_sh(ctx, means, quats, scales, opacities, sh, viewmats, Ks, campos, W, H, reg_sums=None,
-               eps2d=0.3, near=0.01, far=1e10, radius_clip=0.0):
+               eps2d=0.3, near=0.01, far=1e10, radius_clip=0.0, out=None):
+    """out: optional (splats [Cn*N,12], tiles int32 [Cn*N]) buffers to write into (steady-state loops)."""
     N, Cn = means.shape[0], viewmats.shape[0]
-    splats = torch.empty((Cn * N, SPLAT), dtype=torch.float32, device=means.device)
-    tiles = torch.empty((Cn * N,), dtype=torch.int32, device=means.device)
+    if out is not None:
+        splats, tiles = out
+    else:
+        splats = torch.empty((Cn * N, SPLAT), dtype=torch.float32, device=means.device)
+        tiles = torch.empty((Cn * N,), dtype=torch.int32, device=means.device)
     _lib.check(_lib.lib().st3r_gs_project_sh(
         ctx.handle, _stream(), N, Cn, _p(means), _p(quats), _p(scales), _p(opacities), _p(sh), sh_stride_of(sh),
         _p(viewmats), _p(Ks), _p(campos), W, H, TILE, eps2d, near, far, radius_clip, _p(splats),
@@ -153,9 +157,9 @@ def blend_bwd(ctx, splats, off, flat, alpha, last, v_rgb, v_alpha, cum, Cn, W, H
 
 
 def project_sh_bwd(ctx, means, quats, scales, opacities, sh, viewmats, Ks, campos, W, H, splats, v_splats,
-                   reg_views=0.0, opac_fac=0.0, scale_fac=0.0, eps2d=0.3):
+                   reg_views=0.0, opac_fac=0.0, scale_fac=0.0, eps2d=0.3, out=None):
     N, Cn = means.shape[0], viewmats.shape[0]
-    grads = torch.empty((23 * N,), dtype=torch.float32, device=means.device)
+    grads = out if out is not None else torch.empty((23 * N,), dtype=torch.float32, device=means.device)
     _lib.check(_lib.lib().st3r_gs_project_sh_bwd(
         ctx.handle, _stream(), N, Cn, _p(means), _p(quats), _p(scales), _p(opacities), _p(sh), sh_stride_of(sh),
         _p(viewmats), _p(Ks), _p(campos), W, H, eps2d, _p(splats), _p(v_splats), reg_views, opac_fac, scale_fac,
