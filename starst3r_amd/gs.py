@@ -257,6 +257,8 @@ def run_3dgs_optim(
     st = scene._gs_optim
     g = scene.gaussians
     rank, world = _dist.rank_world()
+    if _sharded_layout(scene, world, enable_pruning):
+        return _run_3dgs_optim_sharded(scene, iters, loss_ssim_fac, loss_opacity_fac, loss_scale_fac, verbose)
     views = _dist.shard_views(len(scene.imgs), rank, world)
     w2c_all = scene.w2c.to(scene.device, torch.float32)
     w2c = w2c_all[views].contiguous()
@@ -287,6 +289,73 @@ def run_3dgs_optim(
             scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
     _dist.all_reduce_sum(losses)
     return losses[:iters].cpu().tolist()   # one device->host copy for the whole call (reference: .item() per step)
+
+
+def _sharded_layout(scene, world, enable_pruning):
+    """Gaussians AND views sharded (layout 2) when a GPU holds at most two views.  The MCMC
+    hooks need every Gaussian on every rank, so enable_pruning keeps the replicated layout.  ST3R_MULTI_GPU =
+    replicated | gaussian-sharded overrides the choice (the latter also with a single rank: tests)."""
+    import os
+    want = os.environ.get("ST3R_MULTI_GPU", "auto")
+    if enable_pruning or want == "replicated":
+        return False
+    n_views, N = len(scene.imgs), scene.gaussians["means"].shape[0]
+    if n_views % world or N % world:
+        return False
+    if want == "gaussian-sharded":
+        return True
+    return world > 1 and n_views // world <= 2
+
+
+def _run_3dgs_optim_sharded(scene, iters, ssim_fac, opac_fac, scale_fac, verbose):
+    """run_3dgs_optim on the Gaussian-sharded layout: this rank trains rows [lo, hi) of the (replicated) parameter
+    tensors in place, exchanging splat records with the other ranks; at the end the shards are all-gathered so that
+    scene.gaussians and the optimiser state are complete on every rank again."""
+    import torch.distributed as tdist
+    height, width = scene.imgs[0].shape[:2]
+    ctx = ops.get_context(scene.device)
+    st, g = scene._gs_optim, scene.gaussians
+    rank, world = _dist.rank_world()
+    N = g["means"].shape[0]
+    lo, hi = _dist.shard_gaussians(N, rank, world)
+    n = hi - lo
+    views = _dist.shard_views_contiguous(len(scene.imgs), rank, world)
+    w2c_all = scene.w2c.to(scene.device, torch.float32).contiguous()
+    Ks_all = scene.intrinsics.to(scene.device, torch.float32).contiguous()
+    gt = _gt_on_device(scene, views)
+    keys = ("means", "quats", "scales", "opacities", "shN")
+    P = {k: g[k].data[lo:hi] for k in keys}                    # views: the shard is updated in place
+    tr = _dist.ShardedTrainer(ctx, P, N, w2c_all, Ks_all, gt, width, height, rank, world, lr=st.lr, ssim_fac=ssim_fac,
+                              opac_fac=opac_fac, scale_fac=scale_fac)
+    off = 0
+    for _, w in ADAM_BLOCKS:                                    # this shard's rows of the [23N] moment blocks
+        tr.m[off * n:(off + w) * n].copy_(st.m[off * N + w * lo:off * N + w * hi])
+        tr.v[off * n:(off + w) * n].copy_(st.v[off * N + w * lo:off * N + w * hi])
+        off += w
+    tr.t = st.step
+    losses = torch.zeros(max(iters, 1), device=scene.device)
+    it_range = range(iters)
+    if verbose:
+        from tqdm import trange
+        it_range = trange(iters)
+    for step in it_range:
+        tr.step(losses[step:step + 1])
+    st.step = tr.t
+    gathered = tdist.is_available() and tdist.is_initialized()
+    def gather(full, local):
+        if gathered:
+            tdist.all_gather_into_tensor(full.reshape(-1), local.reshape(-1).clone())
+        else:
+            full.reshape(-1).copy_(local.reshape(-1))
+    for k in keys:
+        gather(g[k].data, P[k])
+    off = 0
+    for _, w in ADAM_BLOCKS:
+        gather(st.m[off * N:(off + w) * N], tr.m[off * n:(off + w) * n])
+        gather(st.v[off * N:(off + w) * N], tr.v[off * n:(off + w) * n])
+        off += w
+    _dist.all_reduce_sum(losses)
+    return losses[:iters].cpu().tolist()
 
 
 train = run_3dgs_optim  # alias for the wording of BASELINE.json's north_star ("gs.train()")
