@@ -292,9 +292,14 @@ GSO_API void gso_isect_offsets(int64_t n_isects, const int64_t* sorted_ids, int 
     while (next < total) offsets[next++] = (int32_t)n_isects;
 }
 
-/* gsplat rasterize_to_pixels fwd [U].  margin (optional, may be NULL): per pixel, the
- * smallest relative distance of any skip/stop decision to its threshold -- lets tests
- * exclude pixels whose control flow may legitimately flip under a 1-ulp exp difference. */
+/* gsplat rasterize_to_pixels fwd [U].  margin (optional, may be NULL): per pixel, how far the pixel is from being
+ * undetermined in float32 arithmetic -- tests exclude pixels with margin <= 1e-4 and require the rest to agree to 1e-4:
+ *   - the smallest relative distance of any skip/stop decision to its threshold (a 1-ulp exp difference may flip it);
+ *   - sigma = (a dx^2 + c dy^2)/2 + b dx dy cancels catastrophically for strongly anisotropic Gaussians far from their
+ *     mean: two float evaluations (this one, gsplat's fma-contracted one, the q-form of the HIP kernel) differ by
+ *     ~2 ulp of the largest term, es = 2^-22 (|a dx^2| + |c dy^2| + 2 |b dx dy|), i.e. alpha is only known to a
+ *     relative es.  Decisions are judged against es (distance / max(1, es / 2.5e-5)), and a pixel whose accumulated
+ *     value uncertainty sum(vis * es) exceeds 2e-5 gets margin 0. */
 GSO_API void gso_blend_fwd(int C, int W, int H, int tile_size, int tile_w, int tile_h, const float* means2d,
                            const float* conics, const float* colors, const float* opacities,
                            const int32_t* offsets, const int32_t* flatten_ids, int64_t n_isects, float* out_rgb,
@@ -310,22 +315,30 @@ GSO_API void gso_blend_fwd(int C, int W, int H, int tile_size, int tile_w, int t
                 float px = (float)j + 0.5f, py = (float)i + 0.5f;
                 float T = 1.0f, r = 0.f, g = 0.f, b = 0.f;
                 int32_t cur = 0;
-                float mg = 1e30f;
+                float mg = 1e30f, uT = 0.f, uval = 0.f;
                 for (int64_t k = start; k < end; ++k) {
                     int32_t id = flatten_ids[k];
                     float dx = means2d[2 * id] - px, dy = means2d[2 * id + 1] - py;
                     float ca = conics[3 * id], cb = conics[3 * id + 1], cc = conics[3 * id + 2];
                     float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
                     float alpha = fminf(0.999f, opacities[id] * expf(-sigma));
+                    float es = 0.f;
                     if (margin) {
-                        float m1 = fabsf(alpha - (1.f / 255.f)) * 255.f;
+                        es = 5.9604644775390625e-08f * (fabsf(ca * dx * dx) + fabsf(cc * dy * dy) + 2.f * fabsf(cb * dx * dy));
+                        float loosen = fmaxf(1.f, es / 2.5e-5f);
+                        float m1 = fabsf(alpha - (1.f / 255.f)) * 255.f / loosen;
                         if (m1 < mg) mg = m1;
                         float m0 = fabsf(sigma); /* sigma<0 decision; absolute */
-                        if (m0 < 1e-6f && m0 < mg) mg = m0;
+                        if (m0 < fmaxf(1e-6f, es) && m0 < mg) mg = m0;
                     }
                     if (sigma < 0.f || alpha < 1.f / 255.f) continue;
                     float nT = T * (1.0f - alpha);
-                    if (margin) { float m2 = fabsf(nT - 1e-4f) * 1e4f; if (m2 < mg) mg = m2; }
+                    if (margin) {
+                        uT += alpha < 0.999f ? alpha * es / (1.0f - alpha) : 0.f;   /* relative uncertainty of T */
+                        float m2 = fabsf(nT - 1e-4f) * 1e4f / fmaxf(1.f, uT / 2.5e-5f);
+                        if (m2 < mg) mg = m2;
+                        uval += alpha * T * (es + uT);
+                    }
                     if (nT <= 1e-4f) break;
                     float vis = alpha * T;
                     r += colors[3 * id] * vis; g += colors[3 * id + 1] * vis; b += colors[3 * id + 2] * vis;
@@ -336,7 +349,7 @@ GSO_API void gso_blend_fwd(int C, int W, int H, int tile_size, int tile_w, int t
                 out_rgb[3 * p] = r; out_rgb[3 * p + 1] = g; out_rgb[3 * p + 2] = b;
                 out_alpha[p] = 1.0f - T;
                 last_ids[p] = cur;
-                if (margin) margin[p] = mg;
+                if (margin) margin[p] = uval > 5e-5f ? 0.f : mg;
             }
 }
 

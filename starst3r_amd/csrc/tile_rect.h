@@ -35,9 +35,12 @@ __device__ __forceinline__ bool influence_extent(float opac, float ca, float cb,
     if (!(o255 > 1.0f)) return false;
     // single hardware instructions (v_log_f32, v_rcp_f32, v_sqrt_f32: ~1 ulp, identical in every kernel that
     // includes this header); their error is orders of magnitude below the inflation
-    const float tau = __logf(o255) * 1.0002f + 1e-4f;
     const float det = ca * cc - cb * cb;
-    const float k = 2.0f * tau * __builtin_amdgcn_rcpf(det);
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    // sigma cancels catastrophically for strongly correlated conics: on the contour sigma = tau its terms reach
+    // tau * ca*cc/det, so two float evaluations of sigma differ by ~1e-6 of that -- the threshold is widened by as much
+    const float tau = __logf(o255) * (1.0002f + 4e-6f * (ca * cc) * rdet) + 1e-4f;
+    const float k = 2.0f * tau * rdet;
     *ex = __builtin_amdgcn_sqrtf(k * cc) * 1.0001f + slack;
     *ey = __builtin_amdgcn_sqrtf(k * ca) * 1.0001f + slack;
     return true;
@@ -83,7 +86,8 @@ __device__ __forceinline__ bool ellipse_prepare(float opac, float ca, float cb, 
 #pragma clang fp contract(off)
     const float o255 = 255.0f * opac;
     if (!(o255 > 1.0f)) return false;
-    e->tau = __logf(o255) * 1.0002f + 2e-4f;
+    // (the anisotropy term: see influence_extent)
+    e->tau = __logf(o255) * (1.0002f + 4e-6f * (ca * cc) * __builtin_amdgcn_rcpf(ca * cc - cb * cb)) + 2e-4f;
     e->A = ca; e->B = cb; e->C = cc;
     e->kyx = -cb * __builtin_amdgcn_rcpf(cc);
     e->kxy = -cb * __builtin_amdgcn_rcpf(ca);
