@@ -21,15 +21,25 @@
 // walks exactly those bits back to front: no alpha test for non-contributors, no work behind
 // a wave's last contribution.
 //
-// Backward reduction.  The 9 per-pixel partial gradients are summed over the wave's 64 pixels
-// with a halving butterfly: v_permlane32_swap and v_permlane16_swap pair registers so that each
-// step halves the live values (5 + 3 swap/add pairs), then 4 fused DPP row steps on 3 registers.
-// The four waves' partial sums meet in LDS (ds_add_f32 at lane-dependent addresses), and one
-// thread per record writes them to the record's stamped slot in HBM -- no global atomics;
-// k_gather_vtile sums the slots of a pair in order.
+// Backward, two phases per wave.  Summing nine gradients over the 64 pixels of a wave for every record costs more
+// than computing them (a 64-lane butterfly per record), so the wave transposes instead:
+//   phase 1 (lanes = pixels)   walks the contributing records back to front exactly like the forward pass walks
+//                              them front to back, and leaves two scalars per (record, pixel) in a wave-private LDS
+//                              buffer: g_o = vis * dL/dalpha and fac = alpha * T.
+//   phase 2 (lanes = records)  every CHUNK records the lanes regroup as (record, pixel row): each lane walks the 8
+//                              pixels of its row and accumulates the record's sums
+//                              sum g_o {1, dx, dy, dx^2, dx dy, dy^2} and sum fac v_rgb in registers; the eight row
+//                              sums of a record meet in one halving butterfly per CHUNK records.
+// A wave meets a record once per round, so its sums are stored (not added) into the wave's own accumulator rows;
+// after the round one thread per record adds the rows of the waves whose contribution bit is set, applies the
+// record constants (opacity, conic) and writes the record's stamped slot in HBM -- no atomics anywhere;
+// k_gather_vtile sums the slots of a (camera, gaussian) pair in order.  Rounds stage HB = 64 records (a quarter of
+// a forward batch): 28 KB of LDS and 95 VGPRs keep five workgroups per CU, which this latency-bound kernel needs
+// (measured: the same code with 3 or 4 workgroups per CU is 15-40 % slower).
 //
-// Both kernels are VALU-issue bound: every instruction in the two inner
-// loops is there on purpose; the file is compiled without packed-fp32 code generation.
+// Cost split of the backward at SYNTH-1M (ablation, tools/abl.sh): phase 1 + 2 arithmetic 1.6 ms, staging 0.7 ms,
+// slot writes + gather 0.9 ms (20 M writes to random 48-byte slots: bound by the number of accesses, not bytes --
+// dense writes plus an index indirection cost the same).  The file is compiled without packed-fp32 code generation.
 //
 // Arithmetic note.  sigma is evaluated as P = dx*(qa*dx + qb*dy) + qc*dy*dy with
 // (qa,qb,qc) = -log2(e) * (a/2, b, c/2) folded at staging time, so exp(-sigma) = exp2(P) is
@@ -95,14 +105,20 @@ __device__ __forceinline__ TileGeom tile_geom(int C, int W, int H, int tile_w, i
 }
 
 // Stage record `id` into LDS slot t (q-form) and return the 4-bit quadrant relevance.
+// q-form of a record in LDS slot t (see the arithmetic note above); forward and backward stage through this one function
+__device__ __forceinline__ void stage_qform(const float4& a, const float4& b, const float4& c, int t, float4* sA,
+                                            float4* sB, float* sC) {
+    sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
+    sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
+    sC[t] = c.x;
+}
+
 __device__ __forceinline__ int stage_record(const float4* __restrict__ splats, int64_t id, int t, int tx0, int ty0,
                                             float4* sA, float4* sB, float* sC) {
     const float4 a = splats[id * 3 + 0];   // x y opacity conic.a
     const float4 b = splats[id * 3 + 1];   // conic.b conic.c r g
     const float4 c = splats[id * 3 + 2];   // b depth radius 0
-    sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
-    sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
-    sC[t] = c.x;
+    stage_qform(a, b, c, t, sA, sB, sC);
     // A quadrant (8x8 pixel centres) is relevant iff the ellipse {sigma(p) <= tau}, tau = ln(255 opacity), reaches
     // it: either the mean lies inside, or the minimum of sigma over one of its four edges is <= tau (sigma is
     // convex, so the minimum over the square sits on the boundary when the mean is outside).  tau is inflated
@@ -294,30 +310,72 @@ __device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, 
         : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(z1));
     k0 = h0 + h1; k1 = h2 + h3; k2 = h4 + z1;
 }
-// 16-lane row sums (every lane of a row receives the row total) of three registers, interleaved so that consecutive DPP reads of one register are three
-// instructions apart (no wait states needed) and the adds stay fused with their DPP operand
-__device__ __forceinline__ void row_allsum3(float& a, float& b, float& c) {
-    asm volatile(
-        "s_nop 1\n"
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-        : "+v"(a), "+v"(b), "+v"(c));
+#define ACC_VALS 9      // S_x S_y S_o S_xx S_xy S_yy S_r S_g S_b per staged record and wave
+#define VT_STRIDE 12    // per-(record, tile) slot: 9 partial gradients (+3 pad) = 3 x 16 B; stamps live in a side array
+#ifndef HB
+#define HB 64           // records staged per backward round (a fraction of a forward batch of 256)
+#endif
+#define HB_WORDS (HB / 64)   // 64-record mask words per round
+#define CHUNK 8         // records per transposition chunk
+#ifndef GROUP
+#define GROUP 1         // records per phase-1 iteration
+#endif
+#define PAIR_STRIDE 65  // float2 per record row of the chunk buffer (64 pixels + 1: conflict-free both ways)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave complete in order; this only stops the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-#define ACC_STRIDE 12  // 9 partial sums + 3 pad words (rows 1..3 park their unused third register there)
-#define ACC_VALS 9
-#define VT_STRIDE 12  // per-(record, tile) slot: 9 partial gradients (+3 pad) = 3 x 16 B; stamps live in a side array
+__device__ __forceinline__ float row_ror8_add(float v) {
+    float r;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
 
+// Phase 2 of the backward pass: the wave's lanes turn from pixels into (record, pixel row) pairs.
+//   lane = r + 8 * part: record r of the chunk, row `part` of the wave's 8x8 quadrant (pixels part*8 .. part*8+7)
+// Each lane walks its 8 pixels, reading the pair scalars (g_o, fac) phase 1 left in LDS, and accumulates the pixel
+// sums of its record in registers -- no cross-lane traffic per record.  The eight row sums of a record meet through
+// the halving butterfly (once per CHUNK records) plus one DPP step, and the result is stored (plain ds_write: a wave
+// meets a record once per round) in the wave's own accumulator rows.
+//   S_o = sum g_o, S_x = sum g_o dx, S_y = sum g_o dy, S_xx = sum g_o dx^2, S_xy, S_yy, S_rgb = sum fac v_rgb
+// with g_o = vis dL/dalpha (so v_sigma = -opacity g_o; the record constants are applied at flush time).
+__device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, const int* __restrict__ idx, int cnt,
+                                           int lane, const float4* sA, float* accw, float qxf, float qyf_part,
+                                           const float (&pvr)[8], const float (&pvg)[8], const float (&pvb)[8]) {
+    const int r = lane & 7, part = lane >> 3;
+    wave_lds_sync();
+    const int t = idx[r];  // rows >= cnt keep an older (valid) index; their sums are dropped below
+    const float2 mean = *reinterpret_cast<const float2*>(&sA[t]);
+    const float dy = mean.y - qyf_part;
+    const float2* src = pr + r * PAIR_STRIDE + part * 8;
+    float So = 0.f, Sx = 0.f, Sxx = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float2 v = src[i];
+        const float dx = mean.x - (qxf + (float)i);
+        const float sdx = v.x * dx;
+        So += v.x; Sx += sdx;
+        Sxx = fmaf(sdx, dx, Sxx);
+        Sr = fmaf(v.y, pvr[i], Sr); Sg = fmaf(v.y, pvg[i], Sg); Sb = fmaf(v.y, pvb[i], Sb);
+    }
+    const float Sy = So * dy, Sxy = Sx * dy, Syy = Sy * dy;  // dy is the same for the lane's 8 pixels
+    float k0, k1, k2;
+    reduce9(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);   // lane bits 5, 4 (rows part>>1)
+    k0 = row_ror8_add(k0); k1 = row_ror8_add(k1); k2 = row_ror8_add(k2);  // lane bit 3 (part & 1)
+    if (r < cnt && (lane & 8) == 0) {
+        // 16-lane row -> slots: k0 -> {0,2,1,3}[row], k1 -> {4,6,5,7}[row], k2 -> 8 (row 0)
+        const int row = lane >> 4;
+        const int slot0 = ((row & 1) << 1) | (row >> 1);
+        float* acc = accw + t * ACC_VALS;
+        acc[slot0] = k0;
+        acc[4 + slot0] = k1;
+        if (row == 0) acc[8] = k2;
+    }
+    wave_lds_sync();
+}
 
 template <bool HAS_VA>  // v_alpha is NULL in the train step (the reference's loss ignores render_alpha, gs.py:126)
 __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
@@ -333,10 +391,12 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const int32_t* __restrict__ cum, int tight,
                                                    float* __restrict__ vtile, int32_t* __restrict__ vstamp,
                                                    int stamp) {
-    __shared__ float4 sA[BLK];
-    __shared__ float4 sB[BLK];
-    __shared__ float sC[BLK];
-    __shared__ float sAcc[BLK * ACC_STRIDE];  // per-batch, per-record partial sums of the 4 waves
+    __shared__ float4 sA[HB];
+    __shared__ float4 sB[HB];
+    __shared__ float sC[HB];
+    __shared__ float sAccW[4][HB * ACC_VALS];             // per wave: the sums of the records it met this round
+    __shared__ float2 sPair[4][CHUNK * PAIR_STRIDE];      // per wave: (g_o, fac) of CHUNK records x 64 pixels
+    __shared__ int sIdx[4][CHUNK];                        // per wave: staged index of the chunk's records
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
     const int nb = tile_nb[g.lb];
     if (nb == 0) return;
@@ -350,109 +410,142 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         if (HAS_VA) va = v_alpha[p];
         bin_final = last_ids[p];
     }
+    // phase-2 view of the quadrant: this lane's 8 pixels are those of lanes (lane>>3)*8 .. +7 (one pixel row); their
+    // v_rgb go through the (still unused) chunk buffer into registers once per tile
+    float2* pr = sPair[w];
+    int* idx = sIdx[w];
+    float* accw = sAccW[w];
+    float pvr[8], pvg[8], pvb[8];
+    {
+        float* px = reinterpret_cast<float*>(pr);
+        px[lane] = vr; px[64 + lane] = vg; px[128 + lane] = vb;
+        if (lane < CHUNK) idx[lane] = 0;
+        wave_lds_sync();
+        const int base = (lane >> 3) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { pvr[i] = px[base + i]; pvg[i] = px[64 + base + i]; pvb[i] = px[128 + base + i]; }
+        wave_lds_sync();
+    }
+    const float qxf = (float)(g.tx0 + ((w & 1) << 3)) + 0.5f;
+    const float qyf_part = (float)(g.ty0 + ((w >> 1) << 3) + (lane >> 3)) + 0.5f;
     float T = T_final;
     // gsplat keeps buffer[k] = sum of the colours blended behind the current record; only its dot product
     // with the pixel's v_rgb is ever used, so one scalar replaces the three components
     float bv = 0.f;
     const int64_t mbase = mask_base(g.lb, g.start);
     const uint64_t* wmask = cmask + (int64_t)w * cmask_words + mbase;
-    // row (16 lanes) r of the folded registers holds: k0 -> slot {0,2,1,3}[r], k1 -> {4,6,5,7}[r], k2 -> 8 (row 0)
-    const int row = lane >> 4;
-    const int slot0 = ((row & 1) << 1) | (row >> 1);
-    const bool row_leader = (lane & 15) == 0;
 
-    for (int bt = nb - 1; bt >= 0; --bt) {
-        const int bs = g.start + bt * BLK;
-        const int bsz = min(BLK, g.end - bs);
+    for (int hb = (BLK / HB) * nb - 1; hb >= 0; --hb) {
+        const int bs = g.start + hb * HB;
+        const int bsz = min(HB, g.end - bs);
+        if (bsz <= 0) continue;   // the tail of the last forward batch may be empty (uniform over the workgroup)
         __syncthreads();
-        int64_t my_id = 0;
+        // ---- staging: one record per thread (threads 0..HB-1).  A record some wave contributed to also fixes its
+        // output slot now, so that the flush below is loads-free:  u = cum_excl[pid] + index of this tile inside the
+        // record's tile rectangle (same float ops as the emit kernel => same integers)
+        int my_u = -1, my_cb = 0;
+        float my_op = 0.f, my_ca = 0.f, my_cbb = 0.f, my_cc = 0.f;
         if ((int)threadIdx.x < bsz) {
-            my_id = flat[bs + threadIdx.x];
-            (void)stage_record(splats, my_id, threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
-        }
+            const int t = threadIdx.x;
+            const int64_t my_id = flat[bs + t];
+            const float4 a = splats[my_id * 3 + 0];   // x y opacity conic.a
+            const float4 b = splats[my_id * 3 + 1];   // conic.b conic.c r g
+            const float4 c = splats[my_id * 3 + 2];   // b depth radius 0
+            stage_qform(a, b, c, t, sA, sB, sC);
+            const int64_t word = mbase + hb * HB_WORDS + (t >> 6);
 #pragma unroll
-        for (int k = 0; k < ACC_STRIDE; ++k) sAcc[threadIdx.x * ACC_STRIDE + k] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int jj = 3; jj >= 0; --jj) {
-            uint64_t m = uniform_u64(wmask[bt * 4 + jj]);
-            while (m) {
-                const int bit = 63 - __builtin_clzll(m);
-                m &= ~(1ull << bit);
-                const int t = jj * 64 + bit;
-                const float4 a = sA[t];
-                const float4 q = sB[t];
-                const float cb_ = sC[t];
-                const float dx = a.x - g.px, dy = a.y - g.py;
-                const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
-                const float P = dx * lx + q.y * dy * dy;
-                const float vis0 = __builtin_amdgcn_exp2f(P);
-                // same include test as the forward pass (bin_final is -1 outside the image)
-                const bool valid = (bs + t <= bin_final) && !(P > 0.f) && !(fminf(0.999f, a.z * vis0) < 1.f / 255.f);
-                // Branch-free from here: a lane that does not include this record gets vis = 0, hence
-                // alpha = 0, ra = 1, fac = 0, and all nine partial gradients vanish without a single branch.
-                const float vis = valid ? vis0 : 0.f;
-                const float ov = a.z * vis;
-                const float alpha = fminf(0.999f, ov);
-                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
-                T *= ra;
-                const float fac = alpha * T;
-                const float cv = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
-                float v_al = cv * T - bv * ra;
-                if (HAS_VA) v_al += T_final * ra * va;
-                // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
-                const float vis_u = (ov <= 0.999f) ? vis : 0.f;
-                const float g_o = vis_u * v_al;
-                const float v_sigma = -a.z * g_o;
-                // Per-record constant factors are applied once per (record, tile) at flush time instead of per
-                // pixel: g_ca, g_cc lack their 1/2; g_x, g_y lack -1/log2(e)
-                // (d sigma/d mean = (a dx + b dy, b dx + c dy) with a = -2 qa/log2e, b = -qb/log2e, c = -2 qc/log2e).
-                const float sdx = v_sigma * dx, sdy = v_sigma * dy;
-                const float g_x = 2.0f * a.w * sdx + q.x * sdy;
-                const float g_y = q.x * sdx + 2.0f * q.y * sdy;
-                const float g_ca = sdx * dx, g_cb = sdx * dy, g_cc = sdy * dy;
-                const float g_r = fac * vr, g_g = fac * vg, g_b = fac * vb;
-                bv += cv * fac;
-                // 9 values x 64 lanes -> halving butterfly
-                float k0, k1, k2;
-                reduce9(g_x, g_y, g_o, g_ca, g_cb, g_cc, g_r, g_g, g_b, k0, k1, k2);
-                row_allsum3(k0, k1, k2);
-                if (row_leader) {
-                    // all four row leaders add their third register at a lane-dependent address (rows 1..3 into
-                    // the pad words): a single-lane atomic at a wave-uniform address makes hipcc wrap it in its
-                    // scalar wave-reduction loop, ~12 extra instructions per record
-                    float* acc = sAcc + t * ACC_STRIDE;
-                    atomicAdd(acc + slot0, k0);
-                    atomicAdd(acc + 4 + slot0, k1);
-                    atomicAdd(acc + 8 + row, k2);
-                }
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < bsz) {
-            const float* acc = sAcc + threadIdx.x * ACC_STRIDE;
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < ACC_VALS; ++k) any |= (acc[k] != 0.f);
-            if (any) {
-                // slot of this (record, tile) pair in emission order: u = cum_excl[pid] + index of this
-                // tile inside the record's tile rectangle (same float ops as k_isect_emit => same ints)
-                const float4 a = splats[my_id * 3 + 0];
-                const float radius = (float)__float_as_int(splats[my_id * 3 + 2].z);
+            for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
+            if (my_cb) {
+                const float radius = (float)__float_as_int(c.z);
                 TileRect tr = ref_tile_rect(a.x, a.y, radius, 16, tile_w, tile_h);
-                if (tight) {
-                    const float4 b1 = splats[my_id * 3 + 1];
-                    tr = tight_tile_rect(tr, a.x, a.y, a.z, a.w, b1.x, b1.y);
-                }
-                const int x0 = tr.x0, y0 = tr.y0, x1 = tr.x1;
+                if (tight) tr = tight_tile_rect(tr, a.x, a.y, a.z, a.w, b.x, b.y);
                 const int cum_excl = my_id == 0 ? 0 : cum[my_id - 1];
-                const int64_t u = (int64_t)cum_excl + ((g.ty0 >> 4) - y0) * (x1 - x0) + ((g.tx0 >> 4) - x0);
-                float4* dst = reinterpret_cast<float4*>(vtile + u * VT_STRIDE);
-                dst[0] = make_float4(acc[0] * (-1.0f / LOG2E), acc[1] * (-1.0f / LOG2E), acc[2], 0.5f * acc[3]);
-                dst[1] = make_float4(acc[4], 0.5f * acc[5], acc[6], acc[7]);
-                dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
-                vstamp[u] = stamp;
+                my_u = cum_excl + ((g.ty0 >> 4) - tr.y0) * (tr.x1 - tr.x0) + ((g.tx0 >> 4) - tr.x0);
+                my_op = a.z; my_ca = a.w; my_cbb = b.x; my_cc = b.y;
             }
+        }
+        __syncthreads();
+        int cnt = 0;
+#pragma unroll
+        for (int jj = HB_WORDS - 1; jj >= 0; --jj) {
+            uint64_t m = uniform_u64(wmask[hb * HB_WORDS + jj]);
+            while (m) {
+                // ---- phase 1: lanes are pixels; GROUP records per iteration, back to front.  Everything up to
+                // 1/(1 - alpha) is independent between the records of a group; only the transmittance chain T, bv
+                // is sequential.  A word's last group may hold dummies (forced invalid: alpha = 0,
+                // 1/(1 - alpha) = 1, nothing changes) whose rows lie beyond cnt and are never summed.
+                int tt[GROUP]; bool real[GROUP];
+                int bit = 0;
+#pragma unroll
+                for (int k = 0; k < GROUP; ++k) {
+                    real[k] = (m != 0);
+                    if (real[k]) { bit = 63 - __builtin_clzll(m); m &= ~(1ull << bit); }
+                    tt[k] = jj * 64 + bit;
+                }
+                float alpha[GROUP], ra[GROUP], vis_u[GROUP], cv[GROUP];
+#pragma unroll
+                for (int k = 0; k < GROUP; ++k) {
+                    const int t = tt[k];
+                    const float4 a = sA[t];
+                    const float4 q = sB[t];
+                    const float cb_ = sC[t];
+                    const float dx = a.x - g.px, dy = a.y - g.py;
+                    const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
+                    const float P = dx * lx + q.y * dy * dy;
+                    const float vis0 = __builtin_amdgcn_exp2f(P);
+                    // same include test as the forward pass (bin_final is -1 outside the image)
+                    const bool valid = real[k] && (bs + t <= bin_final) && !(P > 0.f) &&
+                                       !(fminf(0.999f, a.z * vis0) < 1.f / 255.f);
+                    // Branch-free from here: a lane that does not include this record gets vis = 0, hence
+                    // alpha = 0, ra = 1, fac = 0, g_o = 0.
+                    const float vis = valid ? vis0 : 0.f;
+                    const float ov = a.z * vis;
+                    alpha[k] = fminf(0.999f, ov);
+                    ra[k] = __builtin_amdgcn_rcpf(1.0f - alpha[k]);
+                    // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
+                    vis_u[k] = (ov <= 0.999f) ? vis : 0.f;
+                    cv[k] = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
+                }
+#pragma unroll
+                for (int k = 0; k < GROUP; ++k) {
+                    T *= ra[k];
+                    const float fac = alpha[k] * T;
+                    float v_al = cv[k] * T - bv * ra[k];
+                    if (HAS_VA) v_al += T_final * ra[k] * va;
+                    bv += cv[k] * fac;
+                    pr[(cnt + k) * PAIR_STRIDE + lane] = make_float2(vis_u[k] * v_al, fac);
+                    idx[cnt + k] = tt[k];
+                }
+#pragma unroll
+                for (int k = 0; k < GROUP; ++k) cnt += real[k] ? 1 : 0;
+                if (cnt > CHUNK - GROUP) {
+                    bwd_phase2(pr, idx, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
+                    cnt = 0;
+                }
+            }
+        }
+        if (cnt) bwd_phase2(pr, idx, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
+        __syncthreads();
+        // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM
+        if (my_cb) {
+            float acc[ACC_VALS];
+#pragma unroll
+            for (int k = 0; k < ACC_VALS; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                if (my_cb & (1 << ww)) {
+#pragma unroll
+                    for (int k = 0; k < ACC_VALS; ++k) acc[k] += sAccW[ww][threadIdx.x * ACC_VALS + k];
+                }
+            }
+            // record constants: v_sigma = -opacity g_o;  v_mean2d = v_sigma (a dx + b dy, b dx + c dy);
+            // v_conic = v_sigma (dx^2 / 2, dx dy, dy^2 / 2)
+            const float sx = -my_op * acc[0], sy = -my_op * acc[1];
+            float4* dst = reinterpret_cast<float4*>(vtile + (int64_t)my_u * VT_STRIDE);
+            vstamp[my_u] = stamp;
+            dst[0] = make_float4(my_ca * sx + my_cbb * sy, my_cbb * sx + my_cc * sy, acc[2], -0.5f * my_op * acc[3]);
+            dst[1] = make_float4(-my_op * acc[4], -0.5f * my_op * acc[5], acc[6], acc[7]);
+            dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
         }
     }
 }
@@ -503,7 +596,7 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * VT_STRIDE * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
     float* vtile = (float*)p;
-    rc = st3r_arena_get2(ctx, SLOT_VSTAMP, sizeof(int32_t) * (size_t)n_isects, &p, &grown);
+        rc = st3r_arena_get2(ctx, SLOT_VSTAMP, sizeof(int32_t) * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
     if (grown) HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VSTAMP], s));
     int32_t* vstamp = (int32_t*)p;
