@@ -26,16 +26,17 @@
 //   phase 1 (lanes = pixels)   walks the contributing records back to front exactly like the forward pass walks
 //                              them front to back, and leaves two scalars per (record, pixel) in a wave-private LDS
 //                              buffer: g_o = vis * dL/dalpha and fac = alpha * T.
-//   phase 2 (lanes = records)  every CHUNK records the lanes regroup as (record, pixel row): each lane walks the 8
-//                              pixels of its row and accumulates the record's sums
-//                              sum g_o {1, dx, dy, dx^2, dx dy, dy^2} and sum fac v_rgb in registers; the eight row
+//   phase 2 (lanes = records)  every CHUNK records the lanes regroup as (record, pixel run): each lane walks CHUNK
+//                              pixels of one row and accumulates the record's sums
+//                              sum g_o {1, dx, dy, dx^2, dx dy, dy^2} and sum fac v_rgb in registers; the partial
 //                              sums of a record meet in one halving butterfly per CHUNK records.
 // A wave meets a record once per round, so its sums are stored (not added) into the wave's own accumulator rows;
 // after the round one thread per record adds the rows of the waves whose contribution bit is set, applies the
 // record constants (opacity, conic) and writes the record's stamped slot in HBM -- no atomics anywhere;
 // k_gather_vtile sums the slots of a (camera, gaussian) pair in order.  Rounds stage HB = 64 records (a quarter of
-// a forward batch): 28 KB of LDS and 95 VGPRs keep five workgroups per CU, which this latency-bound kernel needs
-// (measured: the same code with 3 or 4 workgroups per CU is 15-40 % slower).
+// a forward batch) and CHUNK = 4: 20 KB of LDS and 76 VGPRs keep six workgroups per CU (measured: the same code
+// with 3 or 4 workgroups per CU is 15-40 % slower, 7 or 8 are no faster).  PMC: 1.48 G VALU instructions per launch
+// (2.19 G for the per-record butterfly it replaces), the VALU pipes are busy for the whole kernel.
 //
 // Cost split of the backward at SYNTH-1M (ablation, tools/abl.sh): phase 1 + 2 arithmetic 1.6 ms, staging 0.7 ms,
 // slot writes + gather 0.9 ms (20 M writes to random 48-byte slots: bound by the number of accesses, not bytes --
@@ -89,7 +90,7 @@ __device__ __forceinline__ TileGeom tile_geom(int C, int W, int H, int tile_w, i
                                               const int32_t* __restrict__ offsets, int n_isects) {
     TileGeom g;
     const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-    g.lb = xcd_remap(blockIdx.x, total, (C & 7) == 0 ? (C >> 3) * n_tiles : tile_w);
+        g.lb = xcd_remap(blockIdx.x, total, (C & 7) == 0 ? (C >> 3) * n_tiles : tile_w);
     g.cam = g.lb / n_tiles;
     const int tile = g.lb - g.cam * n_tiles;
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
@@ -316,9 +317,9 @@ __device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, 
 #define HB 64           // records staged per backward round (a fraction of a forward batch of 256)
 #endif
 #define HB_WORDS (HB / 64)   // 64-record mask words per round
-#define CHUNK 8         // records per transposition chunk
-#ifndef GROUP
-#define GROUP 1         // records per phase-1 iteration
+static_assert(HB == 64, "the backward walks one mask word per round");
+#ifndef CHUNK
+#define CHUNK 4         // records per transposition chunk (4 or 8); a lane of phase 2 owns CHUNK pixels of one row
 #endif
 #define PAIR_STRIDE 65  // float2 per record row of the chunk buffer (64 pixels + 1: conflict-free both ways)
 
@@ -333,39 +334,46 @@ __device__ __forceinline__ float row_ror8_add(float v) {
     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
     return r;
 }
+__device__ __forceinline__ float row_ror4_add(float v) {
+    float r;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
 
-// Phase 2 of the backward pass: the wave's lanes turn from pixels into (record, pixel row) pairs.
-//   lane = r + 8 * part: record r of the chunk, row `part` of the wave's 8x8 quadrant (pixels part*8 .. part*8+7)
-// Each lane walks its 8 pixels, reading the pair scalars (g_o, fac) phase 1 left in LDS, and accumulates the pixel
-// sums of its record in registers -- no cross-lane traffic per record.  The eight row sums of a record meet through
-// the halving butterfly (once per CHUNK records) plus one DPP step, and the result is stored (plain ds_write: a wave
-// meets a record once per round) in the wave's own accumulator rows.
+// Phase 2 of the backward pass: the wave's lanes turn from pixels into (record, pixel run) pairs.
+//   lane = r + CHUNK * part: record r of the chunk, pixels part*CHUNK .. part*CHUNK + CHUNK-1 of the wave's 8x8
+//   quadrant (a whole pixel row for CHUNK = 8, half a row for CHUNK = 4)
+// Each lane walks its pixels, reading the pair scalars (g_o, fac) phase 1 left in LDS, and accumulates the pixel
+// sums of its record in registers -- no cross-lane traffic per record.  The 64 / CHUNK partial sums of a record meet
+// through the halving butterfly (once per CHUNK records) plus one or two DPP steps, and the result is stored (plain
+// ds_write: a wave meets a record once per round) in the wave's own accumulator rows.
 //   S_o = sum g_o, S_x = sum g_o dx, S_y = sum g_o dy, S_xx = sum g_o dx^2, S_xy, S_yy, S_rgb = sum fac v_rgb
 // with g_o = vis dL/dalpha (so v_sigma = -opacity g_o; the record constants are applied at flush time).
-__device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, const int* __restrict__ idx, int cnt,
-                                           int lane, const float4* sA, float* accw, float qxf, float qyf_part,
-                                           const float (&pvr)[8], const float (&pvg)[8], const float (&pvb)[8]) {
-    const int r = lane & 7, part = lane >> 3;
+__device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsigned tpack, int cnt, int lane, const float4* sA, float* accw, float qxf_lane, float qyf_lane,
+                                           const float (&pvr)[CHUNK], const float (&pvg)[CHUNK],
+                                           const float (&pvb)[CHUNK]) {
+    const int r = lane & (CHUNK - 1), part = lane / CHUNK;
     wave_lds_sync();
-    const int t = idx[r];  // rows >= cnt keep an older (valid) index; their sums are dropped below
+    const int t = (tpack >> (8 * r)) & 0xFF;  // rows >= cnt read index 0 (valid); their sums are dropped below
     const float2 mean = *reinterpret_cast<const float2*>(&sA[t]);
-    const float dy = mean.y - qyf_part;
-    const float2* src = pr + r * PAIR_STRIDE + part * 8;
+    const float dy = mean.y - qyf_lane;
+    const float2* src = pr + r * PAIR_STRIDE + part * CHUNK;
     float So = 0.f, Sx = 0.f, Sxx = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < CHUNK; ++i) {
         const float2 v = src[i];
-        const float dx = mean.x - (qxf + (float)i);
+        const float dx = mean.x - (qxf_lane + (float)i);
         const float sdx = v.x * dx;
         So += v.x; Sx += sdx;
         Sxx = fmaf(sdx, dx, Sxx);
         Sr = fmaf(v.y, pvr[i], Sr); Sg = fmaf(v.y, pvg[i], Sg); Sb = fmaf(v.y, pvb[i], Sb);
     }
-    const float Sy = So * dy, Sxy = Sx * dy, Syy = Sy * dy;  // dy is the same for the lane's 8 pixels
+    const float Sy = So * dy, Sxy = Sx * dy, Syy = Sy * dy;  // dy is the same for the lane's pixels
     float k0, k1, k2;
-    reduce9(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);   // lane bits 5, 4 (rows part>>1)
-    k0 = row_ror8_add(k0); k1 = row_ror8_add(k1); k2 = row_ror8_add(k2);  // lane bit 3 (part & 1)
-    if (r < cnt && (lane & 8) == 0) {
+    reduce9(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);            // lane bits 5, 4
+    k0 = row_ror8_add(k0); k1 = row_ror8_add(k1); k2 = row_ror8_add(k2);  // lane bit 3
+    if (CHUNK == 4) { k0 = row_ror4_add(k0); k1 = row_ror4_add(k1); k2 = row_ror4_add(k2); }  // lane bit 2
+    if (r < cnt && (lane & 15) < CHUNK) {
         // 16-lane row -> slots: k0 -> {0,2,1,3}[row], k1 -> {4,6,5,7}[row], k2 -> 8 (row 0)
         const int row = lane >> 4;
         const int slot0 = ((row & 1) << 1) | (row >> 1);
@@ -396,7 +404,6 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     __shared__ float sC[HB];
     __shared__ float sAccW[4][HB * ACC_VALS];             // per wave: the sums of the records it met this round
     __shared__ float2 sPair[4][CHUNK * PAIR_STRIDE];      // per wave: (g_o, fac) of CHUNK records x 64 pixels
-    __shared__ int sIdx[4][CHUNK];                        // per wave: staged index of the chunk's records
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
     const int nb = tile_nb[g.lb];
     if (nb == 0) return;
@@ -410,24 +417,22 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         if (HAS_VA) va = v_alpha[p];
         bin_final = last_ids[p];
     }
-    // phase-2 view of the quadrant: this lane's 8 pixels are those of lanes (lane>>3)*8 .. +7 (one pixel row); their
+    // phase-2 view of the quadrant: this lane's CHUNK pixels are those of lanes pbase .. pbase + CHUNK-1; their
     // v_rgb go through the (still unused) chunk buffer into registers once per tile
     float2* pr = sPair[w];
-    int* idx = sIdx[w];
     float* accw = sAccW[w];
-    float pvr[8], pvg[8], pvb[8];
+    float pvr[CHUNK], pvg[CHUNK], pvb[CHUNK];
+    const int pbase = (lane / CHUNK) * CHUNK;   // first of this lane's phase-2 pixels (quadrant-local index y*8 + x)
     {
         float* px = reinterpret_cast<float*>(pr);
         px[lane] = vr; px[64 + lane] = vg; px[128 + lane] = vb;
-        if (lane < CHUNK) idx[lane] = 0;
         wave_lds_sync();
-        const int base = (lane >> 3) * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { pvr[i] = px[base + i]; pvg[i] = px[64 + base + i]; pvb[i] = px[128 + base + i]; }
+        for (int i = 0; i < CHUNK; ++i) { pvr[i] = px[pbase + i]; pvg[i] = px[64 + pbase + i]; pvb[i] = px[128 + pbase + i]; }
         wave_lds_sync();
     }
-    const float qxf = (float)(g.tx0 + ((w & 1) << 3)) + 0.5f;
-    const float qyf_part = (float)(g.ty0 + ((w >> 1) << 3) + (lane >> 3)) + 0.5f;
+    const float qxf = (float)(g.tx0 + ((w & 1) << 3) + (pbase & 7)) + 0.5f;
+    const float qyf_part = (float)(g.ty0 + ((w >> 1) << 3) + (pbase >> 3)) + 0.5f;
     float T = T_final;
     // gsplat keeps buffer[k] = sum of the colours blended behind the current record; only its dot product
     // with the pixel's v_rgb is ever used, so one scalar replaces the three components
@@ -465,27 +470,17 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             }
         }
         __syncthreads();
-        int cnt = 0;
+        uint64_t m = uniform_u64(wmask[hb]);   // HB = 64: one mask word per round
+        while (m) {
+            // ---- phase 1: lanes are pixels; up to CHUNK records, back to front (unrolled: the chunk row is an
+            // immediate offset, the records' staged indices travel to phase 2 in one scalar, 8 bits each)
+            unsigned tpack = 0;
+            int cnt = 0;
 #pragma unroll
-        for (int jj = HB_WORDS - 1; jj >= 0; --jj) {
-            uint64_t m = uniform_u64(wmask[hb * HB_WORDS + jj]);
-            while (m) {
-                // ---- phase 1: lanes are pixels; GROUP records per iteration, back to front.  Everything up to
-                // 1/(1 - alpha) is independent between the records of a group; only the transmittance chain T, bv
-                // is sequential.  A word's last group may hold dummies (forced invalid: alpha = 0,
-                // 1/(1 - alpha) = 1, nothing changes) whose rows lie beyond cnt and are never summed.
-                int tt[GROUP]; bool real[GROUP];
-                int bit = 0;
-#pragma unroll
-                for (int k = 0; k < GROUP; ++k) {
-                    real[k] = (m != 0);
-                    if (real[k]) { bit = 63 - __builtin_clzll(m); m &= ~(1ull << bit); }
-                    tt[k] = jj * 64 + bit;
-                }
-                float alpha[GROUP], ra[GROUP], vis_u[GROUP], cv[GROUP];
-#pragma unroll
-                for (int k = 0; k < GROUP; ++k) {
-                    const int t = tt[k];
+            for (int k = 0; k < CHUNK; ++k) {
+                if (m) {
+                    const int t = 63 - __builtin_clzll(m);
+                    m &= ~(1ull << t);
                     const float4 a = sA[t];
                     const float4 q = sB[t];
                     const float cb_ = sC[t];
@@ -493,38 +488,28 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                     const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
                     const float P = dx * lx + q.y * dy * dy;
                     const float vis0 = __builtin_amdgcn_exp2f(P);
-                    // same include test as the forward pass (bin_final is -1 outside the image)
-                    const bool valid = real[k] && (bs + t <= bin_final) && !(P > 0.f) &&
-                                       !(fminf(0.999f, a.z * vis0) < 1.f / 255.f);
-                    // Branch-free from here: a lane that does not include this record gets vis = 0, hence
-                    // alpha = 0, ra = 1, fac = 0, g_o = 0.
-                    const float vis = valid ? vis0 : 0.f;
-                    const float ov = a.z * vis;
-                    alpha[k] = fminf(0.999f, ov);
-                    ra[k] = __builtin_amdgcn_rcpf(1.0f - alpha[k]);
+                    const float ov0 = a.z * vis0;
+                    const float al0 = fminf(0.999f, ov0);
+                    // same include test as the forward pass (bin_final is -1 outside the image).  Branch-free: a
+                    // lane that does not include this record gets alpha = 0, hence 1/(1-alpha) = 1, fac = 0, g_o = 0.
+                    const bool valid = (bs + t <= bin_final) && !(P > 0.f) && !(al0 < 1.f / 255.f);
+                    const float alpha = valid ? al0 : 0.f;
                     // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
-                    vis_u[k] = (ov <= 0.999f) ? vis : 0.f;
-                    cv[k] = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
-                }
-#pragma unroll
-                for (int k = 0; k < GROUP; ++k) {
-                    T *= ra[k];
-                    const float fac = alpha[k] * T;
-                    float v_al = cv[k] * T - bv * ra[k];
-                    if (HAS_VA) v_al += T_final * ra[k] * va;
-                    bv += cv[k] * fac;
-                    pr[(cnt + k) * PAIR_STRIDE + lane] = make_float2(vis_u[k] * v_al, fac);
-                    idx[cnt + k] = tt[k];
-                }
-#pragma unroll
-                for (int k = 0; k < GROUP; ++k) cnt += real[k] ? 1 : 0;
-                if (cnt > CHUNK - GROUP) {
-                    bwd_phase2(pr, idx, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
-                    cnt = 0;
+                    const float vis_u = (valid && ov0 <= 0.999f) ? vis0 : 0.f;
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    const float cv = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
+                    T *= ra;
+                    const float fac = alpha * T;
+                    float v_al = cv * T - bv * ra;
+                    if (HAS_VA) v_al += T_final * ra * va;
+                    bv += cv * fac;
+                    pr[k * PAIR_STRIDE + lane] = make_float2(vis_u * v_al, fac);
+                    tpack |= (unsigned)t << (8 * k);
+                    cnt = k + 1;
                 }
             }
+            bwd_phase2(pr, tpack, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
         }
-        if (cnt) bwd_phase2(pr, idx, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
         __syncthreads();
         // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM
         if (my_cb) {
