@@ -241,6 +241,9 @@ def main():
     # Two ways to use N GPUs.  With one or two views per GPU the Gaussians are sharded as well
     # (two all-to-alls of splat records instead of the gradient all-reduce, no replicated Adam); with more views per
     # GPU the records would outweigh the gradients, so the views are sharded and the parameters replicated.
+    # ST3R_BENCH_FREEZE=1 (tools/abl.sh): no optimizer step, so that kernel variants with deliberately broken
+    # gradients are all timed on the same scene; never set for a reported number
+    FREEZE = os.environ.get("ST3R_BENCH_FREEZE") == "1"
     mode = args.multi_gpu
     if mode == "auto":
         mode = "gaussian-sharded" if (world > 1 and C_local <= 2 and N % world == 0) else "replicated"
@@ -273,7 +276,8 @@ def main():
             st = ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1])
             if world > 1:
                 dist.all_reduce(grads)          # RCCL sum over ranks (views are sharded, loss is a sum over views)
-            ops.adam_step(ctx, P, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1)
+            if not FREEZE:
+                ops.adam_step(ctx, P, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1)
             return st
 
     for it in range(args.warmup):

@@ -38,9 +38,11 @@
 // with 3 or 4 workgroups per CU is 15-40 % slower, 7 or 8 are no faster).  PMC: 1.48 G VALU instructions per launch
 // (2.19 G for the per-record butterfly it replaces), the VALU pipes are busy for the whole kernel.
 //
-// Cost split of the backward at SYNTH-1M (ablation, tools/abl.sh): phase 1 + 2 arithmetic 1.6 ms, staging 0.7 ms,
-// slot writes + gather 0.9 ms (20 M writes to random 48-byte slots: bound by the number of accesses, not bytes --
-// dense writes plus an index indirection cost the same).  The file is compiled without packed-fp32 code generation.
+// Cost split of the backward at SYNTH-1M (ablations on a frozen scene, tools/abl.sh): phase 1 + 2 arithmetic
+// 1.25 ms, staging + flush 0.9 ms, gather 0.27 ms.  The non-arithmetic part is a per-workgroup chain of dependent
+// loads (id -> record, id -> slot base) behind barriers; it is neither shortened by more workgroups per CU nor by
+// denser writes (slots addressed by sorted position plus an index indirection, the stamp inside the slot, 64-byte
+// slots: all measured equal or slower).  The file is compiled without packed-fp32 code generation.
 //
 // Arithmetic note.  sigma is evaluated as P = dx*(qa*dx + qb*dy) + qc*dy*dy with
 // (qa,qb,qc) = -log2(e) * (a/2, b, c/2) folded at staging time, so exp(-sigma) = exp2(P) is

@@ -14,7 +14,7 @@ else
   cp starst3r_amd/libst3r_hip.so /tmp/orig.so
   for f in build_variants/v*.so; do
     echo "== $(cat ${f%.so}.txt)"; cp $f starst3r_amd/libst3r_hip.so
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+    ST3R_BENCH_FREEZE=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); s = d['roofline']['stage_ms']
 print('ms', round(d['ms_per_step'], 3), 'fwd', round(s['blend_fwd'], 3), 'bwd', round(s['blend_bwd'], 3))"
