@@ -109,19 +109,19 @@ __device__ __forceinline__ TileGeom tile_geom(int C, int W, int H, int tile_w, i
 
 // Stage record `id` into LDS slot t (q-form) and return the 4-bit quadrant relevance.
 // q-form of a record in LDS slot t (see the arithmetic note above); forward and backward stage through this one function
-__device__ __forceinline__ void stage_qform(const float4& a, const float4& b, const float4& c, int t, float4* sA,
-                                            float4* sB, float* sC) {
-    sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
-    sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
-    sC[t] = c.x;
+// LDS record: 3 x float4 = (x y opacity qa | qb qc r g | b - - -); one address register serves the three reads
+__device__ __forceinline__ void stage_qform(const float4& a, const float4& b, const float4& c, int t, float4* sR) {
+    sR[3 * t + 0] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
+    sR[3 * t + 1] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
+    sR[3 * t + 2] = make_float4(c.x, 0.f, 0.f, 0.f);
 }
 
 __device__ __forceinline__ int stage_record(const float4* __restrict__ splats, int64_t id, int t, int tx0, int ty0,
-                                            float4* sA, float4* sB, float* sC) {
+                                            float4* sR) {
     const float4 a = splats[id * 3 + 0];   // x y opacity conic.a
     const float4 b = splats[id * 3 + 1];   // conic.b conic.c r g
     const float4 c = splats[id * 3 + 2];   // b depth radius 0
-    stage_qform(a, b, c, t, sA, sB, sC);
+    stage_qform(a, b, c, t, sR);
     // A quadrant (8x8 pixel centres) is relevant iff the ellipse {sigma(p) <= tau}, tau = ln(255 opacity), reaches
     // it: either the mean lies inside, or the minimum of sigma over one of its four edges is <= tau (sigma is
     // convex, so the minimum over the square sits on the boundary when the mean is outside).  tau is inflated
@@ -152,16 +152,15 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                                                    int32_t* __restrict__ last_ids,
                                                    uint64_t* __restrict__ cmask, int64_t cmask_words,
                                                    int32_t* __restrict__ tile_nb, int no_cull) {
-    __shared__ float4 sA[BLK];  // x y opacity qa
-    __shared__ float4 sB[BLK];  // qb qc r g
-    __shared__ float sC[BLK];   // b
+    __shared__ float4 sR[BLK * 3];  // staged records (stage_qform)
     __shared__ uint64_t sMask[4][4];  // [quadrant][64-record chunk]
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Per-lane state is kept in VGPRs and updated with selects instead of branches: the scalar unit (one per
     // CU, shared by the 4 SIMDs) was the limiter of the branchy version (~38 SALU instructions of exec-mask
-    // bookkeeping per record; PMC: SQ_INSTS_SALU ~ SQ_INSTS_VALU).  `live` is 1.0 until the pixel saturates.
-    float live = g.inside ? 1.0f : 0.0f;
+    // bookkeeping per record; PMC: SQ_INSTS_SALU ~ SQ_INSTS_VALU).
+    // `thr` is the per-lane alpha threshold: 1/255 while the pixel is live, +inf once it saturated (or outside)
+    float thr = g.inside ? 1.f / 255.f : __builtin_inff();
     float T = 1.0f, r = 0.f, gg = 0.f, b = 0.f;
     int cur = 0;
     int nb = 0;
@@ -170,11 +169,11 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
 #endif
     const int64_t mbase = mask_base(g.lb, g.start);
     for (int bs = g.start; bs < g.end; bs += BLK, ++nb) {
-        if (__syncthreads_and(live == 0.0f)) break;
+        if (__syncthreads_and(thr > 1.0f)) break;
         const int idx = bs + threadIdx.x;
         int rel = 0;
         if (idx < g.end) {
-            rel = stage_record(splats, flat[idx], threadIdx.x, g.tx0, g.ty0, sA, sB, sC);
+            rel = stage_record(splats, flat[idx], threadIdx.x, g.tx0, g.ty0, sR);
             if (no_cull) rel = 0xF;   // test hook: every staged record is walked by every wave
         }
         const uint64_t m0 = __ballot(rel & 1), m1 = __ballot(rel & 2), m2 = __ballot(rel & 4), m3 = __ballot(rel & 8);
@@ -187,24 +186,24 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
         for (int jj = 0; jj < 4; ++jj) {
             uint64_t m = uniform_u64(sMask[w][jj]);
             uint64_t contributed = 0;
-            if (__builtin_amdgcn_ballot_w64(live != 0.0f) == 0) m = 0;  // every pixel of this wave is saturated
+            if (__builtin_amdgcn_ballot_w64(thr < 1.0f) == 0) m = 0;  // every pixel of this wave is saturated
             while (m) {
                 const int bit = __builtin_ctzll(m);
                 m &= m - 1;
                 const int t = jj * 64 + bit;
-                const float4 a = sA[t];
-                const float4 q = sB[t];
-                const float cb = sC[t];
+                const float4 a = sR[3 * t];
+                const float4 q = sR[3 * t + 1];
+                const float cb = sR[3 * t + 2].x;
                 const float dx = a.x - g.px, dy = a.y - g.py;
                 const float P = dx * (a.w * dx + q.x * dy) + q.y * dy * dy;
                 const float al0 = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
-                // skipped: sigma < 0, below the visibility threshold, or a saturated pixel -- three independent
-                // compares and one select instead of a chain of selects
-                const bool ok = !(P > 0.f) && !(al0 < 1.f / 255.f) && (live != 0.0f);
+                // skipped: sigma < 0, or below the lane's threshold (visibility for a live pixel, +inf for a
+                // saturated one) -- two independent compares and one select
+                const bool ok = !(P > 0.f) && !(al0 < thr);
                 float al = ok ? al0 : 0.f;
                 const float nT = T * (1.0f - al);        // == T exactly when al == 0
                 const bool stop = nT <= 1e-4f;           // only a live pixel with al > 0 can get here (T > 1e-4 otherwise)
-                live = stop ? 0.0f : live;
+                thr = stop ? __builtin_inff() : thr;
                 al = stop ? 0.0f : al;                   // the record that saturates the pixel is not blended
                 const float vis = al * T;
                 T = stop ? T : nT;
@@ -401,9 +400,11 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const int32_t* __restrict__ cum, int tight,
                                                    float* __restrict__ vtile, int32_t* __restrict__ vstamp,
                                                    int stamp) {
-    __shared__ float4 sA[HB];
-    __shared__ float4 sB[HB];
-    __shared__ float sC[HB];
+    // staged records, same q-form as the forward's but as three arrays (measured: the forward is faster with one
+    // 48-byte record per staged index, this kernel with the split layout)
+    __shared__ float4 sA[HB];   // x y opacity qa
+    __shared__ float4 sB[HB];   // qb qc r g
+    __shared__ float sC[HB];    // b
     __shared__ float sAccW[4][HB * ACC_VALS];             // per wave: the sums of the records it met this round
     __shared__ float2 sPair[4][CHUNK * PAIR_STRIDE];      // per wave: (g_o, fac) of CHUNK records x 64 pixels
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
@@ -458,7 +459,9 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             const float4 a = splats[my_id * 3 + 0];   // x y opacity conic.a
             const float4 b = splats[my_id * 3 + 1];   // conic.b conic.c r g
             const float4 c = splats[my_id * 3 + 2];   // b depth radius 0
-            stage_qform(a, b, c, t, sA, sB, sC);
+            sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
+            sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
+            sC[t] = c.x;
             const int64_t word = mbase + hb * HB_WORDS + (t >> 6);
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
