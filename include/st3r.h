@@ -312,6 +312,27 @@ int st3r_dense_clean(st3r_ctx* ctx, void* stream, int C, int max_view_pixels, co
                      float bad_conf, float* conf);
 
 /* ----------------------------------------------------------------------------------
+ * Canonical-data condensation: the arithmetic of Mast3r's prepare_canonical_data between the
+ * matching and the alignment, called from starster/reconstruct.py:101 (mast3r/cloud_opt/sparse_ga.py [U], not
+ * vendored by the reference).  All pointers are device pointers, float32.
+ * st3r_canon_view (canonical_view, mode 'avg-angle'): ptmaps [n,H,W,3] / confs [n,H,W] = the n predictions of an
+ *   image in its own frame -> canon [H,W,3] confidence-weighted mean (weights conf - 0.999), cconf [H,W] =
+ *   sum w^2 / sum w, canon2 [H,W] = depth of every pixel relative to its subsample-block centre from averaged
+ *   elevation angles.  H, W multiples of subsample.
+ * st3r_focal_weiszfeld (dust3r estimate_focal_knowing_depth, 'weiszfeld'): focal_out [1] on the device;
+ *   min_focal / max_focal are multiples of the 60-degree-FOV focal max(H,W) / (2 tan 30deg) (upstream 0.5 / 3.5).
+ * st3r_anchor_offsets (anchor_depth_offsets): xy [n,2] pixels of an image's correspondences -> idx_out int32 [n]
+ *   (index of the block's core depth, row-major over the (H/s, W/s) grid), off_out [n] = canon2(pixel) / canon2(block
+ *   centre).
+ * ---------------------------------------------------------------------------------- */
+int st3r_canon_view(st3r_ctx* ctx, void* stream, int n, int H, int W, int subsample, const float* ptmaps,
+                    const float* confs, float* canon, float* canon2, float* cconf);
+int st3r_focal_weiszfeld(st3r_ctx* ctx, void* stream, int H, int W, const float* canon, float ppx, float ppy,
+                         float min_focal, float max_focal, float* focal_out);
+int st3r_anchor_offsets(st3r_ctx* ctx, void* stream, int64_t n, int H, int W, int subsample, const float* canon2,
+                        const float* xy, int32_t* idx_out, float* off_out);
+
+/* ----------------------------------------------------------------------------------
  * Gaussian-sharded multi-GPU mode (an alternative to the gradient all-reduce when every rank owns one or two
  * views): rank r owns the Gaussians [r N/w, (r+1) N/w) -- parameters and Adam state are NOT replicated -- and
  * the views [r C, (r+1) C).  Per iteration:

@@ -1,0 +1,151 @@
+// SURVEY 8(f) row 2 -- canonical-data condensation between the matching (path A) and the alignment (path B):
+// what starster/reconstruct.py:101-106 gets from Mast3r's prepare_canonical_data / condense_data
+// (mast3r/cloud_opt/sparse_ga.py [U]: the submodule is not vendored in the reference tree; the formulas below
+// restate its published algorithm, oracle/condense_oracle.py is their CPU restatement).
+//
+//   k_canon_mean     per pixel: confidence-weighted mean of the n pointmaps an image got as "image 1" of a pair,
+//                    weights w = conf - 0.999;  cconf = sum w^2 / sum w                    (canonical_view [U])
+//   k_canon_angle    per pixel ('avg-angle' mode): inside its subsample x subsample block every prediction k gives
+//                    an elevation angle of the pixel relative to the block centre, atan((z - zc) / |xy - xyc|);
+//                    the angles are averaged with the weights, turned back into a depth at the mean radius and
+//                    stored relative to the canonical depth of the block centre:  canon2 = 1 + depth / canon_z(c)
+//   k_focal_weiszfeld  focal of a canonical pointmap given the principal point: closed-form L2 start, then 10
+//                    re-weighted least-squares steps (weights 1 / |pixel - f xy/z|), clipped to
+//                    [min_focal, max_focal] x the 60-degree-FOV focal      (dust3r estimate_focal_knowing_depth [U])
+//   k_anchor_offsets per correspondence pixel: index of its block's core depth and the pixel's canon2 relative to the
+//                    block centre's                                                         (anchor_depth_offsets [U])
+// The problems are small (n <= C-1 maps of 512 x 384): everything is HBM/latency bound and deterministic (fixed-order
+// sums); the focal solve is one workgroup.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void k_canon_mean(int n, int HW, const float* __restrict__ ptmaps,
+                                                    const float* __restrict__ confs, float* __restrict__ canon,
+                                                    float* __restrict__ cconf) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f, sw2 = 0.f;
+    for (int k = 0; k < n; ++k) {
+        const float w = confs[(int64_t)k * HW + p] - 0.999f;
+        const float* X = ptmaps + ((int64_t)k * HW + p) * 3;
+        sx += w * X[0]; sy += w * X[1]; sz += w * X[2];
+        sw += w; sw2 += w * w;
+    }
+    canon[3 * p + 0] = sx / sw; canon[3 * p + 1] = sy / sw; canon[3 * p + 2] = sz / sw;
+    cconf[p] = sw2 / sw;
+}
+
+__global__ __launch_bounds__(256) void k_canon_angle(int n, int H, int W, int S, const float* __restrict__ ptmaps,
+                                                     const float* __restrict__ confs,
+                                                     const float* __restrict__ canon, float* __restrict__ canon2) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int HW = H * W;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const int c = ((y / S) * S + S / 2) * W + (x / S) * S + S / 2;   // block centre
+    float sa = 0.f, sw = 0.f, sr = 0.f;
+    for (int k = 0; k < n; ++k) {
+        const float* Xp = ptmaps + ((int64_t)k * HW + p) * 3;
+        const float* Xc = ptmaps + ((int64_t)k * HW + c) * 3;
+        const float zc = fmaxf(Xc[2], 1.1920928955078125e-07f);    // clip(min = finfo(float32).eps)
+        const float dx = Xp[0] - Xc[0], dy = Xp[1] - Xc[1];
+        const float r = fmaxf(sqrtf(dx * dx + dy * dy), 1e-8f);
+        const float ang = atanf((Xp[2] - zc) / r);
+        const float w = confs[(int64_t)k * HW + p] - 0.999f;
+        sa += w * ang; sw += w; sr += r;
+    }
+    const float depth = (sr / (float)n) * tanf(sa / sw);
+    canon2[p] = 1.0f + depth / canon[3 * c + 2];
+}
+
+#define FT 1024
+__device__ __forceinline__ float block_sum_ft(float v, float* red) {
+    // fixed-order tree over the workgroup
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = FT / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float t = red[0];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(FT) void k_focal_weiszfeld(int H, int W, const float* __restrict__ canon, float ppx,
+                                                        float ppy, float min_focal, float max_focal,
+                                                        float* __restrict__ focal_out) {
+    __shared__ float red[FT];
+    const int HW = H * W;
+    // pass 0: closed form  f = mean(xy/z . pixel) / mean(|xy/z|^2);  passes 1..10: the same with weights 1 / distance
+    float focal = 0.f;
+    for (int it = 0; it <= 10; ++it) {
+        float num = 0.f, den = 0.f;
+        for (int p = threadIdx.x; p < HW; p += FT) {
+            const int y = p / W, x = p - y * W;
+            const float u = (float)x - ppx, v = (float)y - ppy;
+            const float z = canon[3 * p + 2];
+            float a = canon[3 * p] / z, b = canon[3 * p + 1] / z;
+            if (!(fabsf(a) <= 3.4028234663852886e+38f)) a = 0.f;   // nan_to_num(nan = 0, posinf = 0, neginf = 0)
+            if (!(fabsf(b) <= 3.4028234663852886e+38f)) b = 0.f;
+            const float dpx = a * u + b * v, dxx = a * a + b * b;
+            float w = 1.f;
+            if (it > 0) {
+                const float eu = u - focal * a, ev = v - focal * b;
+                w = 1.0f / fmaxf(sqrtf(eu * eu + ev * ev), 1e-8f);
+            }
+            num += w * dpx; den += w * dxx;
+        }
+        const float N = block_sum_ft(num, red), D = block_sum_ft(den, red);
+        focal = (N / (float)HW) / (D / (float)HW);
+    }
+    if (threadIdx.x == 0) {
+        const float base = (float)max(H, W) / (2.0f * 0.57735026918962576f);   // 2 tan(30 deg)
+        focal_out[0] = fminf(fmaxf(focal, min_focal * base), max_focal * base);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_anchor_offsets(int64_t n, int H, int W, int S,
+                                                        const float* __restrict__ canon2,
+                                                        const float* __restrict__ xy, int32_t* __restrict__ idx_out,
+                                                        float* __restrict__ off_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int px = (int)xy[2 * i], py = (int)xy[2 * i + 1];     // .long(): truncation
+    const int bx = px / S, by = py / S, W2 = (W - S / 2 + S - 1) / S;   // len(range(S/2, W, S))
+    idx_out[i] = by * W2 + bx;
+    const float ref = canon2[(by * S + S / 2) * W + bx * S + S / 2];
+    off_out[i] = canon2[py * W + px] / ref;
+}
+
+ST3R_EXPORT int st3r_canon_view(st3r_ctx* ctx, void* stream, int n, int H, int W, int subsample, const float* ptmaps,
+                                const float* confs, float* canon, float* canon2, float* cconf) {
+    ARG_CHECK(ctx && n > 0 && H > 0 && W > 0 && subsample > 0 && H % subsample == 0 && W % subsample == 0);
+    ARG_CHECK(ptmaps && confs && canon && canon2 && cconf);
+    const int HW = H * W;
+    hipLaunchKernelGGL(k_canon_mean, dim3(ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, n, HW, ptmaps, confs,
+                       canon, cconf);
+    hipLaunchKernelGGL(k_canon_angle, dim3(ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, n, H, W, subsample,
+                       ptmaps, confs, canon, canon2);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_focal_weiszfeld(st3r_ctx* ctx, void* stream, int H, int W, const float* canon, float ppx,
+                                     float ppy, float min_focal, float max_focal, float* focal_out) {
+    ARG_CHECK(ctx && H > 0 && W > 0 && canon && focal_out && min_focal > 0.f && max_focal >= min_focal);
+    hipLaunchKernelGGL(k_focal_weiszfeld, dim3(1), dim3(FT), 0, (hipStream_t)stream, H, W, canon, ppx, ppy, min_focal,
+                       max_focal, focal_out);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_anchor_offsets(st3r_ctx* ctx, void* stream, int64_t n, int H, int W, int subsample,
+                                    const float* canon2, const float* xy, int32_t* idx_out, float* off_out) {
+    ARG_CHECK(ctx && n >= 0 && H > 0 && W > 0 && subsample > 0 && canon2);
+    if (n == 0) return ST3R_OK;
+    ARG_CHECK(xy && idx_out && off_out);
+    hipLaunchKernelGGL(k_anchor_offsets, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n, H, W, subsample,
+                       canon2, xy, idx_out, off_out);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}

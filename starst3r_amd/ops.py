@@ -238,6 +238,36 @@ def dense_clean(ctx, view_start, sizes_hw, cam_rows, pts, zcam, conf, tol=0.001,
     return out
 
 
+def canon_view(ctx, ptmaps, confs, subsample):
+    """Mast3r canonical_view(mode='avg-angle') [U]: ptmaps [n,H,W,3], confs [n,H,W] -> canon [H,W,3], canon2 [H,W],
+    cconf [H,W]."""
+    n, H, W = confs.shape
+    canon = torch.empty((H, W, 3), device=confs.device); canon2 = torch.empty((H, W), device=confs.device)
+    cconf = torch.empty((H, W), device=confs.device)
+    _lib.check(_lib.lib().st3r_canon_view(ctx.handle, _stream(), n, H, W, subsample, _p(ptmaps), _p(confs), _p(canon),
+                                          _p(canon2), _p(cconf)))
+    return canon, canon2, cconf
+
+
+def focal_weiszfeld(ctx, canon, pp, min_focal=0.5, max_focal=3.5):
+    """dust3r estimate_focal_knowing_depth(focal_mode='weiszfeld') [U] -> tensor [1] on the device."""
+    H, W = canon.shape[:2]
+    out = torch.empty(1, device=canon.device)
+    _lib.check(_lib.lib().st3r_focal_weiszfeld(ctx.handle, _stream(), H, W, _p(canon), float(pp[0]), float(pp[1]),
+                                               min_focal, max_focal, _p(out)))
+    return out
+
+
+def anchor_offsets(ctx, canon2, xy, subsample):
+    """Mast3r anchor_depth_offsets [U] for one list of correspondence pixels xy [n,2] -> (idx int32 [n], off [n])."""
+    H, W = canon2.shape
+    n = xy.shape[0]
+    idx = torch.empty(n, dtype=torch.int32, device=canon2.device); off = torch.empty(n, device=canon2.device)
+    _lib.check(_lib.lib().st3r_anchor_offsets(ctx.handle, _stream(), n, H, W, subsample, _p(canon2), _p(xy),
+                                              _p(idx, torch.int32), _p(off)))
+    return idx, off
+
+
 def raster_train(ctx, records, N, Cn, gt, W, H, ssim_fac, v_records, loss_out):
     """Middle phase of the Gaussian-sharded mode: records [Cn*N,12] of ALL Gaussians for this rank's views ->
     v_records (same shape), this rank's image loss."""

@@ -7,13 +7,16 @@ What runs where:
   * pairwise inference (the Mast3r ViT) stays on PyTorch-ROCm and is supplied by `model`;
   * reciprocal-NN matching (path A) -> starst3r_amd.matching (MFMA kernel);
   * global alignment (path B)       -> starst3r_amd.align   (fused HIP optimiser);
-  * the condensation between them (canonical pointmaps, MST, anchors; Mast3r prepare_canonical_data /
-    condense_data) is a "next" row: `model` must provide it for now, see below.
+  * the condensation between them (canonical pointmaps, focals, MST, anchors; Mast3r prepare_canonical_data /
+    compute_min_spanning_tree / condense_data) -> starst3r_amd.condense (HIP kernels + host lists).
 
 Model protocol.  The Mast3r package is not vendored by the reference (empty submodule) and its weights
-cannot be fetched offline, so `model` is any object with
+cannot be fetched offline, so `model` is any object with either
+      model.forward_pairs(imgs, filelist, device, cache_dir) -> (tmp_pairs, images)
+the per-pair cache of Mast3r's forward_mast3r (see starst3r_amd.condense for the layout; tensors or torch.save
+paths) plus the resized images -- condensation and alignment then run here --, or
       model.condense(imgs, filelist, device, cache_dir) -> dict
-returning the condensed problem in starst3r_amd.synth_align.flatten() layout plus
+returning the already condensed problem in starst3r_amd.synth_align.flatten() layout plus
       "imgs": list of HxWx3 float arrays in [0,1] (the Mast3r-resized GT images),
       "dense": optional per-view dict(pixels [n,2], idxs [n], offsets [n], confs [n], base_focal) -- the dense
                pixels as anchors of the view's core depthmap (dense unprojection).
@@ -57,7 +60,9 @@ class SparseGAResult:
         ctx = ops.get_context(dev)
         counts = [len(d["idxs"]) for d in self._dense]
         start = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32, device=dev)
-        cat = lambda key, dt: torch.cat([torch.as_tensor(np.asarray(d[key]), dtype=dt) for d in self._dense]).to(dev).contiguous()
+        def cat(key, dt):   # numpy arrays or tensors (host or device), one entry per view
+            return torch.cat([(d[key] if torch.is_tensor(d[key]) else torch.as_tensor(np.asarray(d[key]))).to(
+                device=dev, dtype=dt) for d in self._dense]).contiguous()
         pix, idx, off, conf = cat("pixels", torch.float32), cat("idxs", torch.int32), cat("offsets", torch.float32), \
             cat("confs", torch.float32)
         pts, z = ops.dense_unproject(ctx, start, pix, idx, off, self._res["_core"], self._res["_cam_rows"],
@@ -212,6 +217,13 @@ def reconstruct_scene(model, imgs, filelist, device, optim_params=None, tmpdir=N
     (starster/reconstruct.py:19-72)."""
     if tmpdir is None:
         tmpdir = tempfile.mkdtemp()
+    if hasattr(model, "forward_pairs"):
+        from . import condense as _condense
+        tmp_pairs, images = model.forward_pairs(imgs, filelist, device, tmpdir)
+        condensed = _condense.condense(list(filelist), tmp_pairs, getattr(model, "subsample", 8), device=device,
+                                       with_dense=True)
+        condensed["imgs"] = images
+        return run_sparse_ga(condensed, device=device, optim_params=optim_params)
     if hasattr(model, "condense"):
         condensed = model.condense(imgs, filelist, device, tmpdir)
         return run_sparse_ga(condensed, device=device, optim_params=optim_params)

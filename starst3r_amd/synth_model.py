@@ -45,3 +45,36 @@ class SyntheticPairwiseModel:
         flat["imgs"] = out_imgs
         flat["dense"] = dense
         return flat
+
+
+class SyntheticPairModel:
+    """The other model protocol of starst3r_amd.reconstruct: `forward_pairs` hands over what Mast3r's forward_mast3r
+    caches per image pair (pointmaps, confidences, correspondences -- starst3r_amd.synth_pairs) and leaves the
+    condensation (starst3r_amd.condense) and the alignment to the library."""
+    subsample = 8
+
+    def __init__(self, width=256, height=192, n_corr=1500, seed=0):
+        self.width, self.height, self.n_corr, self.seed = width, height, n_corr, seed
+
+    def forward_pairs(self, imgs, filelist, device, cache_dir):
+        from . import synth_pairs
+        W, H = self.width, self.height
+        P = synth_pairs.make_pair_predictions(len(imgs), W, H, self.subsample, seed=self.seed, n_corr=self.n_corr)
+        names = list(filelist)
+        ren = dict(zip(P["imgs"], names))
+        tmp_pairs = {(ren[a], ren[b]): v for (a, b), v in P["pairs"].items()}
+        f = P["focal_true"]
+        ys, xs = np.mgrid[0:H, 0:W]
+        rays = np.stack([(xs - W / 2) / f, (ys - H / 2) / f, np.ones((H, W))], -1).reshape(-1, 3)
+        images = []
+        for v in range(len(imgs)):
+            c2w = P["c2w_true"][v].astype(np.float64)
+            d = rays @ c2w[:3, :3].T; o = c2w[:3, 3]
+            b = d @ o; a = (d * d).sum(-1); cc = o @ o - 1.0
+            disc = b * b - a * cc
+            hit = disc > 0
+            t = np.where(hit, (-b - np.sqrt(np.maximum(disc, 0))) / a, 3.5)
+            pw = o + d * t[:, None]
+            tex = 0.5 + 0.5 * np.stack([np.sin(4 * pw[:, 0] + 1), np.sin(5 * pw[:, 1] + 2), np.sin(3 * pw[:, 2])], -1)
+            images.append(np.where(hit[:, None], tex, 0.35).reshape(H, W, 3).astype(np.float32))
+        return tmp_pairs, images

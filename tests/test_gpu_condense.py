@@ -1,0 +1,156 @@
+"""SURVEY 8(f) row 2 on the GPU: the condensation kernels against the CPU oracle (oracle/condense_oracle.py -- the
+restatement of the un-vendored upstream, parity unpinned against Mast3r itself) and the whole chain
+pair predictions -> condensation -> alignment against the geometric ground truth of the synthetic scene."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import condense_oracle as co
+from starst3r_amd import synth_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from starst3r_amd import ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return ops.get_context("cuda:0")
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda:0")
+
+
+def maps_of(P, img):
+    pt, cf = [], []
+    for (a, b), ((p1, p2), _c) in P["pairs"].items():
+        if a == img:
+            pt.append(p1[0]); cf.append(p1[1])
+        elif b == img:
+            pt.append(p2[0]); cf.append(p2[1])
+    return np.stack(pt), np.stack(cf)
+
+
+@pytest.mark.parametrize("views,W,H,S", [(2, 64, 48, 8), (4, 128, 96, 8), (3, 96, 64, 16)])
+def test_canonical_view_focal_anchors_vs_oracle(ctx, views, W, H, S):
+    from starst3r_amd import ops
+    P = synth_pairs.make_pair_predictions(views, W, H, subsample=S, seed=views, n_corr=400)
+    for img in P["imgs"][:2]:
+        X, Cf = maps_of(P, img)
+        canon_o, canon2_o, cconf_o = co.canonical_view(X, Cf, S)
+        canon, canon2, cconf = ops.canon_view(ctx, dev(X), dev(Cf), S)
+        assert np.allclose(canon.cpu().numpy(), canon_o, rtol=1e-5, atol=1e-6)
+        assert np.allclose(cconf.cpu().numpy(), cconf_o, rtol=1e-5)
+        # atan / tan of the device library against numpy's: 1e-4 relative (north_star tolerance for floats)
+        assert np.allclose(canon2.cpu().numpy(), canon2_o, rtol=1e-4, atol=1e-5)
+        f = float(ops.focal_weiszfeld(ctx, canon, (W / 2, H / 2))[0])
+        f_o = float(co.estimate_focal_knowing_depth(canon_o, (W / 2, H / 2)))
+        assert abs(f - f_o) <= 1e-4 * f_o
+        assert abs(f - P["focal_true"]) < 0.02 * P["focal_true"]
+        rng = np.random.default_rng(0)
+        xy = np.stack([rng.integers(0, W, 500), rng.integers(0, H, 500)], -1).astype(np.float32)
+        idx, off = ops.anchor_offsets(ctx, dev(canon2_o), dev(xy), S)
+        idx_o, off_o = co.anchor_depth_offsets(canon2_o, xy, S)
+        assert np.array_equal(idx.cpu().numpy(), idx_o)            # integer work: bit exact
+        assert np.allclose(off.cpu().numpy(), off_o, rtol=1e-6)
+
+
+def test_focal_clip(ctx):
+    from starst3r_amd import ops
+    P = synth_pairs.make_pair_predictions(2, 64, 48, seed=5, n_corr=50)
+    X, Cf = maps_of(P, "0.png")
+    canon, _, _ = ops.canon_view(ctx, dev(X), dev(Cf), 8)
+    base = 64 / (2 * np.tan(np.deg2rad(30)))
+    lo = ops.focal_weiszfeld(ctx, (canon * dev([10, 10, 1])).contiguous(), (32, 24))
+    hi = ops.focal_weiszfeld(ctx, (canon * dev([0.01, 0.01, 1])).contiguous(), (32, 24))
+    assert float(lo[0]) == pytest.approx(0.5 * base, rel=1e-6) and float(hi[0]) == pytest.approx(3.5 * base, rel=1e-6)
+
+
+def test_condense_structure_matches_oracle_functions(ctx):
+    """prepare_canonical_data / condense_data: same structure as upstream, contents equal to the oracle's per image."""
+    from starst3r_amd import condense
+    P = synth_pairs.make_pair_predictions(3, 128, 96, seed=7, n_corr=300)
+    imgs, S = P["imgs"], P["subsample"]
+    _, scores, views, _, preds_21 = condense.prepare_canonical_data(imgs, P["pairs"], S)
+    s = scores.cpu().numpy()
+    assert np.array_equal(s, s.T) and all(s[i, j] == len(P["pairs"][(imgs[i], imgs[j])][1][1][2])
+                                          for i in range(3) for j in range(i + 1, 3))
+    assert condense.compute_min_spanning_tree(scores) == co.compute_min_spanning_tree(s)
+    for img in imgs:
+        pp, (H, W), focal, core, pixels, idxs, offs = views[img]
+        X, Cf = maps_of(P, img)
+        canon_o, canon2_o, _ = co.canonical_view(X, Cf, S)
+        assert (H, W) == (96, 128) and np.allclose(pp.cpu().numpy(), [64, 48])
+        assert np.allclose(core.cpu().numpy(), canon_o[S // 2::S, S // 2::S, 2], rtol=1e-5)
+        assert set(pixels) == set(imgs) - {img}
+        for other, (xy, cf) in pixels.items():
+            idx_o, off_o = co.anchor_depth_offsets(canon2_o, xy.cpu().numpy(), S)
+            assert np.array_equal(idxs[other].cpu().numpy(), idx_o)
+            assert np.allclose(offs[other].cpu().numpy(), off_o, rtol=2e-4)
+            assert preds_21[img][other][0].shape == ((96 // S) * (128 // S), 3)
+    imsizes, pps, focals, core_depth, anchors, corres, corres2d, sub = condense.condense_data(imgs, P["pairs"], views,
+                                                                                              preds_21)
+    assert imsizes.tolist() == [[128, 96]] * 3 and focals.shape == (3,) and len(core_depth) == 3
+    n_pairs = len(P["pairs"])
+    assert len(corres[2]) == 2 * n_pairs        # both orders (reconstruct.py:286,299)
+    for sl in corres[2]:
+        n1 = sl.slice1.stop - sl.slice1.start
+        assert n1 == sl.slice2.stop - sl.slice2.start == len(sl.confs)
+    for v in range(3):
+        assert len(anchors[v][0]) == len(anchors[v][1]) == len(anchors[v][2]) == corres2d[v][1].shape[0]
+        for other in set(imgs) - {imgs[v]}:
+            assert sub[other][imgs[v]][0].shape[0] == len(anchors[v][1])   # fallback targets follow img1's anchors
+
+
+def _similarity(A, B):
+    """least-squares similarity (Umeyama) mapping points A -> B; returns s, R, t."""
+    ma, mb = A.mean(0), B.mean(0)
+    Ac, Bc = A - ma, B - mb
+    U, D, Vt = np.linalg.svd(Bc.T @ Ac / len(A))
+    S = np.eye(3); S[2, 2] = np.sign(np.linalg.det(U) * np.linalg.det(Vt))
+    R = U @ S @ Vt
+    s = np.trace(np.diag(D) @ S) / (Ac ** 2).sum() * len(A)
+    return s, R, mb - s * R @ ma
+
+
+def test_pairs_to_poses_end_to_end(ctx):
+    """pair predictions -> condensation -> st3r_align_run: camera centres, orientations and focals of the synthetic
+    scene are recovered up to the global similarity the problem leaves free."""
+    from starst3r_amd import align, condense
+    P = synth_pairs.make_pair_predictions(4, 256, 192, seed=3, n_corr=1500)
+    flat = condense.condense(P["imgs"], P["pairs"], P["subsample"])
+    res, _ = align.run(flat)
+    c2w = res["cam2w"].cpu().numpy().astype(np.float64); K = res["intrinsics"].cpu().numpy()
+    gt = P["c2w_true"].astype(np.float64)
+    s, R, t = _similarity(c2w[:, :3, 3], gt[:, :3, 3])
+    centres = (s * (R @ c2w[:, :3, 3].T)).T + t
+    baseline = np.linalg.norm(gt[0, :3, 3] - gt[1, :3, 3])
+    assert np.abs(centres - gt[:, :3, 3]).max() < 0.05 * baseline
+    for v in range(4):
+        Rv = R @ c2w[v, :3, :3]
+        ang = np.degrees(np.arccos(np.clip((np.trace(Rv.T @ gt[v, :3, :3]) - 1) / 2, -1, 1)))
+        assert ang < 1.5, (v, ang)
+        assert abs(K[v, 0, 0] - P["focal_true"]) < 0.03 * P["focal_true"]
+    L = res["losses"].cpu().numpy()
+    assert np.all(np.isfinite(L)) and L[499] < L[0]
+
+
+def test_scene_from_pair_predictions():
+    """Scene.add_images with a model that only supplies pair predictions: condensation, alignment, dense seeding and
+    a few 3DGS iterations all run in the library; the seeded points lie on the synthetic unit sphere."""
+    import starst3r_amd as st
+    from starst3r_amd.synth_model import SyntheticPairModel
+    sc = st.Scene(device="cuda:0")
+    sc.add_images(SyntheticPairModel(width=128, height=96, n_corr=600, seed=4), [torch.zeros(3, 96, 128)] * 3)
+    n = sum(p.shape[0] for p in sc.dense_pts)
+    assert 0 < n < 3 * 96 * 128
+    P = sc.dense_pts_flat.double().cpu().numpy()
+    A = np.concatenate([2 * P, np.ones((len(P), 1))], 1)               # |p|^2 = 2 p.c + (r^2 - |c|^2)
+    sol, *_ = np.linalg.lstsq(A, (P * P).sum(1), rcond=None)
+    c = sol[:3]; r = np.sqrt(sol[3] + c @ c)
+    assert np.abs(np.linalg.norm(P - c, axis=1) - r).mean() / r < 0.05
+    sc.init_3dgs()
+    losses = sc.run_3dgs_optim(20, enable_pruning=False, verbose=False)
+    if losses is not None:
+        assert np.all(np.isfinite(np.asarray(losses)))
