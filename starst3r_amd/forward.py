@@ -1,0 +1,88 @@
+"""Pairwise inference bookkeeping, matching and the on-disk pair cache -- what the reference gets from Mast3r's
+`forward_mast3r` at starster/reconstruct.py:97 (mast3r/cloud_opt/sparse_ga.py [U], not vendored): for every unordered
+image pair the network runs symmetrically (the ViT itself stays the model's business), the four descriptor maps are
+matched with reciprocal nearest neighbours (path A: st3r_recip_nn, MFMA kernel) and everything is `torch.save`d under
+`cache_path` with the upstream file layout
+
+    forward/<md5 img1>/<md5 img2>.pth                 (X11, C11, X21, C21)   pointmaps / confidences, frame of img1
+    forward/<md5 img2>/<md5 img1>.pth                 (X22, C22, X12, C12)
+    corres_conf=<desc_conf>_subsample=<s>/<md5 1>-<md5 2>.pth   ((conf score, sum of confs, count), (xy1, xy2, confs))
+
+so that a second call with more images (Scene.add_images, starster/scene.py:117-122: the file names are the fake
+"0.png", "1.png", ...) only infers the new pairs.  SURVEY 8(f) row 4 (pair cache) and the caller side of path A.
+
+Model protocol: `model.symmetric_inference(img1, img2, device)` -> (res11, res21, res22, res12), dicts with
+'pts3d' [1,H,W,3], 'conf' [1,H,W], 'desc' [1,H,W,D], 'desc_conf' [1,H,W] like Mast3r's heads."""
+import hashlib
+import os
+
+import torch
+
+from . import matching
+
+
+def hash_md5(s):
+    return hashlib.md5(s.encode("utf-8")).hexdigest()
+
+
+def _mkdir_for(path):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    return path
+
+
+def extract_correspondences(feats, qonfs, subsample=8, device="cuda:0"):
+    """Mast3r extract_correspondences [U]: reciprocal matches of (desc11, desc21) and of (desc12, desc22), both
+    directions each, merged; confidence = sqrt(qonf1 qonf2) at the matched pixels."""
+    feat11, feat21, feat22, feat12 = feats
+    qonf11, qonf21, qonf22, qonf12 = qonfs
+    assert feat11.shape[:2] == feat12.shape[:2] == qonf11.shape == qonf12.shape
+    assert feat21.shape[:2] == feat22.shape[:2] == qonf21.shape == qonf22.shape
+    idx1, idx2, q1, q2 = [], [], [], []
+    for A, B, QA, QB in ((feat11, feat21, qonf11, qonf21), (feat12, feat22, qonf12, qonf22)):
+        a12, b12 = matching.fast_reciprocal_NNs(A, B, subsample_or_initxy1=subsample, ret_xy=False, device=device)
+        b21, a21 = matching.fast_reciprocal_NNs(B, A, subsample_or_initxy1=subsample, ret_xy=False, device=device)
+        i1 = torch.cat([a12, a21]).long(); i2 = torch.cat([b12, b21]).long()
+        idx1.append(i1); idx2.append(i2)
+        q1.append(QA.reshape(-1).to(i1.device)[i1]); q2.append(QB.reshape(-1).to(i2.device)[i2])
+    H1, W1 = feat11.shape[:2]; H2, W2 = feat22.shape[:2]
+    xy1, xy2, index = matching.merge_corres(torch.cat(idx1), torch.cat(idx2), (H1, W1), (H2, W2), ret_xy=True,
+                                            ret_index=True)
+    confs = (torch.cat(q1)[index] * torch.cat(q2)[index]).sqrt()
+    return xy1.float(), xy2.float(), confs
+
+
+def forward_mast3r(pairs, model, cache_path, desc_conf="desc_conf", device="cuda:0", subsample=8, **matching_kw):
+    """pairs: iterable of (img1, img2) dicts with 'instance' (Mast3r's pair list).  Returns (res_paths, cache_path)
+    with res_paths[(instance1, instance2)] = ((path1, path2), path_corres) -- the `tmp_pairs` of
+    prepare_canonical_data.  Pairs already in the cache (in either order) are not inferred again."""
+    res_paths = {}
+    for img1, img2 in pairs:
+        n1, n2 = img1["instance"], img2["instance"]
+        if (n2, n1) in res_paths or (n1, n2) in res_paths:
+            continue   # the symmetrized list holds both orders; one symmetric inference serves both
+        i1, i2 = hash_md5(n1), hash_md5(n2)
+        path1 = os.path.join(cache_path, "forward", i1, i2 + ".pth")
+        path2 = os.path.join(cache_path, "forward", i2, i1 + ".pth")
+        cdir = os.path.join(cache_path, f"corres_conf={desc_conf}_subsample={subsample}")
+        path_corres = os.path.join(cdir, f"{i1}-{i2}.pth")
+        path_corres2 = os.path.join(cdir, f"{i2}-{i1}.pth")
+        if os.path.isfile(path_corres2) and not os.path.isfile(path_corres):
+            score, (xy1, xy2, confs) = torch.load(path_corres2)
+            torch.save((score, (xy2, xy1, confs)), _mkdir_for(path_corres))
+        if not all(os.path.isfile(p) for p in (path1, path2, path_corres)):
+            if model is None:
+                continue
+            res = model.symmetric_inference(img1, img2, device)
+            X11, X21, X22, X12 = [r["pts3d"][0] for r in res]
+            C11, C21, C22, C12 = [r["conf"][0] for r in res]
+            descs = [r["desc"][0] for r in res]
+            qonfs = [r[desc_conf][0] for r in res]
+            cpu = lambda ts: tuple(t.detach().cpu() for t in ts)
+            torch.save(cpu((X11, C11, X21, C21)), _mkdir_for(path1))
+            torch.save(cpu((X22, C22, X12, C12)), _mkdir_for(path2))
+            corres = extract_correspondences(descs, qonfs, subsample=subsample, device=device)
+            conf_score = (C11.mean() * C12.mean() * C21.mean() * C22.mean()).sqrt().sqrt()
+            score = (float(conf_score), float(corres[2].sum()), len(corres[2]))
+            torch.save((score, cpu(corres)), _mkdir_for(path_corres))
+        res_paths[n1, n2] = (path1, path2), path_corres
+    return res_paths, cache_path

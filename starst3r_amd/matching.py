@@ -25,17 +25,24 @@ def nn_dot_argmax(ctx, queries, db, want_score=False):
     return (nn, score) if want_score else nn
 
 
-def merge_corres(idx1, idx2, shape1=None, shape2=None, ret_xy=True):
-    """unique correspondences sorted on (idx2, idx1) packed as one int64 -- Mast3r merge_corres."""
+def merge_corres(idx1, idx2, shape1=None, shape2=None, ret_xy=True, ret_index=False):
+    """unique correspondences sorted on (idx2, idx1) packed as one int64 -- Mast3r merge_corres; ret_index adds the
+    position of the first occurrence of every kept pair in the input (numpy.unique(return_index=True))."""
     key = (idx2.to(torch.int64) & 0xFFFFFFFF) | (idx1.to(torch.int64) << 32)  # little endian view of np.c_[idx2, idx1]
-    key = torch.unique(key)  # sorted
+    if ret_index:
+        key, order = torch.sort(key, stable=True)
+        first = torch.ones_like(key, dtype=torch.bool)
+        first[1:] = key[1:] != key[:-1]
+        key, index = key[first], order[first]
+    else:
+        key = torch.unique(key)  # sorted
     i2 = (key & 0xFFFFFFFF).to(torch.int32); i1 = (key >> 32).to(torch.int32)
+    out = (i1, i2)
     if ret_xy and shape1 is not None:
         W1, W2 = shape1[1], shape2[1]
-        xy1 = torch.stack((i1 % W1, torch.div(i1, W1, rounding_mode="floor")), dim=-1)
-        xy2 = torch.stack((i2 % W2, torch.div(i2, W2, rounding_mode="floor")), dim=-1)
-        return xy1, xy2
-    return i1, i2
+        out = (torch.stack((i1 % W1, torch.div(i1, W1, rounding_mode="floor")), dim=-1),
+               torch.stack((i2 % W2, torch.div(i2, W2, rounding_mode="floor")), dim=-1))
+    return out + (index,) if ret_index else out
 
 
 def fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, ret_xy=True, pixel_tol=0, ret_basin=False, device="cuda",

@@ -11,7 +11,10 @@ What runs where:
     compute_min_spanning_tree / condense_data) -> starst3r_amd.condense (HIP kernels + host lists).
 
 Model protocol.  The Mast3r package is not vendored by the reference (empty submodule) and its weights
-cannot be fetched offline, so `model` is any object with either
+cannot be fetched offline, so `model` is any object with one of
+      model.symmetric_inference(img1, img2, device) -> (res11, res21, res22, res12)
+the network alone (head outputs 'pts3d', 'conf', 'desc', 'desc_conf' per pair, like Mast3r's symmetric_inference):
+pair list, reciprocal matching, the resumable disk cache (starst3r_amd.forward), condensation and alignment run here;
       model.forward_pairs(imgs, filelist, device, cache_dir) -> (tmp_pairs, images)
 the per-pair cache of Mast3r's forward_mast3r (see starst3r_amd.condense for the layout; tensors or torch.save
 paths) plus the resized images -- condensation and alignment then run here --, or
@@ -217,6 +220,20 @@ def reconstruct_scene(model, imgs, filelist, device, optim_params=None, tmpdir=N
     (starster/reconstruct.py:19-72)."""
     if tmpdir is None:
         tmpdir = tempfile.mkdtemp()
+    if hasattr(model, "symmetric_inference"):
+        # the network only: pair bookkeeping, matching (path A), the disk cache, condensation and alignment run here
+        from . import condense as _condense
+        from .forward import forward_mast3r
+        from .image import make_pair_indices, prepare_images_for_mast3r
+        views = prepare_images_for_mast3r(imgs)
+        for v in views:
+            v["instance"] = filelist[v["idx"]]                      # convert_dust3r_pairs_naming (reconstruct.py:95)
+        pairs = [(views[i], views[j]) for i, j in make_pair_indices(len(views), symmetric=True)]
+        sub = getattr(model, "subsample", 8)
+        tmp_pairs, _ = forward_mast3r(pairs, model, tmpdir, device=device, subsample=sub)
+        condensed = _condense.condense(list(filelist), tmp_pairs, sub, device=device, with_dense=True)
+        condensed["imgs"] = [((im.detach().float().cpu().permute(1, 2, 0) + 1) / 2).clamp(0, 1).numpy() for im in imgs]
+        return run_sparse_ga(condensed, device=device, optim_params=optim_params)
     if hasattr(model, "forward_pairs"):
         from . import condense as _condense
         tmp_pairs, images = model.forward_pairs(imgs, filelist, device, tmpdir)

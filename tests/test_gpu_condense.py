@@ -154,3 +154,29 @@ def test_scene_from_pair_predictions():
     losses = sc.run_3dgs_optim(20, enable_pruning=False, verbose=False)
     if losses is not None:
         assert np.all(np.isfinite(np.asarray(losses)))
+
+
+def test_network_only_model_with_resumable_pair_cache(tmp_path):
+    """The model is the network alone: pair list, reciprocal matching of the descriptor maps (st3r_recip_nn), the disk
+    cache with Mast3r's file layout, condensation and alignment run in the library.  Adding an image re-uses the
+    cached pairs (starster/scene.py:117-122, main.py:49-50): only the new pairs are inferred."""
+    import os
+    import starst3r_amd as st
+    from starst3r_amd.synth_model import SyntheticNetwork
+    net = SyntheticNetwork(n_views=4, width=128, height=96, seed=1)
+    views = net.images()
+    sc = st.Scene(device="cuda:0", cache_dir=str(tmp_path))
+    sc.add_images(net, views[:3])
+    assert net.calls == 3                                   # 3 unordered pairs, one symmetric inference each
+    files = [f for _r, _d, fs in os.walk(tmp_path) for f in fs]
+    assert len(files) == 9                                  # 2 forward files + 1 correspondence file per pair
+    c2w3 = sc.c2w.clone() if torch.is_tensor(sc.c2w) else np.array(sc.c2w)
+    sc.add_images(net, views[3:])
+    assert net.calls == 6                                   # only (3,0), (3,1), (3,2) are new
+    gt = net.P["c2w_true"].astype(np.float64)
+    c2w = (sc.c2w.cpu().numpy() if torch.is_tensor(sc.c2w) else np.asarray(sc.c2w)).astype(np.float64)
+    s, R, t = _similarity(c2w[:, :3, 3], gt[:, :3, 3])
+    centres = (s * (R @ c2w[:, :3, 3].T)).T + t
+    baseline = np.linalg.norm(gt[0, :3, 3] - gt[1, :3, 3])
+    assert np.abs(centres - gt[:, :3, 3]).max() < 0.08 * baseline
+    assert len(c2w3) == 3 and len(c2w) == 4
