@@ -165,93 +165,186 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
     }
 }
 
-__global__ __launch_bounds__(LT) void k_ssim_bwd(int LH, int H, int W, const float* __restrict__ render,
-                                                 const float* __restrict__ gt, const float* __restrict__ D,
-                                                 Win win, float k_l1, float k_ss,
-                                                 float* __restrict__ v_render) {
-    __shared__ float sd[2][SEGD];
+// Forward and backward in one pass: the derivative maps D never leave the CU.  The strip's output columns need D on
+// 5 more columns each side, D needs x, y on 5 more again, so the workgroup stages 84-column row segments.
+// Wave specialisation: waves 0-3 (222 active threads) run the forward for 74 columns (same arithmetic, same order as
+// k_ssim_fwd) and leave each D row in LDS; waves 4-6 (192 threads) run the second convolution for the 64 output
+// columns one row behind them -- the two stages overlap instead of alternating, each thread carries one 11-row
+// register ring, one barrier per image row.  Saves the 9-float-per-pixel round trip through HBM (1.2 of the 2.6 GB
+// the two-kernel version moves per iteration at 8 x 1080p).
+#define FT1 256                       // forward threads (4 waves)
+#define FT2 (FT1 + LW * 3)            // + backward threads (3 waves) = 448
+#define HALO2 (2 * HALO)
+#define SEG2 ((LW + 2 * HALO2) * 3)   // floats per staged row segment of an image (252)
+#define DCOLS (LW + 2 * HALO)         // columns of D a workgroup computes (74)
+
+__global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const float* __restrict__ render,
+                                                    const float* __restrict__ gt, Win win, float k_l1, float k_ss,
+                                                    double* __restrict__ sums, float* __restrict__ v_render) {
+    __shared__ float sx[2][SEG2];
+    __shared__ float sy[2][SEG2];
+    __shared__ float sd[2][DCOLS * 9];
+    __shared__ float red[8];
     const int cam = blockIdx.z;
     const int j0 = blockIdx.x * LW, i0 = blockIdx.y * LH;
-    const int t = threadIdx.x;
-    const int col = t / 3, ch = t - col * 3;
-    const int j = j0 + col;
-    const float* Dc = D + (int64_t)cam * H * W * 9;
-    const int nrows = min(LH, H - i0) + 2 * HALO;
+    const float* xr = render + (int64_t)cam * H * W * 3;
+    const float* yr = gt + (int64_t)cam * H * W * 3;
+    const int rows_out = min(LH, H - i0);
+    const int nrows = rows_out + 2 * HALO2;  // input rows i0-10 .. i0+rows_out+9
+    float l1 = 0.f, ssim_acc = 0.f;
 
-    constexpr int NPF = (SEGD + LT - 1) / LT;
-    float pf[NPF];
-    auto prefetch = [&](int r) {
-        const int i = i0 - HALO + r;
-        const bool row_ok = (r < nrows) && (i >= 0) && (i < H);
+    if (threadIdx.x < FT1) {
+        // ================= forward waves: D column `col` = image column j0 - 5 + col =================
+        const int t = threadIdx.x;
+        const int col = t / 3, ch = t - col * 3;
+        const bool active = t < DCOLS * 3;
+        const int jd = j0 - HALO + col;
+        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+        float pfx = 0.f, pfy = 0.f;   // SEG2 <= FT1: one element per thread and row
+        auto prefetch = [&](int r) {
+            const int i = i0 - HALO2 + r;
+            const int jj = j0 - HALO2 + t / 3;
+            float vx = 0.f, vy = 0.f;
+            if (r < nrows && i >= 0 && i < H && t < SEG2 && jj >= 0 && jj < W) {
+                const int64_t q = ((int64_t)i * W + j0 - HALO2) * 3 + t;
+                vx = xr[q]; vy = yr[q];
+            }
+            pfx = vx; pfy = vy;
+        };
+        auto commit = [&](int b) {
+            if (t < SEG2) { sx[b][t] = pfx; sy[b][t] = pfy; }
+        };
+        float ring[KS][5];
 #pragma unroll
-        for (int n = 0; n < NPF; ++n) {
-            const int e = t + n * LT;
-            const int jj = j0 - HALO + e / 9;
-            float v = 0.f;
-            if (row_ok && e < SEGD && jj >= 0 && jj < W) v = Dc[((int64_t)i * W + j0 - HALO) * 9 + e];
-            pf[n] = v;
-        }
-    };
-    auto commit = [&](int b) {
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int n = 0; n < NPF; ++n) {
-            const int e = t + n * LT;
-            if (e < SEGD) sd[b][e] = pf[n];
-        }
-    };
-
-    float ring[KS][3];
+            for (int m = 0; m < 5; ++m) ring[s][m] = 0.f;
+        const bool own_col = (col >= HALO) && (col < HALO + LW) && (jd < W);
+        prefetch(0);
+        commit(0);
+        prefetch(1);
+        __syncthreads();
+        for (int rb = 0; rb <= nrows; rb += KS) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
-
-    float xn = 0.f, yn = 0.f;
-    prefetch(0);
-    commit(0);
-    prefetch(1);
-    __syncthreads();
-    for (int rb = 0; rb < nrows; rb += KS) {
+            for (int s = 0; s < KS; ++s) {
+                const int r = rb + s;
+                if (r <= nrows) {
+                    if (r < nrows) {
+                        const int b = r & 1;
+                        commit(b ^ 1);     // row r+1 (prefetched one iteration ago)
+                        prefetch(r + 2);
+                        if (active) {
+                            const float* px = &sx[b][col * 3 + ch];
+                            const float* py = &sy[b][col * 3 + ch];
+                            float h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int r = rb + s;
-            if (r < nrows) {
-                const int b = r & 1;
-                commit(b ^ 1);
-                prefetch(r + 2);
-                // x, y of the output pixel of this iteration were requested one iteration ago
-                const float x = xn, y = yn;
-                {
-                    const int ion = i0 + r + 1 - 2 * HALO;  // next iteration's output row
-                    if (ion >= i0 && ion < H && j < W) {
-                        const int64_t qn = (((int64_t)cam * H + ion) * W + j) * 3 + ch;
-                        xn = render[qn]; yn = gt[qn];
-                    }
-                }
-                const float* pd = &sd[b][col * 9 + ch * 3];
-                float h0 = 0, h1 = 0, h2 = 0;
+                            for (int k = 0; k < KS; ++k) {
+                                const float xx = px[k * 3], yy = py[k * 3], w = win.w[k];
+                                const float wx = w * xx, wy = w * yy;
+                                h0 += wx; h1 += wy; h2 += wx * xx; h3 += wy * yy; h4 += wx * yy;
+                            }
+                            ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2; ring[s][3] = h3; ring[s][4] = h4;
+                            const int i = i0 - HALO2 + r;  // image row just staged
+                            if (own_col && i >= i0 && i < i0 + rows_out) l1 += fabsf(py[HALO * 3] - px[HALO * 3]);
+                            if (r >= 2 * HALO) {
+                                const int id = i0 + r - 3 * HALO;  // image row of the D row completed now
+                                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                                const bool interior = (id >= HALO) && (id < H - HALO) && (jd >= HALO) && (jd < W - HALO);
+                                if (interior) {
+                                    float mx = 0, my = 0, exx = 0, eyy = 0, exy = 0;
 #pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    const float w = win.w[k];
-                    h0 += w * pd[k * 9]; h1 += w * pd[k * 9 + 1]; h2 += w * pd[k * 9 + 2];
-                }
-                ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2;
-                if (r >= 2 * HALO) {
-                    const int io = i0 + r - 2 * HALO;
-                    if (io < H && j < W) {
-                        float a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-                        for (int k = 0; k < KS; ++k) {
-                            const int slot = (s + 1 + k) % KS;
-                            const float w = win.w[k];
-                            a0 += w * ring[slot][0]; a1 += w * ring[slot][1]; a2 += w * ring[slot][2];
+                                    for (int k = 0; k < KS; ++k) {
+                                        const int slot = (s + 1 + k) % KS;  // input row r-10+k
+                                        const float w = win.w[k];
+                                        mx += w * ring[slot][0]; my += w * ring[slot][1]; exx += w * ring[slot][2];
+                                        eyy += w * ring[slot][3]; exy += w * ring[slot][4];
+                                    }
+                                    const float sxx = exx - mx * mx, syy = eyy - my * my, sxy = exy - mx * my;
+                                    const float n1 = 2.f * mx * my + c1, n2 = 2.f * sxy + c2;
+                                    const float dd1 = mx * mx + my * my + c1, dd2 = sxx + syy + c2;
+                                    const float inv1 = __builtin_amdgcn_rcpf(dd1), inv2 = __builtin_amdgcn_rcpf(dd2);
+                                    const float inv = inv1 * inv2;
+                                    const float ssim = n1 * n2 * inv;
+                                    if (own_col && id >= i0 && id < i0 + rows_out) ssim_acc += ssim;  // one strip counts it
+                                    const float dn1 = n2 * inv, dn2 = n1 * inv;
+                                    const float g1 = -ssim * inv1, g2 = -ssim * inv2;
+                                    d0 = 2.f * my * (dn1 - dn2) + 2.f * mx * (g1 - g2);  // dS/dmu_x
+                                    d1 = g2;                                             // dS/dE[x^2]
+                                    d2 = 2.f * dn2;                                      // dS/dE[xy]
+                                }
+                                float* dst = &sd[b][col * 9 + ch * 3];
+                                dst[0] = d0; dst[1] = d1; dst[2] = d2;
+                            }
                         }
-                        const int64_t q = (((int64_t)cam * H + io) * W + j) * 3 + ch;
-                        const float sgn = (x > y) ? 1.0f : ((x < y) ? -1.0f : 0.0f);
-                        v_render[q] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
         }
+    } else {
+        // ================= backward waves: output column j0 + col, one row behind the forward waves =================
+        const int t = threadIdx.x - FT1;
+        const int col = t / 3, ch = t - col * 3;
+        const int j = j0 + col;
+        float ring[KS][3];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
+        float xn = 0.f, yn = 0.f;
+        __syncthreads();
+        for (int rb = 0; rb <= nrows; rb += KS) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int r = rb + s;
+                if (r <= nrows) {
+                    const int rp = r - 1;                 // the forward iteration whose D row is consumed now
+                    const int sp = (s + KS - 1) % KS;     // its ring slot (compile time)
+                    // x, y of the output pixel of this iteration were requested one iteration ago
+                    const float x = xn, y = yn;
+                    {
+                        const int ion = i0 + rp + 1 - 2 * HALO2;  // next iteration's output row
+                        if (ion >= i0 && ion < H && j < W) {
+                            const int64_t qn = ((int64_t)ion * W + j) * 3 + ch;
+                            xn = xr[qn]; yn = yr[qn];
+                        }
+                    }
+                    if (rp >= 2 * HALO) {
+                        const float* pd = &sd[rp & 1][col * 9 + ch * 3];
+                        float h0 = 0, h1 = 0, h2 = 0;
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            const float w = win.w[k];
+                            h0 += w * pd[k * 9]; h1 += w * pd[k * 9 + 1]; h2 += w * pd[k * 9 + 2];
+                        }
+                        ring[sp][0] = h0; ring[sp][1] = h1; ring[sp][2] = h2;
+                        if (rp >= 2 * HALO2) {
+                            const int io = i0 + rp - 2 * HALO2;
+                            if (io < H && j < W) {
+                                float a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+                                for (int k = 0; k < KS; ++k) {
+                                    const int slot = (sp + 1 + k) % KS;
+                                    const float w = win.w[k];
+                                    a0 += w * ring[slot][0]; a1 += w * ring[slot][1]; a2 += w * ring[slot][2];
+                                }
+                                const int64_t q = (((int64_t)cam * H + io) * W + j) * 3 + ch;
+                                const float sgn = (x > y) ? 1.0f : ((x < y) ? -1.0f : 0.0f);
+                                v_render[q] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    // sums of the forward waves (the others hold zeros)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_down(l1, off); ssim_acc += __shfl_down(ssim_acc, off); }
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < FT1) { red[threadIdx.x >> 6] = l1; red[4 + (threadIdx.x >> 6)] = ssim_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * cam + 0], (double)((red[0] + red[1]) + (red[2] + red[3])));
+        atomicAdd(&sums[2 * cam + 1], (double)((red[4] + red[5]) + (red[6] + red[7])));
     }
 }
 
@@ -259,27 +352,21 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
                    float w_l1, float w_ssim, double* sums, float* v_render) {
     static const Win win = make_window();
     HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)C, s));
-    float* D = nullptr;
-    if (v_render) {
-        void* p;
-        int rc = st3r_arena_get(ctx, SLOT_SSIM_A, sizeof(float) * 9 * (size_t)C * H * W, &p);
-        if (rc) return rc;
-        D = (float*)p;
-    }
-    // 64-row strips re-read 16 % halo rows, 32-row strips 31 %: take the short ones only when the long ones
+    // 64-row strips re-read 16-31 % halo rows, 32-row strips twice that: take the short ones only when the long ones
     // would give fewer than ~4 workgroups per CU (one or two views per GPU)
     const int LH = (ceil_div(W, LW) * ceil_div(H, LH_MAX) * C >= 1024) ? LH_MAX : LH_MAX / 2;
     dim3 grid(ceil_div(W, LW), ceil_div(H, LH), C);
-    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(LT), 0, s, LH, H, W, render, gt, win, sums, D);
-    LAUNCH_CHECK();
-    if (v_render) {
-        const int Hi = H - 2 * HALO, Wi = W - 2 * HALO;
-        const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
-        const float k_l1 = (float)((double)w_l1 / ((double)H * W * 3));
-        const float k_ss = cnt > 0 ? (float)(-(double)w_ssim / cnt) : 0.f;
-        hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(LT), 0, s, LH, H, W, render, gt, D, win, k_l1, k_ss, v_render);
+    if (!v_render) {   // loss value only
+        hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(LT), 0, s, LH, H, W, render, gt, win, sums, (float*)nullptr);
         LAUNCH_CHECK();
+        return ST3R_OK;
     }
+    const int Hi = H - 2 * HALO, Wi = W - 2 * HALO;
+    const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
+    const float k_l1 = (float)((double)w_l1 / ((double)H * W * 3));
+    const float k_ss = cnt > 0 ? (float)(-(double)w_ssim / cnt) : 0.f;
+    hipLaunchKernelGGL(k_ssim_fused, grid, dim3(FT2), 0, s, LH, H, W, render, gt, win, k_l1, k_ss, sums, v_render);
+    LAUNCH_CHECK();
     return ST3R_OK;
 }
 
