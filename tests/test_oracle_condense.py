@@ -84,3 +84,16 @@ def test_spanning_tree_is_maximal():
             if okay:
                 best = max(best, sum(s[i, j] for i, j in sub))
         assert abs(total - best) < 1e-9
+
+
+def test_spanning_tree_against_scipy():
+    """upstream calls scipy.sparse.csgraph.minimum_spanning_tree on the negated scores: same total weight, a tree."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import minimum_spanning_tree
+    rng = np.random.default_rng(3)
+    for C in (3, 8, 32):
+        s = rng.uniform(1, 100, (C, C)); s = np.triu(s, 1)
+        tree = minimum_spanning_tree(sp.csr_matrix(-s))
+        root, edges = co.compute_min_spanning_tree(s + s.T)
+        assert len(edges) == C - 1 == tree.nnz
+        assert abs(sum((s + s.T)[a, b] for a, b in edges) + tree.sum()) < 1e-9
