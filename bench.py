@@ -155,6 +155,50 @@ def align_bench(device, with_cpu=True, views=8):
     return out
 
 
+def condense_bench(device, with_cpu=True, views=8, W=512, H=384):
+    """canonical pointmaps + focals + anchors for `views` images of W x H from the C(C-1)/2 pair
+    predictions (the step between matching and alignment), device kernels vs the numpy restatement."""
+    from starst3r_amd import condense, synth_pairs
+    P = synth_pairs.make_pair_predictions(views, W, H, seed=0, n_corr=2000)
+    dev_pairs = {}
+    for k, ((p1, p2), (score, corr)) in P["pairs"].items():   # resident on the device like freshly inferred pairs
+        dev_pairs[k] = ((tuple(torch.tensor(a, device=device) for a in p1), tuple(torch.tensor(a, device=device) for a in p2)),
+                        (score, tuple(torch.tensor(a, device=device) for a in corr)))
+    w = condense.prepare_canonical_data(P["imgs"], dev_pairs, 8, device=device)     # warm-up of both parts
+    condense.condense_data(P["imgs"], dev_pairs, w[2], w[4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, scores, cviews, _, preds = condense.prepare_canonical_data(P["imgs"], dev_pairs, 8, device=device)
+    torch.cuda.synchronize()
+    t_canon = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    condense.compute_min_spanning_tree(scores)
+    condense.condense_data(P["imgs"], dev_pairs, cviews, preds)
+    torch.cuda.synchronize()
+    t_lists = time.perf_counter() - t0
+    f = [float(cviews[i][2][0]) for i in P["imgs"]]
+    out = {"views": views, "image": f"{W}x{H}", "pairs": len(dev_pairs), "prepare_canonical_data_ms": t_canon * 1e3,
+           "mst_and_condense_data_ms": t_lists * 1e3, "focal_error_max": max(abs(x - P["focal_true"]) for x in f) / P["focal_true"],
+           "bound": "HBM / latency, small (not roofline bound)"}
+    if with_cpu:
+        from oracle import condense_oracle as co
+        t0 = time.perf_counter()
+        for img in P["imgs"][:2]:
+            pt, cf = [], []
+            for (a, b), ((p1, p2), _c) in P["pairs"].items():
+                if a == img:
+                    pt.append(p1[0]); cf.append(p1[1])
+                elif b == img:
+                    pt.append(p2[0]); cf.append(p2[1])
+            canon, canon2, _ = co.canonical_view(np.stack(pt), np.stack(cf), 8)
+            co.estimate_focal_knowing_depth(canon, (W / 2, H / 2))
+        cpu = (time.perf_counter() - t0) * views / 2
+        out.update(cpu_port_ms=cpu * 1e3, cpu_kind="port", cpu_cores=1,
+                   cpu_note="oracle/condense_oracle.py (numpy): canonical_view + focal of 2 images timed, scaled to all",
+                   speedup=cpu / t_canon)
+    return out
+
+
 # HBM bytes per launch from the PMC passes committed in profiles/r1i_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # in separate runs; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md).  They belong to the default
 # single-GPU SYNTH-1M workload only; any other configuration reports null (counters cannot be read from inside
@@ -358,6 +402,7 @@ def main():
                                                     for c in (2, 32)}
             out["align"]["hip_seconds_by_views"]["8"] = out["align"]["hip_seconds"]
             out["matching"] = matching_bench(device, with_cpu=not args.no_cpu_baseline)
+            out["condense"] = condense_bench(device, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
