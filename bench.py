@@ -199,12 +199,12 @@ def condense_bench(device, with_cpu=True, views=8, W=512, H=384):
     return out
 
 
-# HBM bytes per launch from the PMC passes committed in profiles/r1i_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# HBM bytes per launch from the PMC passes committed in profiles/r1j_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # in separate runs; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md).  They belong to the default
 # single-GPU SYNTH-1M workload only; any other configuration reports null (counters cannot be read from inside
 # the benchmark process).
 PMC_TRAFFIC_SYNTH1M = {"blend_bwd": 5.01e9 + 1.62e9,   # k_blend_bwd + k_gather_vtile (one stage)
-                       "blend_fwd": 1.89e9, "loss": 0.92e9, "project": 0.76e9, "project_bwd": 1.06e9,
+                       "blend_fwd": 1.89e9, "loss": 0.83e9, "project": 0.76e9, "project_bwd": 1.06e9,
                        "adam": 0.78e9, "emit": 0.35e9}
 
 
