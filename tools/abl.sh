@@ -5,11 +5,11 @@ set -u
 if [ "$1" = build ]; then
   shift; rm -rf build_variants; mkdir -p build_variants; i=0
   for D in "$@"; do
-    i=$((i+1)); touch starst3r_amd/csrc/gs_blend.hip starst3r_amd/csrc/loss.hip
+    i=$((i+1)); touch starst3r_amd/csrc/gs_blend.hip starst3r_amd/csrc/loss.hip starst3r_amd/csrc/api.hip
     ST3R_DEFS="$D" python -m starst3r_amd.build > /dev/null 2>&1 || echo "build failed: $D"
     cp starst3r_amd/libst3r_hip.so build_variants/v$i.so; echo "$D" > build_variants/v$i.txt
   done
-  touch starst3r_amd/csrc/gs_blend.hip starst3r_amd/csrc/loss.hip; python -m starst3r_amd.build > /dev/null 2>&1
+  touch starst3r_amd/csrc/gs_blend.hip starst3r_amd/csrc/loss.hip starst3r_amd/csrc/api.hip; python -m starst3r_amd.build > /dev/null 2>&1
 else
   cp starst3r_amd/libst3r_hip.so /tmp/orig.so
   for f in build_variants/v*.so; do
@@ -17,7 +17,7 @@ else
     ST3R_BENCH_FREEZE=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); s = d['roofline']['stage_ms']
-print('ms', round(d['ms_per_step'], 3), 'fwd', round(s['blend_fwd'], 3), 'bwd', round(s['blend_bwd'], 3), 'loss', round(s['loss'], 3))"
+print('ms', round(d['ms_per_step'], 3), 'fwd', round(s['blend_fwd'], 3), 'bwd', round(s['blend_bwd'], 3), 'loss', round(s['loss'], 3), 'pbwd', round(s['project_bwd'], 3))"
   done
   cp /tmp/orig.so starst3r_amd/libst3r_hip.so
 fi
