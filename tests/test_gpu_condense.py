@@ -192,3 +192,26 @@ def test_example_pipeline_improves_psnr():
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     before, after = mod.main(views=3, iters=600, W=128, H=96)
     assert np.isfinite(after) and after > before + 8.0 and after > 15.0, (before, after)
+
+
+def test_reference_size_and_argument_errors(ctx):
+    """512 x 384 (the reference's Mast3r resolution), one and seven predictions per image; malformed calls are
+    refused with an error code instead of reading out of bounds."""
+    from starst3r_amd import ops
+    P = synth_pairs.make_pair_predictions(2, 512, 384, seed=11, n_corr=200)
+    X, Cf = maps_of(P, "0.png")                       # a single prediction
+    assert X.shape[0] == 1
+    canon, canon2, cconf = ops.canon_view(ctx, dev(X), dev(Cf), 8)
+    canon_o, canon2_o, cconf_o = co.canonical_view(X, Cf, 8)
+    assert np.allclose(canon.cpu().numpy(), canon_o, rtol=1e-5, atol=1e-6)
+    assert np.allclose(canon2.cpu().numpy(), canon2_o, rtol=1e-4, atol=1e-5)
+    X7 = np.concatenate([X * np.float32(1 + 0.01 * k) for k in range(7)]); C7 = np.concatenate([Cf + np.float32(k) for k in range(7)])
+    canon, canon2, cconf = ops.canon_view(ctx, dev(X7), dev(C7), 8)
+    canon_o, canon2_o, cconf_o = co.canonical_view(X7, C7, 8)
+    assert np.allclose(canon.cpu().numpy(), canon_o, rtol=1e-5, atol=1e-6)
+    assert np.allclose(canon2.cpu().numpy(), canon2_o, rtol=1e-4, atol=1e-5)
+    assert np.allclose(cconf.cpu().numpy(), cconf_o, rtol=1e-5)
+    with pytest.raises(ValueError):   # ST3R_EINVAL surfaces as ValueError (starst3r_amd._lib.check)
+        ops.canon_view(ctx, dev(X[:, :380]), dev(Cf[:, :380]), 8)          # height not a multiple of the subsample
+    with pytest.raises(ValueError):
+        ops.focal_weiszfeld(ctx, canon, (256, 192), min_focal=2.0, max_focal=1.0)
