@@ -84,18 +84,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(int32_t* __rest
     if (threadIdx.x == 0) total_out[0] = carry;
 }
 
-// (in may alias out: every thread loads all of its items before it stores any)
+// (in may alias out: the block loads its whole tile before it stores any of it)
+// Thread t owns SCAN_ITEMS consecutive elements so the scan order is the array order; the tile travels through LDS so
+// that both the loads and the stores are coalesced (padded by one word per 32: the 16-word runs of neighbouring
+// threads would otherwise meet in the same banks).
+#define SCAN_PAD(i) ((i) + ((i) >> 5))
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, const int32_t* __restrict__ perm,
                                                             int64_t n, const int32_t* __restrict__ block_sums,
                                                             int32_t* out) {
-    // thread t owns SCAN_ITEMS consecutive elements so the scan order is the array order
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    __shared__ int tile[SCAN_PAD(SCAN_TILE) + 1];
+    const int64_t base0 = (int64_t)blockIdx.x * SCAN_TILE;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int e = i * SCAN_THREADS + threadIdx.x;
+        const int64_t idx = base0 + e;
+        tile[SCAN_PAD(e)] = idx < n ? (perm ? in[perm[idx]] : in[idx]) : 0;
+    }
+    __syncthreads();
     int v[SCAN_ITEMS];
     int s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + i;
-        v[i] = idx < n ? (perm ? in[perm[idx]] : in[idx]) : 0;
+        const int e = threadIdx.x * SCAN_ITEMS + i;
+        v[i] = tile[SCAN_PAD(e)];
         s += v[i];
     }
     int total;
@@ -104,8 +115,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, c
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         run += v[i];
-        int64_t idx = base + i;
-        if (idx < n) out[idx] = run;
+        tile[SCAN_PAD(threadIdx.x * SCAN_ITEMS + i)] = run;   // own elements only: no barrier needed before
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int e = i * SCAN_THREADS + threadIdx.x;
+        const int64_t idx = base0 + e;
+        if (idx < n) out[idx] = tile[SCAN_PAD(e)];
     }
 }
 
