@@ -354,27 +354,46 @@ int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, 
 }
 
 // Emission from the depth-ordered packed rectangles (written by the depth-order scan): everything this kernel
-// reads is sequential -- no gather of 48-byte records, no floating point.
+// reads is sequential -- no gather of 48-byte records, no floating point.  The 256 pairs of a block own one
+// contiguous output range; it is assembled in LDS and written out coalesced (ranges above EMIT_CAP entries -- a
+// block holding image-filling Gaussians -- are written directly).
+#define EMIT_CAP 4096
 __global__ __launch_bounds__(256) void k_isect_emit_rects(int N, int64_t n_pairs, const int32_t* __restrict__ perm,
                                                           const int32_t* __restrict__ cum_sorted,
                                                           const uint64_t* __restrict__ rects_sorted, int tile_w,
                                                           int tile_h, uint32_t* __restrict__ tile_keys,
                                                           int32_t* __restrict__ vals) {
-    const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx >= n_pairs) return;
-    const uint64_t r = rects_sorted[sidx];
-    const int w = (int)((r >> 32) & 0xFFFF), h = (int)(r >> 48);
-    if (w == 0 || h == 0) return;
-    const int x0 = (int)(r & 0xFFFF), y0 = (int)((r >> 16) & 0xFFFF);
-    const int32_t pid = perm[sidx];
-    int cur = sidx == 0 ? 0 : cum_sorted[sidx - 1];
-    const uint32_t cam_base = (uint32_t)(pid / N) * (uint32_t)(tile_w * tile_h);
-    for (int ty = y0; ty < y0 + h; ++ty)
-        for (int tx = x0; tx < x0 + w; ++tx) {
-            tile_keys[cur] = cam_base + (uint32_t)(ty * tile_w + tx);
-            vals[cur] = pid;
-            ++cur;
+    __shared__ uint32_t sk[EMIT_CAP];
+    __shared__ int32_t sv[EMIT_CAP];
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t last = min(n_pairs, first + (int64_t)blockDim.x) - 1;
+    const int base = first == 0 ? 0 : cum_sorted[first - 1];
+    const int total = cum_sorted[last] - base;
+    const bool staged = total <= EMIT_CAP;
+    const int64_t sidx = first + threadIdx.x;
+    if (sidx < n_pairs) {
+        const uint64_t r = rects_sorted[sidx];
+        const int w = (int)((r >> 32) & 0xFFFF), h = (int)(r >> 48);
+        if (w != 0 && h != 0) {
+            const int x0 = (int)(r & 0xFFFF), y0 = (int)((r >> 16) & 0xFFFF);
+            const int32_t pid = perm[sidx];
+            int cur = sidx == 0 ? 0 : cum_sorted[sidx - 1];
+            const uint32_t cam_base = (uint32_t)(pid / N) * (uint32_t)(tile_w * tile_h);
+            for (int ty = y0; ty < y0 + h; ++ty)
+                for (int tx = x0; tx < x0 + w; ++tx) {
+                    const uint32_t key = cam_base + (uint32_t)(ty * tile_w + tx);
+                    if (staged) { sk[cur - base] = key; sv[cur - base] = pid; }
+                    else { tile_keys[cur] = key; vals[cur] = pid; }
+                    ++cur;
+                }
         }
+    }
+    if (!staged) return;   // uniform over the block
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        tile_keys[base + i] = sk[i];
+        vals[base + i] = sv[i];
+    }
 }
 
 int st3r_isect_emit_rects_impl(hipStream_t s, int N, int C, const int32_t* perm, const int32_t* cum_sorted,
