@@ -441,11 +441,15 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     // with the pixel's v_rgb is ever used, so one scalar replaces the three components
     float bv = 0.f;
     const int64_t mbase = mask_base(g.lb, g.start);
-    const uint64_t* wmask = cmask + (int64_t)w * cmask_words + mbase;
-
+    // wave-uniform pointer (scalar loads); the mask word of a round is fetched one round ahead so that no dependent
+    // load sits at the head of a round
+    const uint64_t* wmask = cmask + (int64_t)__builtin_amdgcn_readfirstlane(w) * cmask_words + mbase;
+    uint64_t m_next = wmask[(BLK / HB) * nb - 1];
     for (int hb = (BLK / HB) * nb - 1; hb >= 0; --hb) {
         const int bs = g.start + hb * HB;
         const int bsz = min(HB, g.end - bs);
+        const uint64_t m_cur = m_next;
+        if (hb > 0) m_next = wmask[hb - 1];
         if (bsz <= 0) continue;   // the tail of the last forward batch may be empty (uniform over the workgroup)
         __syncthreads();
         // ---- staging: one record per thread (threads 0..HB-1).  A record some wave contributed to also fixes its
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             }
         }
         __syncthreads();
-        uint64_t m = uniform_u64(wmask[hb]);   // HB = 64: one mask word per round
+        uint64_t m = m_cur;   // HB = 64: one mask word per round
         while (m) {
             // ---- phase 1: lanes are pixels; up to CHUNK records, back to front (unrolled: the chunk row is an
             // immediate offset, the records' staged indices travel to phase 2 in one scalar, 8 bits each)
