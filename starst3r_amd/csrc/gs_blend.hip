@@ -466,7 +466,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
             sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
             sC[t] = c.x;
-            const int64_t word = mbase + hb * HB_WORDS + (t >> 6);
+            const int64_t word = mbase + hb;   // HB = 64: one (wave-uniform) mask word per round and wave
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
             if (my_cb) {
