@@ -34,8 +34,8 @@
 // after the round one thread per record adds the rows of the waves whose contribution bit is set, applies the
 // record constants (opacity, conic) and writes the record's stamped slot in HBM -- no atomics anywhere;
 // k_gather_vtile sums the slots of a (camera, gaussian) pair in order.  Rounds stage HB = 64 records (a quarter of
-// a forward batch) and CHUNK = 4: 20 KB of LDS and 76 VGPRs keep six workgroups per CU (measured: the same code
-// with 3 or 4 workgroups per CU is 15-40 % slower, 7 or 8 are no faster).  PMC: 1.48 G VALU instructions per launch
+// a forward batch) and CHUNK = 4: 20 KB of LDS and 64 VGPRs keep eight workgroups per CU (measured: the same code
+// with 3 to 5 workgroups per CU is 8-40 % slower).  PMC: 1.48 G VALU instructions per launch
 // (2.19 G for the per-record butterfly it replaces), the VALU pipes are busy for the whole kernel.
 //
 // Cost split of the backward at SYNTH-1M (ablations on a frozen scene, tools/abl.sh): phase 1 + 2 arithmetic
