@@ -52,7 +52,7 @@ def fuzz_scene(seed):
     return g, w2c, Ks, W, H
 
 
-FUZZ = ["fuzz0", "fuzz1", "fuzz2", "fuzz3", "fuzz4", "fuzz5"]
+FUZZ = ["fuzz%d" % i for i in range(12)]
 
 
 def make(name):
