@@ -8,12 +8,12 @@ from starst3r_amd import image
 
 @pytest.mark.parametrize("H,W,size", [(300, 451, 224), (480, 640, 512), (1080, 1920, 512), (97, 33, 224), (224, 224, 224)])
 def test_process_image_size_rules(H, W, size):
-    x = torch.rand(3, H, W)
+    x = torch.rand(3, H, W, generator=torch.Generator().manual_seed(H * 1000 + W))
     y = image.process_image(x, size)
     nh, nw = int(H * size / max(H, W)), int(W * size / max(H, W))       # image.py:62 (truncation)
     cy, cx = nh // 2, nw // 2                                             # image.py:65-66
     assert y.shape == (3, 2 * ((cy // 8) * 8), 2 * ((cx // 8) * 8))       # image.py:69-73: multiples of 16
-    assert y.dtype == torch.float32 and float(y.min()) >= -1.3 and float(y.max()) <= 1.3   # Normalize(0.5, 0.5)
+    assert y.dtype == torch.float32 and float(y.min()) >= -2.0 and float(y.max()) <= 2.0   # Normalize(0.5, 0.5); bicubic overshoots on noise
 
 
 def test_process_image_is_centre_crop_of_the_resize():
