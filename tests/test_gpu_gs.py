@@ -179,20 +179,20 @@ def test_backward_vs_oracle(ctx, name):
         close(G[k], go_grads[k], k, tol=4e-3 if name.startswith("fuzz") else 1e-3)
 
 
-def test_backward_deterministic_enough(ctx):
-    """Run the atomics-based backward twice: results agree to float-atomic reordering noise."""
+def test_backward_is_deterministic(ctx):
+    """The backward has no atomics (per-wave accumulator rows, stamped slots, in-order gather): two runs agree bit
+    for bit."""
     from starst3r_amd import ops
     g, w2c, Ks, W, H = make("medium")
     P, rgb, alpha, info = run_hip(ctx, g, w2c, Ks, W, H)
-    v_rgb = torch.randn_like(rgb)
+    v_rgb = torch.randn(rgb.shape, device=rgb.device, generator=torch.Generator(device=rgb.device).manual_seed(5))
     Cn = w2c.shape[0]
     a = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
                       info["_last_ids"], v_rgb, None, info["_cum_tiles"], Cn, W, H)
     b = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
                       info["_last_ids"], v_rgb, None, info["_cum_tiles"], Cn, W, H)
     torch.cuda.synchronize()
-    scale = a.abs().max()
-    assert float((a - b).abs().max() / scale) < 1e-5
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
 @pytest.mark.parametrize("shape", [(1, 30, 37), (2, 64, 96), (1, 75, 101)])

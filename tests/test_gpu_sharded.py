@@ -115,7 +115,7 @@ def test_sharded_step_through_rccl_single_rank():
     P0 = {k: torch.from_numpy(g[k]).to(DEV) for k in ("means", "quats", "scales", "opacities", "shN")}
     w2c = torch.from_numpy(w2c_np).to(DEV); Ks = torch.from_numpy(Ks_np).to(DEV)
     ctx = ops.get_context(DEV)
-    gt = torch.rand((V, H, W, 3), device=DEV)
+    gt = torch.rand((V, H, W, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
 
     def run(a2a):
         P = {k: v.clone() for k, v in P0.items()}
