@@ -199,7 +199,7 @@ def condense_bench(device, with_cpu=True, views=8, W=512, H=384):
     return out
 
 
-# HBM bytes per launch from the PMC passes committed in profiles/r1l_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# HBM bytes per launch from the PMC passes committed in profiles/r1m_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # in separate runs; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md).  They belong to the default
 # single-GPU SYNTH-1M workload only; any other configuration reports null (counters cannot be read from inside
 # the benchmark process).

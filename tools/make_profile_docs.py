@@ -12,12 +12,12 @@ stage = {k: round(v, 3) for k, v in line["roofline"]["stage_ms"].items()}
 body = subprocess.run([sys.executable, "tools/rocprof_summary.py", glob.glob(f"{T}/trace/runc/*_kernel_trace.csv")[0]],
                       capture_output=True, text=True).stdout.splitlines()
 with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
-    f.write(f"# Round 1 ({note}) -- rocprofv3 --kernel-trace --stats of `python bench.py --steps 6 --warmup 2 --no-cpu-baseline`\n\n"
+    f.write(f"# Round 1 ({note}) -- rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` (default 30 steps + 5 warm-up)\n\n"
             "SYNTH-1M (1 M Gaussians, 8 x 1920x1080), 1 MI355X; the run also executes the alignment and matching benches.\n"
-            f"Command: `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_{tag}/trace -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline` (tools/profile_round.sh).\n"
+            f"Command: `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_{tag}/trace -- python bench.py --no-cpu-baseline` (tools/profile_round.sh).\n"
             f"bench.py's own line in the same run: {line['value']:.2f} iters/s; stage_ms (HIP events inside bench.py): {stage}\n"
             "(blend_bwd stage = k_blend_bwd + k_gather_vtile; loss = k_ssim_fused; sort/sort_depth = the rocPRIM kernels; scan = k_scan_*.)\n"
-            f"(6 timed steps only; the default 30-step bench line of the same build is {tag}_bench_default.json.)\n\n")
+            f"(the bench line of the same build without the profiler is {tag}_bench_default.json.)\n\n")
     f.write("\n".join(body[2:44]) + "\n")
 shutil.copy(glob.glob(f"{T}/trace/runc/*_kernel_stats.csv")[0], f"profiles/{tag}_rocprof_kernel_stats.csv")
 shutil.copy(bench_json, f"profiles/{tag}_bench_default.json")

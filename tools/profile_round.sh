@@ -8,7 +8,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+# the kernel trace runs the default step counts so that its kernel means and the bench line's stage_ms describe the same run
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -- python $ROOT/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/pmc_$C -- $CMD > $OUT/pmc_$C.log 2>&1
 done
