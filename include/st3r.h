@@ -72,7 +72,8 @@ int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t byt
  * fused steps (no host synchronisation while enabled).  st3r_ctx_get_stage_ms synchronises
  * the device, writes the accumulated milliseconds and sample counts of the ST3R_NUM_STAGES
  * stages and resets them.  Stage order: project, scan, emit, sort, offsets, blend_fwd, loss,
- * blend_bwd, project_bwd, adam, sort_depth (names from st3r_stage_name). */
+ * blend_bwd, project_bwd, adam, sort_depth (names from st3r_stage_name).
+ * enable: 0 = off, 1 = every stage, 2 + s = stage s only (two events per step instead of twenty-two). */
 #define ST3R_NUM_STAGES 11
 int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
 /* test hook. bit 0: the blend forward walks every staged record in every wave (no per-quadrant relevance test):

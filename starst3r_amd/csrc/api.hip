@@ -118,12 +118,12 @@ static void prof_harvest_slot(st3r_ctx* ctx, int slot) {
 }
 
 void st3r_prof_begin(st3r_ctx* ctx, hipStream_t s, int stage) {
-    if (!ctx->prof_enabled) return;
+    if (!((ctx->prof_enabled >> stage) & 1)) return;
     (void)hipEventRecord(ctx->prof_ev[ctx->prof_slot][stage][0], s);
 }
 
 void st3r_prof_end(st3r_ctx* ctx, hipStream_t s, int stage) {
-    if (!ctx->prof_enabled) return;
+    if (!((ctx->prof_enabled >> stage) & 1)) return;
     (void)hipEventRecord(ctx->prof_ev[ctx->prof_slot][stage][1], s);
     ctx->prof_used[ctx->prof_slot][stage] = 1;
 }
@@ -141,13 +141,14 @@ ST3R_EXPORT int st3r_ctx_set_debug(st3r_ctx* ctx, int flags) {
 }
 
 ST3R_EXPORT int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable) {
-    ARG_CHECK(ctx);
+    ARG_CHECK(ctx && enable >= 0 && enable < 2 + STG_COUNT);
     if (enable && !ctx->prof_ev[0][0][0]) {
         for (int r = 0; r < PROF_RING; ++r)
             for (int st = 0; st < STG_COUNT; ++st)
                 for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreate(&ctx->prof_ev[r][st][k]));
     }
-    ctx->prof_enabled = enable ? 1 : 0;
+    // prof_enabled is the mask of timed stages: enable = 1 -> all of them, enable = 2 + stage -> that stage only
+    ctx->prof_enabled = enable == 0 ? 0 : (enable == 1 ? (1 << STG_COUNT) - 1 : (1 << (enable - 2)));
     return ST3R_OK;
 }
 

@@ -318,8 +318,14 @@ def set_debug(ctx, flags):
     _lib.check(_lib.lib().st3r_ctx_set_debug(ctx.handle, int(flags)))
 
 
-def set_profiling(ctx, enable):
-    _lib.check(_lib.lib().st3r_ctx_set_profiling(ctx.handle, 1 if enable else 0))
+STAGES = ("project", "scan", "emit", "sort", "offsets", "blend_fwd", "loss", "blend_bwd", "project_bwd", "adam",
+          "sort_depth")
+
+
+def set_profiling(ctx, enable, only=None):
+    """HIP-event timing of the stages of the fused steps; `only` = a stage name: time just that stage."""
+    code = 0 if not enable else (1 if only is None else 2 + STAGES.index(only))
+    _lib.check(_lib.lib().st3r_ctx_set_profiling(ctx.handle, code))
 
 
 def stage_ms(ctx):
