@@ -3,16 +3,15 @@
 // (data_range=1: 11x11 gaussian window sigma 1.5, k1=.01, k2=.03, mean over the interior
 // (H-10)x(W-10)) and their autograd, starster/gs.py:126-130,153.
 //
-// Row-streaming separable convolution.  A workgroup owns a strip 64 pixels wide (x3 interleaved
-// channels = 192 threads, one per (column, channel)) and walks down 64+10 image rows.  Each
-// row segment is staged once in LDS (coalesced: interleaved channels make the segment one
-// contiguous run), the 11-tap horizontal pass reads it from LDS, and the vertical pass never
-// touches LDS: every thread keeps the last 11 horizontal results in a register ring (the row
-// loop is unrolled by 11 so ring slots are compile-time indices).
-//   k_ssim_fwd: x,y -> 5 windowed moments -> SSIM map; accumulates sum|x-y| and the SSIM sum;
-//               writes the per-pixel derivative maps D = (dS/dmu_x, dS/dE[x^2], dS/dE[xy]) of the
-//               interior (zero elsewhere), 9 floats/pixel;
-//   k_ssim_bwd: v_x = k_l1*sign(x-y) + k_ss*( G*D0 + 2x G*D1 + y G*D2 )   (G symmetric).
+// Row-streaming separable convolution.  A workgroup owns a strip 64 pixels wide (x3 interleaved channels, one
+// thread per (column, channel)) and walks down its rows plus the halo.  Each row segment is staged once in LDS
+// (coalesced: interleaved channels make the segment one contiguous run), the 11-tap horizontal pass reads it from
+// LDS, and the vertical pass never touches LDS: every thread keeps the last 11 horizontal results in a register ring
+// (the row loop is unrolled by 11 so ring slots are compile-time indices).
+//   forward:  x,y -> 5 windowed moments -> SSIM map; accumulates sum|x-y| and the SSIM sum; per pixel the derivative
+//             maps D = (dS/dmu_x, dS/dE[x^2], dS/dE[xy]) of the interior (zero elsewhere), 9 floats/pixel;
+//   backward: v_x = k_l1*sign(x-y) + k_ss*( G*D0 + 2x G*D1 + y G*D2 )   (G symmetric).
+// k_ssim_fwd is the forward alone (value-only calls); k_ssim_fused runs both with D kept in LDS (see there).
 // The window never touches padding for interior outputs, so reflect-padding is not needed.
 #include "common.h"
 
