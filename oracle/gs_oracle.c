@@ -152,7 +152,7 @@ static void project_one(const float* mean, const float* q, const float* s, const
     o->conic[1] = -c01 * inv_det;
     o->conic[2] = c00 * inv_det;
     float bb = 0.5f * (c00 + c11);
-    float v1 = bb + sqrtf(fmaxf(0.1f, bb * bb - det));
+    float v1 = bb + sqrtf(fmaxf(0.01f, bb * bb - det));
     float radius = ceilf(3.0f * sqrtf(v1));
     if (radius <= radius_clip) return;
     if (o->mean2d[0] + radius <= 0.0f || o->mean2d[0] - radius >= (float)W ||

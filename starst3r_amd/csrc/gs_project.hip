@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
                 float inv_det = 1.0f / det;
                 ca = c11 * inv_det; cb = -c01 * inv_det; cc = c00 * inv_det;
                 float bb = 0.5f * (c00 + c11);
-                float v1 = bb + sqrtf(fmaxf(0.1f, bb * bb - det));
+                float v1 = bb + sqrtf(fmaxf(0.01f, bb * bb - det));
                 radius = ceilf(3.0f * sqrtf(v1));
                 if (radius <= radius_clip) valid = false;
                 else if (m2x + radius <= 0.0f || m2x - radius >= (float)W || m2y + radius <= 0.0f ||

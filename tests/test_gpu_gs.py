@@ -92,6 +92,17 @@ def test_projection_tiles_sort_offsets_bit_exact(ctx, name):
     assert meta["isect_ids"].size > 0
 
 
+def test_radius_constant_kat(ctx):
+    """Known answer from the formula itself (radius = ceil(3 sqrt(b + sqrt(max(0.01, b^2 - det))))),
+    not from the oracle: isotropic cov2d 0.8 -> radius 3 (the INRIA constant 0.1 would give 4)."""
+    from kat_scenes import radius_kat_scene
+    g, V, K, W, H = radius_kat_scene()
+    P, rgb, alpha, info = run_hip(ctx, g, V, K, W, H)
+    assert info["radii"].cpu().numpy().tolist() == [3]
+    assert info["tiles_per_gauss"].cpu().numpy().tolist() == [1]
+    assert info["isect_ids"].numel() == 1
+
+
 @pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "many"] + FUZZ)
 def test_fused_two_level_sort_matches_reference_order(ctx, name):
     """The fused render/train path sorts in two levels ((camera|depth) then a stable (camera,tile)

@@ -14,21 +14,7 @@ import torch
 from oracle import gs_oracle as go
 from oracle import gs_torch_ref as tr
 from starst3r_amd import synth
-
-
-def _cam_front(W, H, f=100.0, cx=None, cy=None):
-    """camera at origin looking down +z (identity viewmat)."""
-    V = np.eye(4, dtype=np.float32)[None]
-    cx = W / 2 if cx is None else cx; cy = H / 2 if cy is None else cy
-    K = np.array([[[f, 0, cx], [0, f, cy], [0, 0, 1]]], np.float32)
-    return V, K
-
-
-def _sh_const(n, rgb):
-    """SH coefficients giving colour `rgb` for every direction (only k0 non-zero)."""
-    sh = np.zeros((n, 24, 3), np.float32)
-    sh[:, 0, :] = (np.asarray(rgb, np.float32) - 0.5) / 0.2820947917738781
-    return sh
+from kat_scenes import cam_front as _cam_front, sh_const as _sh_const, radius_kat_scene as _radius_kat_scene
 
 
 def test_single_gaussian_kat(oracle_built):
@@ -64,6 +50,17 @@ def test_single_gaussian_kat(oracle_built):
     # opacity > 0.999 saturates
     rgb2, alpha2, _ = go.rasterization(means, quats, scales, np.array([5.0], np.float32), sh, V, K, W, H)
     np.testing.assert_allclose(alpha2[0, 12, 20, 0], 0.999, rtol=1e-6)
+
+
+def test_radius_constant_kat(oracle_built):
+    """Hand-computed from the formula of SURVEY.md App. A.1, not from the oracle."""
+    g, V, K, W, H = _radius_kat_scene()
+    _, _, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], V, K, W, H)
+    np.testing.assert_allclose(meta["conics"][0], [1 / 0.8, 0, 1 / 0.8], rtol=1e-5, atol=1e-7)
+    assert meta["radii"][0] == 3
+    # mean at (20.5, 12.5): the square [17.5, 23.5] x [9.5, 15.5] touches tile columns 1 and rows 0 only ... x: floor(17.5/16)=1,
+    # ceil(23.5/16)=2 -> one column; y: floor(9.5/16)=0, ceil(15.5/16)=1 -> one row
+    assert meta["tiles_per_gauss"][0] == 1
 
 
 def test_two_gaussians_depth_order_and_last_id(oracle_built):
