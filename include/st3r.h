@@ -114,6 +114,13 @@ int st3r_gs_isect_emit(st3r_ctx* ctx, void* stream, int N, int C, const float* s
 int st3r_gs_sort(st3r_ctx* ctx, void* stream, int64_t n_isects, int end_bit, int64_t* isect_ids,
                  int32_t* flatten_ids, int64_t* isect_ids_sorted, int32_t* flatten_ids_sorted);
 
+/* The sort underneath st3r_gs_sort, for any key shape of the pipeline: stable ascending LSD radix sort of
+ * (key, int32 value) pairs on key bits [begin_bit, end_bit), key_bytes = 4 or 8 (unsigned).  Hand-written
+ * onesweep (one histogram launch + one chained-scan launch per 8-bit digit); inputs are left untouched,
+ * vals_in/vals_out may be NULL (keys only).  Scratch comes from the ctx. */
+int st3r_radix_sort_pairs(st3r_ctx* ctx, void* stream, int key_bytes, int64_t n, int begin_bit, int end_bit,
+                          const void* keys_in, const int32_t* vals_in, void* keys_out, int32_t* vals_out);
+
 /* gsplat isect_offset_encode: offsets [C,tile_h,tile_w] */
 int st3r_gs_offsets(st3r_ctx* ctx, void* stream, int64_t n_isects, const int64_t* isect_ids_sorted, int C,
                     int tile_w, int tile_h, int32_t* offsets);

@@ -605,14 +605,17 @@ GSO_API void gso_l1_ssim(int H, int W, const float* render, const float* gt, dou
                 for (int k = 0; k < KS; ++k)
                     for (int m = 0; m < 5; ++m) s[m] += gw[k] * tmp[((size_t)m * H + i + k) * Wi + j];
                 double mx = s[0], my = s[1];
-                double sxx = s[2] - mx * mx, syy = s[3] - my * my, sxy = s[4] - mx * my;
+                /* torchmetrics clamps both variances at 0 (torch.clamp(E[x^2] - mu^2, min=0)) [U] */
+                double sxx_raw = s[2] - mx * mx;
+                double sxx = sxx_raw < 0 ? 0 : sxx_raw, syy = s[3] - my * my, sxy = s[4] - mx * my;
+                if (syy < 0) syy = 0;
                 double n1 = 2 * mx * my + c1, n2 = 2 * sxy + c2, d1 = mx * mx + my * my + c1, d2 = sxx + syy + c2;
                 double ssim = (n1 * n2) / (d1 * d2);
                 ssim_sum += ssim;
                 if (v_render) {
                     /* d ssim / d(mx), d(Exx), d(Exy) with Exx = E[x^2], Exy = E[xy]; y constant */
                     double dn1 = n2 / (d1 * d2), dn2 = n1 / (d1 * d2);
-                    double dd1 = -ssim / d1, dd2 = -ssim / d2;
+                    double dd1 = -ssim / d1, dd2 = sxx_raw < 0 ? 0.0 : -ssim / d2;   /* clamped: no gradient */
                     /* n1 = 2 mx my + c1 ; n2 = 2(Exy - mx my) + c2 ; d1 = mx^2+my^2+c1 ; d2 = Exx - mx^2 + Eyy - my^2 + c2 */
                     double d_mx = dn1 * 2 * my + dn2 * (-2 * my) + dd1 * 2 * mx + dd2 * (-2 * mx);
                     double d_exx = dd2;

@@ -121,7 +121,7 @@ def ssim_mean(x, y):
     o = torch.nn.functional.conv2d(inp, k2, groups=3)
     mx, my, exx, eyy, exy = o[0:1], o[1:2], o[2:3], o[3:4], o[4:5]
     c1, c2 = 0.01 ** 2, 0.03 ** 2
-    sxx = exx - mx * mx; syy = eyy - my * my; sxy = exy - mx * my
+    sxx = torch.clamp(exx - mx * mx, min=0); syy = torch.clamp(eyy - my * my, min=0); sxy = exy - mx * my   # torchmetrics
     s = ((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2))
     s = s[..., 5:-5, 5:-5]
     return s.reshape(1, -1).mean()

@@ -31,6 +31,7 @@ SIGNATURES = {
     "st3r_gs_isect_scan": [vp, vp, i64, vp, vp, C.POINTER(i64)],
     "st3r_gs_isect_emit": [vp, vp, i32, i32, vp, vp, i32, i32, i32, i64, vp, vp],
     "st3r_gs_sort": [vp, vp, i64, i32, vp, vp, vp, vp],
+    "st3r_radix_sort_pairs": [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp],
     "st3r_gs_offsets": [vp, vp, i64, vp, i32, i32, i32, vp],
     "st3r_gs_blend_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp],
     "st3r_gs_blend_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp],

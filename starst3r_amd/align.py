@@ -16,7 +16,8 @@ PARAM_KEYS = ("pps", "log_focals", "quats", "trans", "log_sizes")
 def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, loss_dust3r_w=0.01, device="cuda:0"):
     """flat: dict of numpy arrays (starst3r_amd.synth_align.flatten layout).
     Returns (result, params): result has intrinsics [C,3,3], cam2w [C,4,4], depthmaps [C,G], pts3d [A,3],
-    losses [niter1+niter2]; params holds the optimised parameters (and the normalised core_depth) so that a
+    losses [niter1+niter2] (st3r_align_run stops updating after a NaN loss, like the reference's `break` at
+    starster/reconstruct.py:397-398: the remaining entries stay 0); params holds the optimised parameters (and the normalised core_depth) so that a
     later call can warm start from them (reconstruct.py:408-415)."""
     ctx = ops.get_context(device)
     dev = ctx.device
@@ -64,8 +65,10 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
                 prev = torch.stack([torch.as_tensor(x).reshape(-1) for x in prev])
             prev = (prev.detach() if torch.is_tensor(prev) else torch.as_tensor(np.asarray(prev))).to(dev, torch.float32)
             n = min(prev.shape[0], Cn)
-            if prev.shape[1] == core.shape[1]:
-                core[:n] = prev[:n]
+            if prev.shape[1] != core.shape[1]:
+                raise ValueError(f"warm start: the previous core depth has {prev.shape[1]} values per view, this call "
+                                 f"{core.shape[1]} (image size or subsampling changed between add_images calls)")
+            core[:n] = prev[:n]
     work = torch.zeros(66 * Cn + 8, device=dev)
     cam = torch.empty(Cn, 24, device=dev)
     A = anchor_idx.numel()

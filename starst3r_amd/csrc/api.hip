@@ -201,7 +201,7 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        const int32_t* cum, int tight, int64_t n_pairs, float* v_splats);
+                        const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -217,7 +217,7 @@ static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } r
     }
 
 struct RasterOut {
-    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
+    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; uint64_t* rects; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
 };
 
 // project -> scan -> emit -> sort -> offsets, all in ctx scratch
@@ -244,13 +244,11 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     // Level-1 keys.  Up to 8 local views: one 32-bit word, camera (3 bits) | depth bits minus those of the near plane
     // (the reference's near = 0.01 and far = 1e10 span < 2^29 float codes) -- the same order as (camera | depth) at
     // 8 instead of 12 bytes per pair and one radix pass less.  More views: 64-bit (camera << 32 | depth bits).
-    // rocPRIM sorts <= 2^20 items with a merge sort that is slower than its radix path: short inputs are padded
-    // with maximal keys (they stay behind everything, the sort being stable).
     const float near_plane = 0.01f, far_plane = 1e10f;
     uint32_t near_bits, far_bits;
     memcpy(&near_bits, &near_plane, 4); memcpy(&far_bits, &far_plane, 4);
     const bool key32 = (C <= 8) && (far_bits - near_bits < 0x1FFFFFFFu);
-    const int64_t n_sort = n_pairs <= (1 << 20) ? (1 << 20) + 1 : n_pairs;
+    const int64_t n_sort = n_pairs;
     GET(SLOT_DKEYS_A, uint64_t, n_sort, dkeys_a);
     GET(SLOT_DKEYS_B, uint64_t, n_sort, dkeys_b);
     GET(SLOT_DVALS_A, int32_t, n_sort, dvals_a);
@@ -269,10 +267,6 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
-    if (n_sort > n_pairs) {
-        const size_t ksz = key32 ? 4 : 8;
-        HIP_TRY(hipMemsetAsync((char*)dkeys_a + ksz * (size_t)n_pairs, 0xFF, ksz * (size_t)(n_sort - n_pairs), s));
-    }
     const int cam_bits = bit_length_u32((uint32_t)(C - 1));
     rc = key32 ? st3r_sort_depth32_impl(ctx, s, n_sort, 29 + cam_bits, (uint32_t*)dkeys_a, dvals_a, (uint32_t*)dkeys_b,
                                         perm)
@@ -320,7 +314,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     rc = st3r_isect_offsets32_impl(s, n_isects, tkeys_b, C, tile_w, tile_h, offsets);
     st3r_prof_end(ctx, s, STG_OFFSETS);
     if (rc) return rc;
-    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->n_isects = n_isects;
+    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->rects = rects; o->n_isects = n_isects;
     o->tile_w = tile_w; o->tile_h = tile_h;
     return ST3R_OK;
 }
@@ -343,6 +337,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
                                       float ssim_fac, float opac_fac, float scale_fac, float* grads,
                                       float* loss_out, int64_t* stats_host) {
     ARG_CHECK(ctx && N > 0 && C > 0 && C <= ST3R_MAX_VIEWS && width > 0 && height > 0 && sh_stride >= 12);
+    ARG_CHECK((int64_t)N * C < 2147483647LL);   // pair ids, tile counts and their scans are int32
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && gt_images && grads && loss_out);
     hipStream_t s = (hipStream_t)stream;
     const int W = width, H = height;
@@ -372,7 +367,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, 1, n_pairs, v_splats);
+                             last, v_rgb, nullptr, ro.cum, ro.rects, 1, n_pairs, v_splats);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
@@ -400,6 +395,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
                                      const float* gt_images, int width, int height, float ssim_fac,
                                      float* v_records, float* loss_out, int64_t* stats_host) {
     ARG_CHECK(ctx && N > 0 && C > 0 && width > 0 && height > 0 && records && gt_images && v_records && loss_out);
+    ARG_CHECK(C <= ST3R_MAX_VIEWS && (int64_t)N * C < 2147483647LL);
     hipStream_t s = (hipStream_t)stream;
     const int W = width, H = height;
     const int64_t n_pairs = (int64_t)N * C, n_px = (int64_t)C * H * W;
@@ -427,7 +423,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, 1, n_pairs, v_records);
+                             last, v_rgb, nullptr, ro.cum, ro.rects, 1, n_pairs, v_records);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     const int Hi = H - 10, Wi = W - 10;
@@ -446,6 +442,8 @@ ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const 
                                const float* viewmats, const float* Ks, const float* campos, int width, int height,
                                float* rgb, float* alpha, int64_t* stats_host) {
     ARG_CHECK(ctx && N > 0 && C > 0 && width > 0 && height > 0 && sh_stride >= 12);
+    // the projection kernel keeps C * 128 B of camera constants in LDS; pair ids are int32
+    ARG_CHECK(C <= ST3R_MAX_VIEWS && (int64_t)N * C < 2147483647LL);
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && rgb && alpha);
     hipStream_t s = (hipStream_t)stream;
     RasterOut ro;

@@ -72,16 +72,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int32_t* __r
 // single block: exclusive scan of block_sums in place; grand total -> total_out[0]
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(int32_t* __restrict__ block_sums, int nblocks,
                                                                  int32_t* __restrict__ total_out) {
-    int carry = 0;
+    // the running total is kept in 64 bits: a grand total past 2^31 - 1 is reported as -1 (the callers turn a
+    // negative count into ST3R_ERR_INVALID) instead of wrapping silently
+    int64_t carry = 0;
     for (int base = 0; base < nblocks; base += SCAN_THREADS) {
         int idx = base + threadIdx.x;
         int v = idx < nblocks ? block_sums[idx] : 0;
         int total;
         int inc = block_incl_scan(v, &total);
-        if (idx < nblocks) block_sums[idx] = carry + inc - v;
-        carry += total;
+        if (idx < nblocks) block_sums[idx] = (int)carry + inc - v;
+        carry += (int64_t)(uint32_t)total;   // a block total < 2^32 (4096 counts < 2^20 each)
     }
-    if (threadIdx.x == 0) total_out[0] = carry;
+    if (threadIdx.x == 0) total_out[0] = carry > 2147483647LL ? -1 : (int32_t)carry;
 }
 
 // (in may alias out: the block loads its whole tile before it stores any of it)

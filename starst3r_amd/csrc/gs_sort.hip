@@ -1,74 +1,35 @@
 // K4: stable ascending sort of the (isect key, pair id) stream on bits [0, end_bit).
 // Replaces cub::DeviceRadixSort::SortPairs as used by gsplat (starster/gs.py:76).
-//
-// Round-1 implementation: rocPRIM's device radix sort (the ROCm counterpart of the cub call
-// the reference reaches); the (tile | depth) structure of the key is exploited by the
-// planned two-level sort (DESIGN.md "sort").
+// The sort itself is the hand-written onesweep radix sort of radix_sort.hip; this file binds it to the four key
+// shapes of the pipeline (64-bit gsplat keys of the stage API; level-1 (camera | depth) keys, 32- or 64-bit; level-2
+// (camera, tile) keys of the fused two-level path -- see gs_isect.hip).
 #include "common.h"
-
-#include <rocprim/rocprim.hpp>
+#include "radix_sort.h"
 
 int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t* keys_in, int32_t* vals_in,
                    int64_t* keys_out, int32_t* vals_out) {
-    if (n == 0) return ST3R_OK;
     if (end_bit > 64) end_bit = 64;
-    size_t tmp_bytes = 0;
     // keys are non-negative (camera id in the top bits, sign clear): sort them as unsigned
-    auto* ki = reinterpret_cast<uint64_t*>(keys_in);
-    auto* ko = reinterpret_cast<uint64_t*>(keys_out);
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ki, ko, vals_in, vals_out, (size_t)n, 0u,
-                                      (unsigned)end_bit, s));
-    void* tmp;
-    int rc = st3r_arena_get(ctx, SLOT_SORT_TMP, tmp_bytes, &tmp);
-    if (rc) return rc;
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, ki, ko, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit,
-                                      s));
-    return ST3R_OK;
+    return st3r_radix_sort_u64(ctx, s, n, 0, end_bit, reinterpret_cast<const uint64_t*>(keys_in), vals_in,
+                               reinterpret_cast<uint64_t*>(keys_out), vals_out);
 }
 
 // 64-bit (camera | depth) keys of the two-level sort, value = pair id
 int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint64_t* keys_in, int32_t* vals_in,
                          uint64_t* keys_out, int32_t* vals_out) {
-    if (n == 0) return ST3R_OK;
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                      (unsigned)end_bit, s));
-    void* tmp;
-    int rc = st3r_arena_get(ctx, SLOT_SORT_TMP, tmp_bytes, &tmp);
-    if (rc) return rc;
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                      (unsigned)end_bit, s));
-    return ST3R_OK;
+    return st3r_radix_sort_u64(ctx, s, n, 0, end_bit, keys_in, vals_in, keys_out, vals_out);
 }
 
 // packed 32-bit (camera | depth - near) keys of the level-1 sort (C <= 8)
 int st3r_sort_depth32_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
                            uint32_t* keys_out, int32_t* vals_out) {
-    if (n == 0) return ST3R_OK;
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                      (unsigned)end_bit, s));
-    void* tmp;
-    int rc = st3r_arena_get(ctx, SLOT_SORT_TMP, tmp_bytes, &tmp);
-    if (rc) return rc;
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit,
-                                      s));
-    return ST3R_OK;
+    return st3r_radix_sort_u32(ctx, s, n, 0, end_bit, keys_in, vals_in, keys_out, vals_out);
 }
 
 // 32-bit (camera, tile) keys, stable: keeps the depth order established by the first level
 int st3r_sort_tile_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
                         uint32_t* keys_out, int32_t* vals_out) {
-    if (n == 0) return ST3R_OK;
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                      (unsigned)end_bit, s));
-    void* tmp;
-    int rc = st3r_arena_get(ctx, SLOT_SORT_TMP, tmp_bytes, &tmp);
-    if (rc) return rc;
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                      (unsigned)end_bit, s));
-    return ST3R_OK;
+    return st3r_radix_sort_u32(ctx, s, n, 0, end_bit, keys_in, vals_in, keys_out, vals_out);
 }
 
 ST3R_EXPORT int st3r_gs_sort(st3r_ctx* ctx, void* stream, int64_t n_isects, int end_bit, int64_t* isect_ids,
@@ -78,4 +39,17 @@ ST3R_EXPORT int st3r_gs_sort(st3r_ctx* ctx, void* stream, int64_t n_isects, int 
     ARG_CHECK(isect_ids && flatten_ids && isect_ids_sorted && flatten_ids_sorted);
     return st3r_sort_impl(ctx, (hipStream_t)stream, n_isects, end_bit, isect_ids, flatten_ids, isect_ids_sorted,
                           flatten_ids_sorted);
+}
+
+ST3R_EXPORT int st3r_radix_sort_pairs(st3r_ctx* ctx, void* stream, int key_bytes, int64_t n, int begin_bit, int end_bit,
+                                      const void* keys_in, const int32_t* vals_in, void* keys_out, int32_t* vals_out) {
+    ARG_CHECK(ctx && n >= 0 && (key_bytes == 4 || key_bytes == 8) && begin_bit >= 0 && end_bit > begin_bit);
+    ARG_CHECK(end_bit <= 8 * key_bytes && n < 2147483647LL);
+    if (n == 0) return ST3R_OK;
+    ARG_CHECK(keys_in && keys_out && ((vals_in == nullptr) == (vals_out == nullptr)));
+    if (key_bytes == 4)
+        return st3r_radix_sort_u32(ctx, (hipStream_t)stream, n, begin_bit, end_bit, (const uint32_t*)keys_in, vals_in,
+                                   (uint32_t*)keys_out, vals_out);
+    return st3r_radix_sort_u64(ctx, (hipStream_t)stream, n, begin_bit, end_bit, (const uint64_t*)keys_in, vals_in,
+                               (uint64_t*)keys_out, vals_out);
 }

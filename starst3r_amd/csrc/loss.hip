@@ -131,7 +131,10 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
                             mx += w * ring[slot][0]; my += w * ring[slot][1]; exx += w * ring[slot][2];
                             eyy += w * ring[slot][3]; exy += w * ring[slot][4];
                         }
-                        const float sxx = exx - mx * mx, syy = eyy - my * my, sxy = exy - mx * my;
+                        // variances clamped at 0 like torchmetrics (torch.clamp(E[x^2] - mu^2, min=0)): float cancellation on flat
+                        // regions would otherwise leave them slightly negative; a clamped sigma_x^2 passes no gradient
+                        const float sxx_raw = exx - mx * mx;
+                        const float sxx = fmaxf(sxx_raw, 0.f), syy = fmaxf(eyy - my * my, 0.f), sxy = exy - mx * my;
                         const float n1 = 2.f * mx * my + c1, n2 = 2.f * sxy + c2;
                         const float dd1 = mx * mx + my * my + c1, dd2 = sxx + syy + c2;
                         // v_rcp_f32 (1 ulp) instead of three IEEE divisions (~10 instructions each): the kernel is
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
                         const float ssim = n1 * n2 * inv;
                         ssim_acc += ssim;
                         const float dn1 = n2 * inv, dn2 = n1 * inv;
-                        const float g1 = -ssim * inv1, g2 = -ssim * inv2;
+                        const float g1 = -ssim * inv1, g2 = sxx_raw < 0.f ? 0.f : -ssim * inv2;
                         d0 = 2.f * my * (dn1 - dn2) + 2.f * mx * (g1 - g2);  // dS/dmu_x
                         d1 = g2;                                             // dS/dE[x^2]
                         d2 = 2.f * dn2;                                      // dS/dE[xy]
@@ -257,7 +260,10 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                                         mx += w * ring[slot][0]; my += w * ring[slot][1]; exx += w * ring[slot][2];
                                         eyy += w * ring[slot][3]; exy += w * ring[slot][4];
                                     }
-                                    const float sxx = exx - mx * mx, syy = eyy - my * my, sxy = exy - mx * my;
+                                    // variances clamped at 0 like torchmetrics (torch.clamp(E[x^2] - mu^2, min=0)): float cancellation on flat
+                        // regions would otherwise leave them slightly negative; a clamped sigma_x^2 passes no gradient
+                        const float sxx_raw = exx - mx * mx;
+                        const float sxx = fmaxf(sxx_raw, 0.f), syy = fmaxf(eyy - my * my, 0.f), sxy = exy - mx * my;
                                     const float n1 = 2.f * mx * my + c1, n2 = 2.f * sxy + c2;
                                     const float dd1 = mx * mx + my * my + c1, dd2 = sxx + syy + c2;
                                     const float inv1 = __builtin_amdgcn_rcpf(dd1), inv2 = __builtin_amdgcn_rcpf(dd2);
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                                     const float ssim = n1 * n2 * inv;
                                     if (own_col && id >= i0 && id < i0 + rows_out) ssim_acc += ssim;  // one strip counts it
                                     const float dn1 = n2 * inv, dn2 = n1 * inv;
-                                    const float g1 = -ssim * inv1, g2 = -ssim * inv2;
+                                    const float g1 = -ssim * inv1, g2 = sxx_raw < 0.f ? 0.f : -ssim * inv2;
                                     d0 = 2.f * my * (dn1 - dn2) + 2.f * mx * (g1 - g2);  // dS/dmu_x
                                     d1 = g2;                                             // dS/dE[x^2]
                                     d2 = 2.f * dn2;                                      // dS/dE[xy]

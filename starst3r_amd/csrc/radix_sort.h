@@ -1,0 +1,15 @@
+// Hand-written LSD radix sort of (key, int32 value) pairs for gfx950: one histogram launch for all digits, then one
+// "onesweep" launch per 8-bit digit (chained scan with decoupled look-back, Adinets & Merrill 2022, restated here
+// for wave64 / 160 KB LDS).  Replaces cub::DeviceRadixSort::SortPairs as reached from gsplat's isect_tiles
+// (starster/gs.py:76); stable, ascending, bits [begin_bit, end_bit).
+#pragma once
+#include "common.h"
+
+// scratch bytes needed in SLOT_SORT_TMP for n items of key size key_bytes (both ping-pong buffers included)
+size_t st3r_radix_sort_scratch_bytes(int64_t n, int key_bytes, int begin_bit, int end_bit);
+
+// keys_in/vals_in are left untouched; the result lands in keys_out/vals_out.  vals may be NULL (keys only).
+int st3r_radix_sort_u32(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint32_t* keys_in,
+                        const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out);
+int st3r_radix_sort_u64(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint64_t* keys_in,
+                        const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out);

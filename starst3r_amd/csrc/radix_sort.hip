@@ -1,0 +1,294 @@
+// K4: stable ascending LSD radix sort of (key, int32 value) pairs, hand-written for gfx950.
+// Replaces cub::DeviceRadixSort::SortPairs as used by gsplat's isect_tiles (starster/gs.py:76); round 1 called
+// rocPRIM here.
+//
+// Structure ("onesweep", Adinets & Merrill 2022, restated for wave64 and 160 KB of LDS):
+//   k_rs_hist        one pass over the keys: 256-bin histograms of ALL digits at once (LDS atomics; a wave whose
+//                    lanes agree on a digit -- the rule for the high digits of depth / tile keys -- adds once);
+//   k_rs_scan_hist   exclusive scan of each histogram = global base of every bin;
+//   k_rs_pass        one launch per 8-bit digit.  A workgroup (8 waves) owns a tile of 8192 (32-bit keys) or 4096
+//                    (64-bit keys) consecutive items.  Ranking is wave-local and stable: wave w holds items
+//                    [w*64*IPT, (w+1)*64*IPT) of the tile as IPT rows of 64 consecutive items; per row the lanes
+//                    find their equals with 8 ballots (match-any), rank = running wave count of the digit (LDS) +
+//                    number of equal lanes below.  The per-digit tile counts then travel through a chained scan with
+//                    decoupled look-back: one 8-byte {flag, count} word per (tile, digit), published and polled
+//                    with relaxed agent-scope atomics (flag and value in ONE word, so no fences are needed and the
+//                    protocol is independent of XCD placement); tiles are handed out by an atomic ticket so that
+//                    every predecessor of a running tile is itself running.  Items are regrouped by digit in LDS
+//                    and leave in runs that are contiguous in the destination.
+// Traffic per pass: one read and one write of keys and values (+ 2 KB of status words per tile).
+#include "radix_sort.h"
+
+namespace {
+
+constexpr int RB = 8;
+constexpr int RADIX = 1 << RB;
+constexpr int THREADS = 512;
+constexpr int WAVES = THREADS / 64;
+constexpr int HIST_THREADS = 256;
+constexpr int HIST_ITEMS = 16;
+constexpr int MAX_PASSES = 8;
+
+typedef unsigned long long u64;
+constexpr u64 FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, VALUE_MASK = (1ull << 62) - 1;
+
+template <typename K> struct Traits;
+template <> struct Traits<uint32_t> { static constexpr int IPT = 16; };
+template <> struct Traits<uint64_t> { static constexpr int IPT = 8; };
+
+__device__ __forceinline__ int wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+template <typename K>
+__global__ __launch_bounds__(HIST_THREADS) void k_rs_hist(const K* __restrict__ keys, int64_t n, int begin_bit,
+                                                          int end_bit, int passes, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[MAX_PASSES * RADIX];
+    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS) sh[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    constexpr int CH = HIST_THREADS * HIST_ITEMS;
+    for (int64_t base = (int64_t)blockIdx.x * CH; base < n; base += (int64_t)gridDim.x * CH) {
+#pragma unroll 4
+        for (int i = 0; i < HIST_ITEMS; ++i) {
+            const int64_t idx = base + i * HIST_THREADS + threadIdx.x;
+            const bool valid = idx < n;
+            const K k = valid ? keys[idx] : K(0);
+            const u64 act = __ballot(valid);
+            if (act == 0) continue;
+            for (int p = 0; p < passes; ++p) {
+                const int shift = begin_bit + RB * p;
+                const int bits = min(RB, end_bit - shift);
+                const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);   // first ACTIVE lane of the wave
+                if (__ballot(valid && d == d0) == act) {
+                    if (lane == (int)__builtin_ctzll(act)) atomicAdd(&sh[p * RADIX + d0], (uint32_t)__popcll(act));
+                } else if (valid) {
+                    atomicAdd(&sh[p * RADIX + d], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS)
+        if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// hist[p][d] <- exclusive prefix over d (one workgroup of 256 threads)
+__global__ __launch_bounds__(RADIX) void k_rs_scan_hist(uint32_t* __restrict__ hist, int passes) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t v = hist[p * RADIX + threadIdx.x];
+        const uint32_t inc = wave_incl_scan_u32(v, lane);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base += i < w ? wsum[i] : 0u;
+        hist[p * RADIX + threadIdx.x] = base + inc - v;
+        __syncthreads();
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, const int32_t* __restrict__ vin,
+                                                     K* __restrict__ kout, int32_t* __restrict__ vout, int64_t n,
+                                                     int shift, int bits, const uint32_t* __restrict__ hist_base,
+                                                     u64* status, uint32_t* tile_counter) {
+    constexpr int IPT = Traits<K>::IPT;
+    constexpr int TILE = THREADS * IPT;
+    __shared__ K sbuf[TILE];
+    __shared__ uint32_t whist[WAVES][RADIX];
+    __shared__ uint32_t lbase[RADIX];
+    __shared__ long long gofs[RADIX];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+    for (int i = tid; i < WAVES * RADIX; i += THREADS) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const int64_t tbase = (int64_t)tile * TILE;
+    const int tcount = (int)min((int64_t)TILE, n - tbase);
+    const uint32_t dmask = (1u << bits) - 1u;
+    const int wbase = w * 64 * IPT + lane;
+
+    K key[IPT];
+    uint32_t rank[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int li = wbase + i * 64;
+        key[i] = li < tcount ? kin[tbase + li] : K(0);
+    }
+    const u64 lt = (1ull << lane) - 1ull;
+    uint32_t* wh = whist[w];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const bool valid = wbase + i * 64 < tcount;
+        const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t below = (uint32_t)__popcll(m & lt);
+        const uint32_t prev = wh[d];
+        if (valid && below == 0) wh[d] = prev + (uint32_t)__popcll(m);
+        rank[i] = prev + below;
+    }
+    __syncthreads();
+
+    // per digit: exclusive scan over the waves (in place), tile count, chained scan over the tiles
+    uint32_t cnt = 0;
+    u64 excl = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) {
+            const uint32_t c = whist[ww][tid];
+            whist[ww][tid] = cnt;
+            cnt += c;
+        }
+        u64* st = status + (size_t)tile * RADIX + tid;
+        if (tile == 0) {
+            __hip_atomic_store(st, FLAG_INC | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(st, FLAG_AGG | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t t = (int64_t)tile - 1; t >= 0; --t) {
+                const u64* pt = status + (size_t)t * RADIX + tid;
+                u64 v = __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while ((v >> 62) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    v = __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // a predecessor always holds an earlier ticket, i.e. it is running: this bound (seconds) can only
+                    // trip on a broken device or a protocol bug, and then it must be loud rather than a hang
+                    if (++spins > (1u << 26)) __builtin_trap();
+                }
+                excl += v & VALUE_MASK;
+                if ((v >> 62) == 2) break;
+            }
+            __hip_atomic_store(st, FLAG_INC | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // tile-local exclusive scan of the digit counts
+    const uint32_t inc = wave_incl_scan_u32(cnt, lane);
+    if (tid < RADIX && lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base += i < w ? wsum[i] : 0u;
+        const uint32_t lb = base + inc - cnt;
+        lbase[tid] = lb;
+        gofs[tid] = (long long)((u64)hist_base[tid] + excl) - (long long)lb;
+    }
+    __syncthreads();
+
+    // regroup by digit in LDS, then leave in runs that are contiguous in the destination
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        if (wbase + i * 64 < tcount) {
+            const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
+            const uint32_t pos = lbase[d] + wh[d] + rank[i];
+            rank[i] = pos;
+            sbuf[pos] = key[i];
+        }
+    }
+    __syncthreads();
+    uint32_t dig[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int p = i * THREADS + tid;
+        dig[i] = 0;
+        if (p < tcount) {
+            const K k = sbuf[p];
+            const uint32_t d = (uint32_t)(k >> shift) & dmask;
+            dig[i] = d;
+            kout[gofs[d] + p] = k;
+        }
+    }
+    if (vin) {
+        __syncthreads();
+        int32_t* sv = reinterpret_cast<int32_t*>(sbuf);
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int li = wbase + i * 64;
+            if (li < tcount) sv[rank[i]] = vin[tbase + li];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int p = i * THREADS + tid;
+            if (p < tcount) vout[gofs[dig[i]] + p] = sv[p];
+        }
+    }
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+template <typename K>
+int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const K* keys_in,
+               const int32_t* vals_in, K* keys_out, int32_t* vals_out) {
+    if (n == 0) return ST3R_OK;
+    if (end_bit > (int)sizeof(K) * 8) end_bit = (int)sizeof(K) * 8;
+    if (begin_bit < 0 || begin_bit >= end_bit) { st3r_set_error("radix sort: empty bit range"); return ST3R_ERR_INVALID; }
+    const int passes = (end_bit - begin_bit + RB - 1) / RB;
+    constexpr int TILE = THREADS * Traits<K>::IPT;
+    const int64_t ntiles = (n + TILE - 1) / TILE;
+    const size_t hist_bytes = align256(sizeof(uint32_t) * (size_t)(passes * RADIX + MAX_PASSES));
+    const size_t status_bytes = sizeof(u64) * (size_t)passes * (size_t)ntiles * RADIX;
+    const size_t meta_bytes = hist_bytes + align256(status_bytes);
+    const bool need_tmp = passes > 1;
+    const size_t tk_bytes = need_tmp ? align256(sizeof(K) * (size_t)n) : 0;
+    const size_t tv_bytes = need_tmp && vals_in ? align256(sizeof(int32_t) * (size_t)n) : 0;
+    void* p;
+    int rc = st3r_arena_get(ctx, SLOT_SORT_TMP, meta_bytes + tk_bytes + tv_bytes, &p);
+    if (rc) return rc;
+    char* base = (char*)p;
+    uint32_t* hist = (uint32_t*)base;
+    uint32_t* counters = hist + passes * RADIX;
+    u64* status = (u64*)(base + hist_bytes);
+    K* tk = (K*)(base + meta_bytes);
+    int32_t* tv = (int32_t*)(base + meta_bytes + tk_bytes);
+    HIP_TRY(hipMemsetAsync(base, 0, meta_bytes, s));
+    const int hist_blocks = (int)min((int64_t)1024, (n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
+    hipLaunchKernelGGL(k_rs_hist<K>, dim3(hist_blocks), dim3(HIST_THREADS), 0, s, keys_in, n, begin_bit, end_bit, passes,
+                       hist);
+    hipLaunchKernelGGL(k_rs_scan_hist, dim3(1), dim3(RADIX), 0, s, hist, passes);
+    const K* kin = keys_in;
+    const int32_t* vin = vals_in;
+    for (int ps = 0; ps < passes; ++ps) {
+        // the last pass writes the caller's output; before that the passes alternate between it and the scratch
+        const bool to_out = ((passes - 1 - ps) & 1) == 0;
+        K* ko = to_out ? keys_out : tk;
+        int32_t* vo = to_out ? vals_out : tv;
+        const int shift = begin_bit + RB * ps;
+        const int bits = min(RB, end_bit - shift);
+        hipLaunchKernelGGL(k_rs_pass<K>, dim3((unsigned)ntiles), dim3(THREADS), 0, s, kin, vin, ko, vin ? vo : nullptr, n,
+                           shift, bits, hist + ps * RADIX, status + (size_t)ps * ntiles * RADIX, counters + ps);
+        kin = ko;
+        if (vin) vin = vo;
+    }
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+}  // namespace
+
+int st3r_radix_sort_u32(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint32_t* keys_in,
+                        const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out) {
+    return sort_pairs<uint32_t>(ctx, s, n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out);
+}
+
+int st3r_radix_sort_u64(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint64_t* keys_in,
+                        const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out) {
+    return sort_pairs<uint64_t>(ctx, s, n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out);
+}

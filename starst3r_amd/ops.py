@@ -117,6 +117,19 @@ def isect(ctx, splats, tiles, N, Cn, W, H):
     return cum, ids, flat
 
 
+def radix_sort_pairs(ctx, keys, vals, begin_bit, end_bit):
+    """Stable ascending radix sort of (key, int32 value) pairs on key bits [begin_bit, end_bit).  keys: int32 or
+    int64 tensor holding UNSIGNED 32/64-bit patterns; vals int32 or None.  Inputs are left untouched."""
+    assert keys.dtype in (torch.int32, torch.int64)
+    kb = 4 if keys.dtype == torch.int32 else 8
+    ko = torch.empty_like(keys)
+    vo = torch.empty_like(vals) if vals is not None else None
+    _lib.check(_lib.lib().st3r_radix_sort_pairs(ctx.handle, _stream(), kb, keys.numel(), begin_bit, end_bit,
+                                                _p(keys, keys.dtype), _p(vals, torch.int32), _p(ko, keys.dtype),
+                                                _p(vo, torch.int32)))
+    return ko, vo
+
+
 def sort_pairs(ctx, ids, flat, end_bit):
     ids_in, flat_in = ids.clone(), flat.clone()
     ids_out, flat_out = torch.empty_like(ids), torch.empty_like(flat)

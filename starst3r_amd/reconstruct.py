@@ -99,6 +99,12 @@ def flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchor
         return np.ascontiguousarray(x).astype(dt)
 
     C = len(imgs)
+    grid_sizes = sorted({int(np.prod(np.shape(npy(d, np.float32)))) for d in core_depth})
+    if len(grid_sizes) > 1:
+        # the reference (and Mast3r) keep per-view lists and accept mixed aspect ratios; st3r_align_run takes one
+        # [C, G] block -- fail loudly instead of stacking ragged rows
+        raise ValueError(f"views with different subsampled depth-grid sizes {grid_sizes} are not supported by "
+                         "st3r_align_run: resize the images to one size (Scene.add_images does)")
     counts = [len(anchors[v][1]) for v in range(C)]
     anchor_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     rng = lambda sl, n: np.arange(n)[sl]
