@@ -94,10 +94,8 @@ struct st3r_ctx {
     size_t slot_bytes[SLOT_COUNT];
     int64_t* pinned;  // small pinned host buffer for read-backs
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
-    int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test,
-                      // bit 1 = round-1 blend backward kernel (A/B timing)
+    int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
-    int bwd_variant;  // which backward kernel wrote the stamps (they are cleared when it changes)
     void* comm;     // ncclComm_t of the view-sharded job (NULL: single replica)
     int comm_owned, comm_rank, comm_size;
     int prof_enabled;

@@ -387,7 +387,7 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
 }
 
 template <bool HAS_VA>  // v_alpha is NULL in the train step (the reference's loss ignores render_alpha, gs.py:126)
-__global__ __launch_bounds__(BLK) void k_blend_bwd_v1(int C, int W, int H, int tile_w, int tile_h,
+__global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
                                                    const int32_t* __restrict__ offsets,
                                                    const int32_t* __restrict__ flat, int n_isects,
@@ -397,7 +397,8 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd_v1(int C, int W, int H, int t
                                                    const float* __restrict__ v_alpha,
                                                    const uint64_t* __restrict__ cmask, int64_t cmask_words,
                                                    const int32_t* __restrict__ tile_nb,
-                                                   const int32_t* __restrict__ cum, int tight,
+                                                   const int32_t* __restrict__ cum,
+                                                   const uint64_t* __restrict__ rects, int tight,
                                                    float* __restrict__ vtile, int32_t* __restrict__ vstamp,
                                                    int stamp) {
     // staged records, same q-form as the forward's but as three arrays (measured: the forward is faster with one
@@ -470,11 +471,18 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd_v1(int C, int W, int H, int t
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
             if (my_cb) {
-                const float radius = (float)__float_as_int(c.z);
-                TileRect tr = ref_tile_rect(a.x, a.y, radius, 16, tile_w, tile_h);
-                if (tight) tr = tight_tile_rect(tr, a.x, a.y, a.z, a.w, b.x, b.y);
+                int x0, y0, rw;
+                if (rects) {   // fused path: the packed rectangle the emit kernel used (one 8-byte load instead of
+                               // ~100 instructions of tight_tile_rect)
+                    const uint64_t r = rects[my_id];
+                    x0 = (int)(r & 0xFFFF); y0 = (int)((r >> 16) & 0xFFFF); rw = (int)((r >> 32) & 0xFFFF);
+                } else {
+                    TileRect tr = ref_tile_rect(a.x, a.y, (float)__float_as_int(c.z), 16, tile_w, tile_h);
+                    if (tight) tr = tight_tile_rect(tr, a.x, a.y, a.z, a.w, b.x, b.y);
+                    x0 = tr.x0; y0 = tr.y0; rw = tr.x1 - tr.x0;
+                }
                 const int cum_excl = my_id == 0 ? 0 : cum[my_id - 1];
-                my_u = cum_excl + ((g.ty0 >> 4) - tr.y0) * (tr.x1 - tr.x0) + ((g.tx0 >> 4) - tr.x0);
+                my_u = cum_excl + ((g.ty0 >> 4) - y0) * rw + ((g.tx0 >> 4) - x0);
                 my_op = a.z; my_ca = a.w; my_cbb = b.x; my_cc = b.y;
             }
         }
@@ -544,263 +552,6 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd_v1(int C, int W, int H, int t
     }
 }
 
-// ------------------------------------------------------------------------------------
-// backward, round 2: the pixel sums of phase 2 on the matrix pipe
-// ------------------------------------------------------------------------------------
-// The nine sums of a record over the 64 pixels of a wave are a small GEMM:
-//     [ sum g_o {1, x, y, x^2, xy, y^2} | sum fac {v_r, v_g, v_b} ]  =  [g_o ; fac] (records x pixels)  .  B (pixels x 9)
-// with (x, y) the pixel offset from the QUADRANT CENTRE (|x|, |y| <= 3.5: the raw moments; the record mean enters later,
-// exactly, in k_gather_vtile4) and B constant for the whole tile (moments of the pixel, its v_rgb).  Phase 1 (lanes =
-// pixels, unchanged) leaves g_o and fac of up to 8 records as rows 0..7 / 8..15 of a 16 x 64 wave-private LDS matrix;
-// 16 x v_mfma_f32_16x16x4_f32 (exact fp32 products, k-ordered fma chain: deterministic) contract it with B:
-//   A operand  lane (i = l & 15, kk = l >> 4) holds row i, pixels 16 c + 4 kk + e for the step s = 4 c + e, read as four
-//              ds_read_b128 (row stride 72 floats: conflict-free for the b128 lane groups of gfx950);
-//   B operand  lane (j = l & 15, kk) holds column j of the same pixel: 16 VGPRs set up once per tile;
-//   D          lane (j, q = l >> 4), register v = element (row 4 q + v, column j): rows 0..7 x columns 0..5 and rows
-//              8..15 x columns 6..8 are the wanted numbers (the other products are ignored).
-// The MFMA pipe is otherwise idle in this kernel and co-issues with the other waves' phase 1, so the ~19 VALU
-// instructions per (record, wave) of the register butterfly it replaces (permlane swaps + DPP) leave the VALU pipe.
-// The sums of a wave go straight from D to the wave's own 48-byte slot (record, tile, quadrant) in HBM -- a record meets
-// 1.04 waves of its tile on average, so combining the four waves in LDS first bought nothing: no accumulator rows, no
-// flush phase, one barrier per round less.  The staging lane stamps the (record, tile) entry with the set of quadrants that
-// contributed; k_gather_vtile4 sums a pair's slots in order, moves the moments from the quadrant centres to the record
-// mean and applies the record constants.  No atomics anywhere: gradients stay bit-reproducible.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define RS 72             // floats per row of the chunk matrix (16-byte aligned rows, conflict-free b128 reads)
-#define CHUNK8 8          // records per chunk: rows 0..7 = g_o, rows 8..15 = fac
-#define VT4_STRIDE 12     // floats per (record, tile, quadrant) slot: 6 raw moments, 3 colour sums, 3 pad
-
-template <bool HAS_VA>
-__global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
-                                                   const float4* __restrict__ splats,
-                                                   const int32_t* __restrict__ offsets,
-                                                   const int32_t* __restrict__ flat, int n_isects,
-                                                   const float* __restrict__ out_alpha,
-                                                   const int32_t* __restrict__ last_ids,
-                                                   const float* __restrict__ v_rgb,
-                                                   const float* __restrict__ v_alpha,
-                                                   const uint64_t* __restrict__ cmask, int64_t cmask_words,
-                                                   const int32_t* __restrict__ tile_nb,
-                                                   const int32_t* __restrict__ cum, const uint64_t* __restrict__ rects,
-                                                   int tight, float* __restrict__ vtile, int32_t* __restrict__ vstamp,
-                                                   int stamp) {
-    __shared__ float4 sA[HB];   // x y opacity qa
-    __shared__ float4 sB[HB];   // qb qc r g
-    __shared__ float sC[HB];    // b
-    __shared__ int sSlot[HB];   // (record, tile) slot of the staged record (-1: no wave of this tile met it)
-    __shared__ __attribute__((aligned(16))) float sRows[4][16 * RS];
-    const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
-    const int nb = tile_nb[g.lb];
-    if (nb == 0) return;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t p = ((int64_t)g.cam * H + g.i) * W + g.j;
-    float T_final = 1.0f, vr = 0.f, vg = 0.f, vb = 0.f, va = 0.f;
-    int bin_final = -1;
-    if (g.inside) {
-        T_final = 1.0f - out_alpha[p];
-        vr = v_rgb[3 * p]; vg = v_rgb[3 * p + 1]; vb = v_rgb[3 * p + 2];
-        if (HAS_VA) va = v_alpha[p];
-        bin_final = last_ids[p];
-    }
-    float* rows = sRows[w];
-    // B operands: step s = 4 c + e contracts the pixels 16 c + 4 kk + e (kk = K slot = lane >> 4)
-    float bop[16];
-    {
-        rows[lane] = vr; rows[64 + lane] = vg; rows[128 + lane] = vb;
-        wave_lds_sync();
-        const int j = lane & 15, kk = lane >> 4;
-        const int ch = min(max(j - 6, 0), 2);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int pix = 16 * (s >> 2) + 4 * kk + (s & 3);   // quadrant-local pixel index y * 8 + x
-            const float x = (float)(pix & 7) - 3.5f, y = (float)(pix >> 3) - 3.5f;
-            float v = 0.f;
-            v = j == 0 ? 1.f : v; v = j == 1 ? x : v; v = j == 2 ? y : v;
-            v = j == 3 ? x * x : v; v = j == 4 ? x * y : v; v = j == 5 ? y * y : v;
-            const float col = rows[ch * 64 + pix];
-            bop[s] = (j >= 6 && j < 9) ? col : v;
-        }
-        wave_lds_sync();
-    }
-    const float* arow = rows + (lane & 15) * RS + (lane >> 4) * 4;
-    float T = T_final;
-    float bv = 0.f;   // (colours blended behind the current record) . v_rgb
-    const int64_t mbase = mask_base(g.lb, g.start);
-    const uint64_t* wmask = cmask + (int64_t)__builtin_amdgcn_readfirstlane(w) * cmask_words + mbase;
-    uint64_t m_next = wmask[(BLK / HB) * nb - 1];
-    const int tile_tx = g.tx0 >> 4, tile_ty = g.ty0 >> 4;
-    for (int hb = (BLK / HB) * nb - 1; hb >= 0; --hb) {
-        const int bs = g.start + hb * HB;
-        const int bsz = min(HB, g.end - bs);
-        const uint64_t m_cur = m_next;
-        if (hb > 0) m_next = wmask[hb - 1];
-        if (bsz <= 0) continue;   // the tail of the last forward batch may be empty (uniform over the workgroup)
-        __syncthreads();
-        // ---- staging: one record per thread (threads 0..HB-1); a record some wave of the tile contributed to also gets
-        // its slot (cum_excl[pid] + index of this tile inside the record's tile rectangle) and its stamp now
-        if ((int)threadIdx.x < bsz) {
-            const int t = threadIdx.x;
-            const int64_t my_id = flat[bs + t];
-            const float4 a = splats[my_id * 3 + 0];   // x y opacity conic.a
-            const float4 b = splats[my_id * 3 + 1];   // conic.b conic.c r g
-            const float4 c = splats[my_id * 3 + 2];   // b depth radius 0
-            sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
-            sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
-            sC[t] = c.x;
-            const int64_t word = mbase + hb;   // HB = 64: one (wave-uniform) mask word per round and wave
-            int my_cb = 0;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
-            int my_u = -1;
-            if (my_cb) {
-                int x0, y0, rw;
-                if (rects) {   // fused path: the packed rectangle the emit kernel used
-                    const uint64_t r = rects[my_id];
-                    x0 = (int)(r & 0xFFFF); y0 = (int)((r >> 16) & 0xFFFF); rw = (int)((r >> 32) & 0xFFFF);
-                } else {
-                    TileRect tr = ref_tile_rect(a.x, a.y, (float)__float_as_int(c.z), 16, tile_w, tile_h);
-                    if (tight) tr = tight_tile_rect(tr, a.x, a.y, a.z, a.w, b.x, b.y);
-                    x0 = tr.x0; y0 = tr.y0; rw = tr.x1 - tr.x0;
-                }
-                const int cum_excl = my_id == 0 ? 0 : cum[my_id - 1];
-                my_u = cum_excl + (tile_ty - y0) * rw + (tile_tx - x0);
-                vstamp[my_u] = (stamp << 4) | my_cb;
-            }
-            sSlot[t] = my_u;
-        }
-        __syncthreads();
-        uint64_t m = m_cur;   // HB = 64: one mask word per round
-        while (m) {
-            // ---- phase 1: lanes are pixels; up to 8 records, back to front
-            unsigned tp_lo = 0, tp_hi = 0;
-            int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < CHUNK8; ++k) {
-                if (m) {
-                    const int t = 63 - __builtin_clzll(m);
-                    m &= ~(1ull << t);
-                    const float4 a = sA[t];
-                    const float4 q = sB[t];
-                    const float cb_ = sC[t];
-                    const float dx = a.x - g.px, dy = a.y - g.py;
-                    const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
-                    const float P = dx * lx + q.y * dy * dy;
-                    const float vis0 = __builtin_amdgcn_exp2f(P);
-                    const float ov0 = a.z * vis0;
-                    const float al0 = fminf(0.999f, ov0);
-                    // same include test as the forward pass (bin_final is -1 outside the image).  Branch-free: a
-                    // lane that does not include this record gets alpha = 0, hence 1/(1-alpha) = 1, fac = 0, g_o = 0.
-                    const bool valid = (bs + t <= bin_final) && !(P > 0.f) && !(al0 < 1.f / 255.f);
-                    const float alpha = valid ? al0 : 0.f;
-                    // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
-                    const float vis_u = (valid && ov0 <= 0.999f) ? vis0 : 0.f;
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    const float cv = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
-                    T *= ra;
-                    const float fac = alpha * T;
-                    float v_al = cv * T - bv * ra;
-                    if (HAS_VA) v_al += T_final * ra * va;
-                    bv += cv * fac;
-                    rows[k * RS + lane] = vis_u * v_al;
-                    rows[(CHUNK8 + k) * RS + lane] = fac;
-                    if (k < 4) tp_lo |= (unsigned)t << (8 * k); else tp_hi |= (unsigned)t << (8 * (k - 4));
-                    cnt = k + 1;
-                }
-            }
-            // ---- phase 2: [g_o ; fac] . B on the matrix pipe, D -> the wave's slots
-            wave_lds_sync();
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 av = *reinterpret_cast<const float4*>(arow + 16 * c);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bop[4 * c + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bop[4 * c + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bop[4 * c + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bop[4 * c + 3], acc, 0, 0, 0);
-            }
-            {
-                const int j = lane & 15, q = lane >> 4;
-                const bool colsel = q < 2 ? (j < 6) : (j >= 6 && j < 9);
-                const unsigned tp = (q & 1) ? tp_hi : tp_lo;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    if (colsel && 4 * (q & 1) + v < cnt) {
-                        const int t = (tp >> (8 * v)) & 0xFF;
-                        const int u = sSlot[t];
-                        vtile[((int64_t)u * 4 + w) * VT4_STRIDE + j] = acc[v];
-                    }
-                }
-            }
-            wave_lds_sync();
-        }
-    }
-}
-
-// v_splats[pid] = the pair's gradient: its (record, tile, quadrant) slots stamped by this backward call, summed in slot
-// order (deterministic).  A slot holds the raw moments of g_o about its quadrant centre c = (16 tx + 8 qx + 4, 16 ty +
-// 8 qy + 4); with e = mean2d - c and pixel = c + (x, y):  dx = mean - pixel = e - (x, y), hence
-//   S_x = e_x M_0 - M_x,   S_xx = e_x^2 M_0 - 2 e_x M_x + M_xx,   S_xy = e_x e_y M_0 - e_x M_y - e_y M_x + M_xy, ...
-// then the record constants:  v_sigma = -opacity g_o;  v_mean2d = v_sigma (a dx + b dy, b dx + c dy);
-// v_conic = v_sigma (dx^2 / 2, dx dy, dy^2 / 2).  One thread per (camera, gaussian) pair.
-__global__ __launch_bounds__(256) void k_gather_vtile4(int64_t n_pairs, const float4* __restrict__ splats,
-                                                       const uint64_t* __restrict__ rects,
-                                                       const int32_t* __restrict__ cum, int tight, int tile_w,
-                                                       int tile_h, const float* __restrict__ vtile,
-                                                       const int32_t* __restrict__ vstamp, int stamp,
-                                                       float4* __restrict__ v_splats) {
-    const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pid >= n_pairs) return;
-    const int end = cum[pid];
-    const int start = pid == 0 ? 0 : cum[pid - 1];
-    float So = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
-    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
-    if (end > start) {
-        const float4 a = splats[pid * 3 + 0];   // x y opacity conic.a
-        const float4 b = splats[pid * 3 + 1];   // conic.b conic.c r g
-        int x0, y0, rw;
-        if (rects) {
-            const uint64_t r = rects[pid];
-            x0 = (int)(r & 0xFFFF); y0 = (int)((r >> 16) & 0xFFFF); rw = (int)((r >> 32) & 0xFFFF);
-        } else {
-            const float4 c = splats[pid * 3 + 2];
-            TileRect tr = ref_tile_rect(a.x, a.y, (float)__float_as_int(c.z), 16, tile_w, tile_h);
-            if (tight) tr = tight_tile_rect(tr, a.x, a.y, a.z, a.w, b.x, b.y);
-            x0 = tr.x0; y0 = tr.y0; rw = tr.x1 - tr.x0;
-        }
-        int tx = x0, ty = y0;
-        for (int u = start; u < end; ++u) {
-            const int sv = vstamp[u];
-            if ((sv >> 4) == stamp) {   // the payload is only fetched for slots written by this backward call
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    if ((sv >> w) & 1) {
-                        const float4* src = reinterpret_cast<const float4*>(vtile + ((int64_t)u * 4 + w) * VT4_STRIDE);
-                        const float4 m0 = src[0], m1 = src[1];
-                        const float m8 = vtile[((int64_t)u * 4 + w) * VT4_STRIDE + 8];
-                        const float ex = a.x - (float)(16 * tx + 8 * (w & 1) + 4);
-                        const float ey = a.y - (float)(16 * ty + 8 * (w >> 1) + 4);
-                        So += m0.x;
-                        Sx += fmaf(ex, m0.x, -m0.y);
-                        Sy += fmaf(ey, m0.x, -m0.z);
-                        Sxx += fmaf(ex, fmaf(ex, m0.x, -2.f * m0.y), m0.w);
-                        Sxy += fmaf(ex, fmaf(ey, m0.x, -m0.z), fmaf(-ey, m0.y, m1.x));
-                        Syy += fmaf(ey, fmaf(ey, m0.x, -2.f * m0.z), m1.y);
-                        Sr += m1.z; Sg += m1.w; Sb += m8;
-                    }
-                }
-            }
-            if (++tx == x0 + rw) { tx = x0; ++ty; }
-        }
-        const float op = a.z;
-        const float sx = -op * Sx, sy = -op * Sy;
-        o0 = make_float4(a.w * sx + b.x * sy, b.x * sx + b.y * sy, So, -0.5f * op * Sxx);
-        o1 = make_float4(-op * Sxy, -0.5f * op * Syy, Sr, Sg);
-    }
-    v_splats[pid * 3 + 0] = o0;
-    v_splats[pid * 3 + 1] = o1;
-    v_splats[pid * 3 + 2] = make_float4(Sb, 0.f, 0.f, 0.f);
-}
-
 // v_splats[pid] = sum over the pair's tiles of the slots stamped by this backward call, in slot order
 // (deterministic given the slots).  One thread per (camera, gaussian) pair.
 __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int32_t* __restrict__ cum,
@@ -839,41 +590,22 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     uint64_t* cmask; int64_t words; int32_t* tile_nb;
     int rc = hand_off_buffers(ctx, C, tile_w, tile_h, n_isects, &cmask, &words, &tile_nb);
     if (rc) return rc;
-    // debug bit 1: the round-1 kernel (register butterfly + LDS accumulator rows + flush), kept for A/B timing
-    const int variant = (ctx->debug_flags & 2) ? 1 : 2;
-    // partial gradients: one 48-byte slot per (record, tile, quadrant) [round-1 kernel: per (record, tile)] and one
-    // stamp word per (record, tile); a slot counts only if its stamp is this call's, so nothing is cleared per call
-    // (the stamps are zeroed when the buffer is (re)allocated, when the kernel variant changes and when the counter wraps)
-    const size_t slot_floats = variant == 1 ? VT_STRIDE : 4 * VT4_STRIDE;
-    void* p; int grown = 0, grown2 = 0;
-    rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * slot_floats * (size_t)n_isects, &p, &grown);
+    // per-(record, tile) partial gradients: 9 floats + a stamp; a slot counts only if its stamp equals this
+    // call's, so the buffer is never cleared per call (the stamps are zeroed when the buffer is (re)allocated and
+    // when the counter is about to wrap)
+    void* p; int grown = 0;
+    rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * VT_STRIDE * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
     float* vtile = (float*)p;
-    rc = st3r_arena_get2(ctx, SLOT_VSTAMP, sizeof(int32_t) * (size_t)n_isects, &p, &grown2);
+    rc = st3r_arena_get2(ctx, SLOT_VSTAMP, sizeof(int32_t) * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
-    if (grown2 || ctx->bwd_variant != variant || ctx->bwd_stamp >= (1 << 27) - 2) {
+    if (grown || ctx->bwd_stamp >= 2147483000) {
         HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VSTAMP], s));
         ctx->bwd_stamp = 0;
-        ctx->bwd_variant = variant;
     }
     int32_t* vstamp = (int32_t*)p;
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
-    if (variant == 1) {
-        if (v_alpha)
-            hipLaunchKernelGGL(k_blend_bwd_v1<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
-                               (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha,
-                               cmask, words, tile_nb, cum, tight, vtile, vstamp, stamp);
-        else
-            hipLaunchKernelGGL(k_blend_bwd_v1<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
-                               (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha,
-                               cmask, words, tile_nb, cum, tight, vtile, vstamp, stamp);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, vstamp,
-                           stamp, (float4*)v_splats);
-        LAUNCH_CHECK();
-        return ST3R_OK;
-    }
     if (v_alpha)
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask,
@@ -883,8 +615,8 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
                            (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask,
                            words, tile_nb, cum, rects, tight, vtile, vstamp, stamp);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gather_vtile4, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, (const float4*)splats,
-                       rects, cum, tight, tile_w, tile_h, vtile, vstamp, stamp, (float4*)v_splats);
+    hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, vstamp, stamp,
+                       (float4*)v_splats);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

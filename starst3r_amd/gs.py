@@ -292,19 +292,15 @@ def run_3dgs_optim(
 
 
 def _sharded_layout(scene, world, enable_pruning):
-    """Gaussians AND views sharded (layout 2) when a GPU holds at most two views.  The MCMC
-    hooks need every Gaussian on every rank, so enable_pruning keeps the replicated layout.  ST3R_MULTI_GPU =
-    replicated | gaussian-sharded overrides the choice (the latter also with a single rank: tests)."""
+    """Gaussians AND views sharded (layout 2) is OPT-IN: ST3R_MULTI_GPU=gaussian-sharded (also with
+    a single rank: tests).  The default under torch.distributed is the north_star partition -- views sharded,
+    Gaussians replicated, one gradient all-reduce per iteration -- which is also the only layout the MCMC hooks
+    (enable_pruning) run on: they need every Gaussian on every rank."""
     import os
-    want = os.environ.get("ST3R_MULTI_GPU", "auto")
-    if enable_pruning or want == "replicated":
+    if os.environ.get("ST3R_MULTI_GPU", "replicated") != "gaussian-sharded" or enable_pruning:
         return False
     n_views, N = len(scene.imgs), scene.gaussians["means"].shape[0]
-    if n_views % world or N % world:
-        return False
-    if want == "gaussian-sharded":
-        return True
-    return world > 1 and n_views // world <= 2
+    return n_views % world == 0 and N % world == 0
 
 
 def _run_3dgs_optim_sharded(scene, iters, ssim_fac, opac_fac, scale_fac, verbose):

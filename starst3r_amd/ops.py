@@ -26,6 +26,9 @@ class Context:
         self._h = C.c_void_p()
         with torch.cuda.device(idx):
             _lib.check(_lib.lib().st3r_ctx_create(idx, C.byref(self._h)))
+        import os
+        if os.environ.get("ST3R_DEBUG_FLAGS"):   # kernel A/B switches of st3r_ctx_set_debug (tools/, profiling runs)
+            _lib.check(_lib.lib().st3r_ctx_set_debug(self._h, int(os.environ["ST3R_DEBUG_FLAGS"])))
 
     @property
     def handle(self):
