@@ -37,35 +37,52 @@ HBM_PEAK_GBS = 8000.0  # MI355X datasheet HBM3E peak (MI355X_MICROARCH.md); ~6.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)     # >= 200 iterations, median of 5 windows
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--multi-gpu", choices=("auto", "replicated", "gaussian-sharded"), default="auto",
-                    help="how N > 1 GPUs are used (DESIGN.md section 5); auto = gaussian-sharded when <= 2 views per GPU")
+    ap.add_argument("--multi-gpu", choices=("replicated", "gaussian-sharded"), default="replicated",
+                    help="how N > 1 GPUs are used (DESIGN.md section 5): replicated = the north_star partition (default)")
     ap.add_argument("--cpu-sample-div", type=int, default=2,
                     help="CPU baseline sample: 1 view at (W/div)x(H/div), N/div^2 gaussians, same density")
     return ap.parse_args()
 
 
-def algorithmic_bytes(N, V, I, P, Ct, keybits):
-    """algorithmic HBM bytes per iteration, per stage (C local views)."""
+def algorithmic_bytes_reference(N, V, I, P, Ct, keybits):
+    """SURVEY.md 8(d) as written: algorithmic HBM bytes per iteration of the REFERENCE algorithm (gsplat's 3-sigma
+    tile squares, I = its intersection count, one 64-bit-key LSD sort).  Reported as `vs_reference_algorithm` only:
+    the fused path never touches the I - I_kept culled records, and bytes not moved are not achieved bandwidth."""
     passes = math.ceil(keybits / 8)
-    sort_total = 24 * passes * I     # SURVEY 8(d): LSD radix over the 64-bit key, 8-bit digits
-    sort_depth = 24 * 5 * V          # level 1 of the two-level sort: (camera | depth) keys, 5 passes
+    return {
+        "project": 92 * N + 44 * V, "scan": 8 * V, "emit": 8 * V + 12 * I, "sort": 24 * passes * I,
+        "offsets": 8 * I + 4 * Ct, "blend_fwd": 40 * I + 20 * P, "loss": 36 * P, "blend_bwd": 112 * I + 20 * P,
+        "project_bwd": 80 * V + 92 * N, "adam": 644 * N,
+    }
+
+
+def algorithmic_bytes(N, C, V, I_kept, P, Ct, key1_bits, key1_bytes, key2_bits):
+    """Algorithmic HBM bytes per iteration of what the fused path EXECUTES: the per-unit figures of SURVEY.md 8(d)
+    (92 B / Gaussian and 44 B / visible pair for the projection, 40 B / record and 20 B / pixel for the blend
+    forward, 112 B / record and 20 B / pixel for the blend backward, 36 B / pixel for the loss, ...) times the units a
+    launch processes -- records = I_kept, the (record, tile) pairs that survive the exact alpha >= 1/255 culling --
+    and, for the two sorts, the passes the two-level sort runs: level 1 sorts all N*C pair slots with
+    (key1_bytes + 4)-byte items in ceil(key1_bits / 8) passes, level 2 the I_kept records with 8-byte items in
+    ceil(key2_bits / 8) passes; a pass reads and writes every item once, the histogram launch reads the keys once."""
+    n_pairs = N * C
+    p1, p2 = math.ceil(key1_bits / 8), math.ceil(key2_bits / 8)
     return {
         "project": 92 * N + 44 * V,
         "scan": 8 * V,
-        "emit": 8 * V + 12 * I,
-        "sort_depth": sort_depth,
-        "sort": sort_total - sort_depth,
-        "offsets": 8 * I + 4 * Ct,
-        "blend_fwd": 40 * I + 20 * P,
+        "emit": 8 * V + 12 * I_kept,
+        "sort_depth": (2 * p1 * (key1_bytes + 4) + key1_bytes) * n_pairs,
+        "sort": (2 * p2 * 8 + 4) * I_kept,
+        "offsets": 8 * I_kept + 4 * Ct,
+        "blend_fwd": 40 * I_kept + 20 * P,
         "loss": 36 * P,
-        "blend_bwd": 112 * I + 20 * P,
+        "blend_bwd": 112 * I_kept + 20 * P,
         "project_bwd": 80 * V + 92 * N,
         "adam": 644 * N,
     }
@@ -199,19 +216,34 @@ def condense_bench(device, with_cpu=True, views=8, W=512, H=384):
     return out
 
 
-# HBM bytes per launch from the PMC passes committed in profiles/r1n_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-# in separate runs; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md).  They belong to the default
-# single-GPU SYNTH-1M workload only; any other configuration reports null (counters cannot be read from inside
-# the benchmark process).
-PMC_TRAFFIC_SYNTH1M = {"blend_bwd": 5.01e9 + 1.62e9,   # k_blend_bwd + k_gather_vtile (one stage)
-                       "blend_fwd": 1.89e9, "loss": 0.83e9, "project": 0.76e9, "project_bwd": 1.06e9,
-                       "adam": 0.78e9, "emit": 0.35e9}
+def csrc_fingerprint():
+    """sha1 over the kernel sources: a PMC measurement belongs to the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "starst3r_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(stage, N, views, W, H, world):
-    if (N, views, W, H, world) == (1_000_000, 8, 1920, 1080, 1):
-        return PMC_TRAFFIC_SYNTH1M.get(stage)
-    return None
+    """HBM bytes per launch of the dominant stage from the PMC passes committed as profiles/pmc_traffic.json
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes; written by
+    tools/pmc_summary.py together with the workload and the fingerprint of the kernel sources it was measured on).
+    Counters cannot be read from inside the benchmark process, so the value is only reported when the file matches
+    this workload AND these kernel sources; otherwise null (stale)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_traffic.json"
+    rec = json.load(open(path))
+    wl = rec.get("workload", {})
+    if [wl.get(k) for k in ("gaussians", "views", "width", "height", "n_gpus")] != [N, views, W, H, world]:
+        return None, "profiles/pmc_traffic.json was measured on another workload"
+    if rec.get("csrc_fingerprint") != csrc_fingerprint():
+        return None, f"stale: measured at commit {rec.get('commit')} on other kernel sources"
+    v = rec.get("traffic_bytes_per_launch", {}).get(stage)
+    return v, f"profiles/pmc_traffic.json (commit {rec.get('commit')}, {rec.get('source')})"
 
 
 def matching_bench(device, with_cpu=True):
@@ -282,15 +314,14 @@ def main():
     assert args.views % world == 0, "views must divide evenly over the GPUs"
     g_np, w2c_np, Ks_np = synth.make_scene(N, args.views, W, H)
     C_local = args.views // world
-    # Two ways to use N GPUs.  With one or two views per GPU the Gaussians are sharded as well
-    # (two all-to-alls of splat records instead of the gradient all-reduce, no replicated Adam); with more views per
-    # GPU the records would outweigh the gradients, so the views are sharded and the parameters replicated.
+    # N GPUs: the headline layout is the north_star partition -- views sharded, Gaussians
+    # replicated, one sum-all-reduce of the [23N] gradient buffer per iteration, issued by the library itself
+    # (st3r_gs_train_step over its own RCCL communicator).  --multi-gpu gaussian-sharded is the labelled alternative
+    # (two all-to-alls of splat records, nothing replicated).
     # ST3R_BENCH_FREEZE=1 (tools/abl.sh): no optimizer step, so that kernel variants with deliberately broken
     # gradients are all timed on the same scene; never set for a reported number
     FREEZE = os.environ.get("ST3R_BENCH_FREEZE") == "1"
     mode = args.multi_gpu
-    if mode == "auto":
-        mode = "gaussian-sharded" if (world > 1 and C_local <= 2 and N % world == 0) else "replicated"
     total = args.warmup + args.steps
     losses = torch.zeros(total, device=device)
     stats = {}
@@ -316,13 +347,16 @@ def main():
         grads = torch.empty(23 * N, device=device)
         m = torch.zeros_like(grads); v = torch.zeros_like(grads)
 
+        if world > 1:
+            from starst3r_amd import dist as sdist
+            sdist.attach_native_comm(ctx)      # torch.distributed only ships the 128-byte RCCL id
+
         def step(it):
-            st = ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1])
-            if world > 1:
-                dist.all_reduce(grads)          # RCCL sum over ranks (views are sharded, loss is a sum over views)
-            if not FREEZE:
-                ops.adam_step(ctx, P, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1)
-            return st
+            if FREEZE:
+                return ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1])
+            # the whole iteration is ONE C call: fwd/bwd -> st3r_grad_allreduce (RCCL, no-op for one rank) -> Adam
+            return ops.train_step(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999,
+                                  1e-8, it + 1, losses[it:it + 1])
 
     # Stage timing costs two HIP events per stage and step (~0.15 ms per step for all eleven): the warm-up steps time
     # every stage to find the dominant one, the timed region times only that one (live, on the launch stream).
@@ -338,13 +372,21 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # one event per step on the launch stream (a few microseconds each): the K timed steps stay ONE uninterrupted
+    # region, and its five windows of K/5 steps are read back from the events afterwards
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for it in range(args.warmup, total):
         stats = step(it)
+        marks[it - args.warmup + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    n_win = 5 if args.steps >= 5 else 1
+    edges = [round(k * args.steps / n_win) for k in range(n_win + 1)]
+    win_ms = [marks[edges[k]].elapsed_time(marks[edges[k + 1]]) / (edges[k + 1] - edges[k]) for k in range(n_win)]
     stage = ops.stage_ms(ctx)
     ops.set_profiling(ctx, False)
     if mode == "gaussian-sharded":   # counts of the own Gaussians over all views ~ those of the own views over all Gaussians
@@ -363,8 +405,12 @@ def main():
         V, I, I_kept = stats["n_visible"], stats["n_isects_ref"], stats["n_isects"]
         P_px = C_local * H * W
         tw, th = ops.tile_grid(W, H)
-        keybits = 32 + (tw * th).bit_length() + C_local.bit_length()
-        ab = algorithmic_bytes(N, V, I, P_px, C_local * tw * th, keybits)
+        keybits = 32 + (tw * th).bit_length() + C_local.bit_length()           # gsplat's single key (reference)
+        key1_bytes = 4 if C_local <= 8 else 8                                   # level-1 (camera | depth) key
+        key1_bits = (29 if C_local <= 8 else 32) + max(C_local - 1, 0).bit_length()
+        key2_bits = max(C_local * tw * th - 1, 1).bit_length()                  # level-2 (camera, tile) key
+        ab = algorithmic_bytes(N, C_local, V, I_kept, P_px, C_local * tw * th, key1_bits, key1_bytes, key2_bits)
+        ab_ref = algorithmic_bytes_reference(N, V, I, P_px, C_local * tw * th, keybits)
         per_stage = dict(warm_ms)                      # every stage: warm-up steps
         per_stage.update({k: ms / n for k, (ms, n) in stage.items() if n > 0})   # timed region (dominant stage only)
         dom = dom_warm if dom_warm is not None else max(per_stage, key=per_stage.get)
@@ -372,6 +418,8 @@ def main():
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         ms_per_step = dt / args.steps * 1e3
         iter_bytes = sum(ab.values())
+        traffic, traffic_src = pmc_traffic(dom, N, args.views, W, H, world)
+        win_sorted = sorted(win_ms)
         out = {
             "metric": "3DGS train iters/sec @ 1M Gaussians, 8x1080p views",
             "value": args.steps / dt, "unit": "iters/sec", "n_gpus": world, "steps": args.steps,
@@ -383,19 +431,35 @@ def main():
                             + ("sharded" if mode == "gaussian-sharded" else "replicated"),
                 "gaussians": N, "views": args.views, "width": W, "height": H, "views_per_gpu": C_local,
                 "parallelism": (f"gaussians+views sharded x{world} (2 all-to-all of splat records / iteration)"
-                                if mode == "gaussian-sharded" else f"view-dp{world} (gradient all-reduce)"), "n_visible_pairs": V, "n_isects": I, "n_isects_kept_after_exact_culling": I_kept,
-                "sort_key_bits": keybits,
-                "mean_tiles_per_visible_gaussian": (I / V) if V else 0.0,
-                "mean_gaussians_per_tile": I / (C_local * tw * th),
+                                if mode == "gaussian-sharded"
+                                else f"view-dp{world} (st3r_grad_allreduce of the [23N] gradients inside st3r_gs_train_step)"),
+                "n_visible_pairs": V, "n_isects_reference_algorithm": I, "n_isects_kept_after_exact_culling": I_kept,
+                "sort_key_bits": {"reference_single_key": keybits, "level1": key1_bits, "level2": key2_bits},
+                "mean_tiles_per_visible_gaussian": (I_kept / V) if V else 0.0,
+                "mean_records_per_tile": I_kept / (C_local * tw * th),
                 "loss_first": float(L[0]), "loss_last": float(L[-1]),
             },
+            # five windows of steps/5 consecutive steps inside the one timed region (HIP events on the launch stream)
+            "windows": {"ms_per_step": win_ms, "median_ms_per_step": win_sorted[len(win_sorted) // 2],
+                        "median_iters_per_sec": 1e3 / win_sorted[len(win_sorted) // 2],
+                        "spread_rel": (win_sorted[-1] - win_sorted[0]) / win_sorted[len(win_sorted) // 2]},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, N, args.views, W, H, world),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": ab[dom], "launch_ms": dom_ms,
+                "formula": "per-unit bytes of SURVEY.md 8(d) x units the launch processes (records = "
+                           "n_isects_kept_after_exact_culling), / mean launch time from HIP events in the timed region",
                 "whole_iter": {"algorithmic_bytes": iter_bytes,
                                "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9,
                                "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                # the same kernel time priced with the REFERENCE algorithm's bytes (gsplat's 3-sigma squares, 64-bit
+                # single-key sort): how much of the reference's traffic per second the fused path retires -- not
+                # achieved bandwidth
+                "vs_reference_algorithm": {
+                    "kernel_bytes": ab_ref.get(dom), "kernel_equiv_GBps": (ab_ref[dom] / (dom_ms * 1e-3) / 1e9) if dom in ab_ref and dom_ms > 0 else None,
+                    "whole_iter_bytes": sum(ab_ref.values()),
+                    "whole_iter_equiv_GBps": sum(ab_ref.values()) / (ms_per_step * 1e-3) / 1e9},
+                "algorithmic_bytes_by_stage": ab,
                 "stage_ms": per_stage,
                 "stage_ms_source": f"{dom}: HIP events over the timed region; other stages: over the warm-up steps",
             },

@@ -1,0 +1,65 @@
+"""BASELINE.json configs[1] on synthetic data: 8 views at Mast3r's 512x384, reconstruct -> 3DGS train 7 000 iterations
+on one MI355X.  The sequence is the reference's main.py:49-50,80-81 -- two views first, the remaining six added
+afterwards (every add_images re-solves all views, warm-started from the previous solution), init_3dgs,
+run_3dgs_optim with the MCMC hooks on -- with a stand-in for the Mast3r network (the weights are not available
+offline); pair list, reciprocal matching, pair cache, condensation, alignment, dense seeding and training run in the
+library.  Prints PSNR before / after, Gaussian counts and wall times.
+
+    python examples/cfg1_eight_views.py [iterations]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import starst3r_amd as st
+from starst3r_amd.synth_model import SyntheticNetwork
+
+
+def psnr_per_view(sc, W, H):
+    vals = []
+    for v in range(len(sc.imgs)):
+        img, _, _ = sc.render_3dgs(sc.w2c[v][None], sc.intrinsics[v][None], W, H)
+        gt = torch.as_tensor(np.asarray(sc.imgs[v]), device=img.device).reshape(H, W, 3)
+        vals.append(-10 * np.log10(float(((img[0].detach().clamp(0, 1) - gt) ** 2).mean())))
+    return vals
+
+
+def main(iters=7000, views=8, W=512, H=384, seed=2, verbose=True):
+    net = SyntheticNetwork(n_views=views, width=W, height=H, seed=seed)
+    imgs = net.images()
+    sc = st.Scene(device="cuda:0")
+    out = {}
+    t0 = time.time()
+    sc.add_images(net, imgs[:2])                      # main.py:49
+    torch.cuda.synchronize(); out["t_reconstruct_2"] = time.time() - t0
+    t0 = time.time()
+    sc.add_images(net, imgs[2:])                      # main.py:50 (re-solves all 8, warm start)
+    torch.cuda.synchronize(); out["t_reconstruct_8"] = time.time() - t0
+    out["pair_inferences"] = net.calls                # C(8,2) = 28: the first pair is served from the cache
+    sc.init_3dgs()                                    # main.py:66
+    out["n_gaussians_init"] = int(sc.gaussians["means"].shape[0])
+    out["psnr_before"] = psnr_per_view(sc, W, H)
+    t0 = time.time()
+    losses = sc.run_3dgs_optim(iters, enable_pruning=True, verbose=False)   # main.py:80 (7 k iterations: configs[1])
+    torch.cuda.synchronize(); out["t_train"] = time.time() - t0
+    out["iters"] = iters
+    out["n_gaussians_final"] = int(sc.gaussians["means"].shape[0])
+    out["psnr_after"] = psnr_per_view(sc, W, H)
+    out["loss_first"], out["loss_last"] = float(losses[0]), float(losses[-1])
+    out["relocated_last"], out["added_last"] = sc.strategy_state["n_relocated"], sc.strategy_state["n_added"]
+    if verbose:
+        print(f"reconstruct 2 views {out['t_reconstruct_2']:.2f} s, then all {views}: {out['t_reconstruct_8']:.2f} s "
+              f"({net.calls} pair inferences)")
+        print(f"{iters} iterations in {out['t_train']:.2f} s = {iters / out['t_train']:.0f} it/s; Gaussians "
+              f"{out['n_gaussians_init']} -> {out['n_gaussians_final']}")
+        print("PSNR per view before", np.round(out["psnr_before"], 2), "mean %.2f" % np.mean(out["psnr_before"]))
+        print("PSNR per view after ", np.round(out["psnr_after"], 2), "mean %.2f" % np.mean(out["psnr_after"]))
+    return out
+
+
+if __name__ == "__main__":
+    main(*[int(x) for x in sys.argv[1:2]])

@@ -12,8 +12,8 @@
  *   starster/gs.py:76-87   gsplat.rasterization(means, quats, scales, opacities,
  *                          colors=shN, viewmats, Ks, width, height, sh_degree=1)
  *   starster/gs.py:126-136 compute_loss (L1 + SSIM + two regularisers)
- *   starster/gs.py:37,159-161  torch.optim.Adam (this part IS pinned: golden vectors
- *                          from torch.optim.Adam, tests/golden/adam_*.npz)
+ *   starster/gs.py:37,159-161  torch.optim.Adam (this part IS pinned: run against
+ *                          torch.optim.Adam itself, tests/test_oracle_gs.py::test_adam_matches_torch_optim)
  * It is pinned by its own known-answer tests and by fp64 autograd of an independent
  * dense torch restatement (oracle/gs_torch_ref.py) -- see tests/test_oracle_gs.py.
  *

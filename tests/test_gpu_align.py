@@ -4,8 +4,8 @@
 Gauge freedom: the loss is invariant to a rigid motion of the rig and to a common size factor; along
 those directions gradients are rounding noise that Adam amplifies (see tests/test_oracle_align.py), so
 all comparisons use gauge-free quantities.  Tolerances: 1e-4 after 1/10 iterations (north_star's
-"aligned pointmaps within 1e-4"); 5e-3 after the full 500+200 schedule, where float32 trajectories of
-reference, oracle and HIP legitimately drift apart (the oracle-vs-reference test uses the same bound)."""
+"aligned pointmaps within 1e-4"); 4e-4 after the full 500+200 schedule: the reference's OWN float32 run ends
+0.9e-4 .. 1.5e-4 from its float64 evaluation (goldens f64_*), so no float32 result can be held to 1e-4 there."""
 import os
 
 import numpy as np
@@ -15,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import align_oracle as ao
-from test_oracle_align import GOLD, gauge_free, load
+from test_oracle_align import F32_DRIFT_BOUND, GOLD, drift, gauge_free, load
 
 
 def run_hip(flat, **kw):
@@ -55,14 +55,28 @@ def test_stage2_first_step_vs_reference_golden(name):
     res, par = run_hip(flat, niter1=500, niter2=1)
     g_res, g_par = golden(z, "r500_1")
     compare(res, par, g_res, g_par, 3e-3, name)
+    # the coarse stage alone against the float64 yardstick (reference32 ends 5e-6 .. 9e-6 from it)
+    res, par = run_hip(flat, niter1=500, niter2=0)
+    d64 = drift(gauge_free(res, par, 0), gauge_free(*golden(z, "f64_r500_0"), 0))
+    print(name, "coarse stage: HIP-reference64 %.2e" % d64)
+    assert d64 <= F32_DRIFT_BOUND["r500_0"]
 
 
 @pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
 def test_full_schedule_vs_reference_golden(name):
+    """Full 500+200 schedule against the reference's float32 result AND against its float64 evaluation: the
+    reference in float32 itself ends 0.9e-4 .. 1.5e-4 from the float64 run (tests/test_oracle_align.py), so 4e-4 is
+    ~2.5x the float32 floor; the HIP result must be as close to the float64 truth as the reference's own float32 run is
+    allowed to be."""
     z, flat = load(name)
     res, par = run_hip(flat, niter1=500, niter2=200)
     g_res, g_par = golden(z, "r500_200")
-    compare(res, par, g_res, g_par, 5e-3, name)
+    compare(res, par, g_res, g_par, 4e-4, name)
+    hip = gauge_free(res, par, 0)
+    d64 = drift(hip, gauge_free(*golden(z, "f64_r500_200"), 0))
+    d32 = drift(hip, gauge_free(g_res, g_par, 0))
+    print(name, "HIP-reference64 %.2e  HIP-reference32 %.2e" % (d64, d32))
+    assert d64 <= F32_DRIFT_BOUND["r500_200"]
     L = res["losses"]
     assert np.all(np.isfinite(L)) and L[499] < L[0] and L[-1] < L[500]
 

@@ -53,6 +53,9 @@ def fuzz_scene(seed):
 
 
 FUZZ = ["fuzz%d" % i for i in range(12)]
+# fraction of pixels whose skip / stop decisions float32 determines (oracle margin > 1e-4), per stress scene
+FUZZ_CHECKED = {"fuzz0": 0.9207, "fuzz1": 0.8785, "fuzz2": 0.6398, "fuzz3": 0.9991, "fuzz4": 0.9981, "fuzz5": 0.9680,
+                "fuzz6": 0.9923, "fuzz7": 0.9416, "fuzz8": 0.9893, "fuzz9": 0.9939, "fuzz10": 0.9666, "fuzz11": 0.9026}
 
 
 def make(name):
@@ -138,8 +141,18 @@ def test_blend_forward(ctx, name):
     # flip under a 1-ulp exp difference (v_exp_f32 vs glibc expf): excluded, and they must be rare
     ok = meta["margin"] > 1e-4
     # (the randomised stress scenes are full of strongly anisotropic, image-filling Gaussians whose sigma is not
-    # determined to 1e-4 in float32 far from the mean: more pixels are excluded there, see gso_blend_fwd)
-    assert ok.mean() > (0.6 if name.startswith("fuzz") else 0.999), ok.mean()
+    # determined to 1e-4 in float32 far from the mean: more pixels are excluded there, see gso_blend_fwd).  The
+    # excluded fraction is a property of the scene and of the oracle alone (CPU, deterministic), so it is pinned per
+    # scene instead of bounded by one loose number: 9 of the 12 stress scenes keep > 90 % of their pixels
+    assert ok.mean() >= (FUZZ_CHECKED[name] - 2e-3 if name.startswith("fuzz") else 0.999), (name, ok.mean())
+    if name.startswith("fuzz"):
+        # the excluded pixels are not left unchecked: whichever way their borderline decisions fall, the image stays
+        # within about one 1/255 step of the oracle's
+        bad = ~ok
+        if bad.any():
+            worst = float(np.abs(rgb[bad] - rgb_o[bad]).max())
+            print(name, "checked fraction %.4f, worst |rgb - oracle| on the excluded pixels %.3e" % (ok.mean(), worst))
+            assert worst <= 5e-3, (name, worst)   # measured: 1e-7 .. 1.4e-3
     # tolerance: 1e-4 relative (north_star) with a 1e-5 absolute floor for near-zero pixels
     np.testing.assert_allclose(rgb[ok], rgb_o[ok], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(alpha[ok], alpha_o[ok], rtol=1e-4, atol=1e-5)

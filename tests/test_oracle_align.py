@@ -60,14 +60,52 @@ def test_first_steps_match_reference(name):
 
 @pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
 def test_full_schedule_matches_reference(name):
-    """500 (+1, +200) iterations: float32 trajectories drift by rounding, so the tolerance is 2e-3."""
+    """500 (+1, +200) iterations: float32 trajectories drift by rounding (quantified against the float64 reference in
+    test_float32_drift_is_bounded_by_the_float64_reference): 4e-5 after the coarse stage, 4e-4 after the full schedule."""
     z, flat = load(name)
     res, params = ao.run(flat, niter1=500, niter2=0)
-    check(z, "r500_0", res, params, 2e-3)
+    check(z, "r500_0", res, params, 4e-5)
     res, params = ao.run(flat, niter1=500, niter2=1)   # first reprojection step (loss_2d gradient incl. focals/pps)
-    check(z, "r500_1", res, params, 2e-3)
+    check(z, "r500_1", res, params, 2e-3)   # one lr2-sized Adam step on near-zero gradients: sign noise * 0.014
     res, params = ao.run(flat, niter1=500, niter2=200)
-    check(z, "r500_200", res, params, 5e-3)
+    check(z, "r500_200", res, params, 4e-4)
+
+
+def golden(z, tag):
+    par = {k: z[f"{tag}__p_{k}"] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")}
+    res = {k: z[f"{tag}__{k}"] for k in ("intrinsics", "cam2w", "depthmaps", "pts3d")}
+    return res, par
+
+
+def drift(a, b):
+    """max over the gauge-free quantities of max|a - b| / max(1, max|b|)."""
+    return max(float(np.abs(np.asarray(a[k], np.float64) - np.asarray(b[k], np.float64)).max() /
+                     max(1.0, float(np.abs(b[k]).max()))) for k in a)
+
+
+# how far a float32 evaluation of the REFERENCE's own optimiser ends from its float64 evaluation (goldens f64_*,
+# same function, dtype=float64): measured 5e-6 .. 9e-6 after the 500 coarse iterations and 0.9e-4 .. 1.5e-4 after the
+# full 500+200 schedule.  Nothing computed in float32 can be held to less; the bounds below are ~2.5x that floor.
+F32_DRIFT_BOUND = {"r500_0": 4e-5, "r500_200": 4e-4}
+
+
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
+def test_float32_drift_is_bounded_by_the_float64_reference(name):
+    """The reference in float32, and the oracle, sit at the same distance from the reference in float64 -- the
+    justification for comparing full-schedule float32 results at a few 1e-4 rather than at 1e-4.  (After 10
+    iterations the float64 run is no yardstick for align_c4_badpair: the first steps split the gradient of
+    sizes.min() between tied minima, and the tie pattern differs between the dtypes; both runs meet again well
+    before iteration 500.)"""
+    z, flat = load(name)
+    for tag, (n1, n2) in (("r500_0", (500, 0)), ("r500_200", (500, 200))):
+        f64 = gauge_free(*golden(z, "f64_" + tag), 0)
+        ref32 = gauge_free(*golden(z, tag), 0)
+        res, par = ao.run(flat, niter1=n1, niter2=n2)
+        orc = gauge_free(res, par, 0)
+        d_ref, d_orc = drift(ref32, f64), drift(orc, f64)
+        print(name, tag, "reference32-reference64 %.2e   oracle-reference64 %.2e" % (d_ref, d_orc))
+        assert d_ref <= F32_DRIFT_BOUND[tag] and d_orc <= F32_DRIFT_BOUND[tag], (tag, d_ref, d_orc)
+        assert d_ref >= 1e-6        # the yardstick is not trivially zero: float32 really does drift
 
 
 def test_interp_se3_golden():

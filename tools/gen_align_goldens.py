@@ -110,15 +110,37 @@ def load_reference():
 from starst3r_amd.synth_align import Slice, to_reference_inputs  # noqa: E402  (shared with the product's B1 tests)
 
 
-def run_reference(ref, P, niter1, niter2):
+def _to_f64(x):
+    """float32 tensors of the reference-input structure -> float64 (same values), recursively."""
+    if torch.is_tensor(x):
+        return x.double() if x.dtype == torch.float32 else x
+    if isinstance(x, Slice):
+        return Slice(x.img1, x.slice1, x.img2, x.slice2, _to_f64(x.confs))
+    if isinstance(x, dict):
+        return {k: _to_f64(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_f64(v) for v in x)
+    return x
+
+
+def run_reference(ref, P, niter1, niter2, f64=False):
+    """f64: the SAME reference function evaluated in float64 (its own `dtype` argument + torch's default dtype): the
+    yardstick that tells how far a float32 trajectory -- the reference's included -- drifts from the exact one."""
     a = to_reference_inputs(P)
+    dtype = torch.float32
+    if f64:
+        a = _to_f64(a); dtype = torch.float64
+        torch.set_default_dtype(torch.float64)
     torch.manual_seed(0)
-    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
-        imgs, coarse, fine, params = ref.sparse_scene_optimizer_slam(
-            a["imgs"], a["subsample"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"],
-            a["corres"], a["corres2d"], a["preds_21"], a["canonical_paths"], a["mst"], cache_path=None,
-            lr1=0.07, niter1=niter1, lr2=0.014, niter2=niter2, device="cpu", opt_depth=False,
-            matching_conf_thr=5, shared_intrinsics=False)  # the reference's own settings, reconstruct.py:61-69
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            imgs, coarse, fine, params = ref.sparse_scene_optimizer_slam(
+                a["imgs"], a["subsample"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"],
+                a["corres"], a["corres2d"], a["preds_21"], a["canonical_paths"], a["mst"], cache_path=None,
+                lr1=0.07, niter1=niter1, lr2=0.014, niter2=niter2, device="cpu", opt_depth=False, dtype=dtype,
+                matching_conf_thr=5, shared_intrinsics=False)  # the reference's own settings, reconstruct.py:61-69
+    finally:
+        torch.set_default_dtype(torch.float32)
     res = fine or coarse
     out = {}
     for k in ("pps", "log_focals", "quats", "trans", "log_sizes"):
@@ -146,6 +168,12 @@ def main():
             for k, v in r.items():
                 runs[f"r{n1}_{n2}__{k}"] = v.astype(np.float32) if v.dtype.kind == "f" else v
             print(name, (n1, n2), "focals", r["intrinsics"][:, 0, 0])
+        # float64 evaluation of the reference at the points where float32 trajectories are compared loosely
+        for (n1, n2) in ((10, 0), (500, 0), (500, 200)):
+            r = run_reference(ref, P, n1, n2, f64=True)
+            for k, v in r.items():
+                runs[f"f64_r{n1}_{n2}__{k}"] = v      # kept in float64
+            print(name, (n1, n2), "float64 focals", r["intrinsics"][:, 0, 0])
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **{"in__" + k: v for k, v in flat.items()}, **runs)
         print("wrote", name, os.path.getsize(os.path.join(out_dir, name + ".npz")) // 1024, "KiB")
     # interp_se3 goldens (starster/utils.py is the only reference file importable as is)
