@@ -34,6 +34,32 @@ def all_reduce_sum(t):
     return t
 
 
+def all_gather_varlen(t):
+    """Variable-length all-gather ("allgatherv") of a 1-D tensor: returns the list of every rank's tensor, in rank
+    order.  Sizes are exchanged first, the payload travels padded to the longest (one collective, no per-rank
+    point-to-point schedule: inside a node every GPU pair has its own xGMI link).  Single process: [t]."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [t]
+    world = dist.get_world_size()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    cap = max(max(sizes), 1)
+    send = torch.zeros(cap, dtype=t.dtype, device=t.device)
+    send[:t.numel()] = t.reshape(-1)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    return [r[:k] for r, k in zip(recv, sizes)]
+
+
+def shard_pairs(n_pairs, rank, world):
+    """Path A: the image pairs of the complete graph (starster/reconstruct.py:52) are independent --
+    round-robin over the ranks, no collective on the data path."""
+    return list(range(rank, n_pairs, world))
+
+
 def sharded_step(local_views_fn, grads, loss):
     """One data-parallel step given a function that fills `grads` / `loss` from this rank's views."""
     local_views_fn(grads, loss)

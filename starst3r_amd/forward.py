@@ -51,38 +51,106 @@ def extract_correspondences(feats, qonfs, subsample=8, device="cuda:0"):
     return xy1.float(), xy2.float(), confs
 
 
-def forward_mast3r(pairs, model, cache_path, desc_conf="desc_conf", device="cuda:0", subsample=8, **matching_kw):
+def _pair_files(cache_path, n1, n2, desc_conf, subsample):
+    i1, i2 = hash_md5(n1), hash_md5(n2)
+    cdir = os.path.join(cache_path, f"corres_conf={desc_conf}_subsample={subsample}")
+    return (os.path.join(cache_path, "forward", i1, i2 + ".pth"), os.path.join(cache_path, "forward", i2, i1 + ".pth"),
+            os.path.join(cdir, f"{i1}-{i2}.pth"), os.path.join(cdir, f"{i2}-{i1}.pth"))
+
+
+def _infer_pair(img1, img2, model, files, desc_conf, device, subsample):
+    """One symmetric inference + the four reciprocal matchings of a pair -> the three cache entries (CPU tensors)."""
+    res = model.symmetric_inference(img1, img2, device)
+    X11, X21, X22, X12 = [r["pts3d"][0] for r in res]
+    C11, C21, C22, C12 = [r["conf"][0] for r in res]
+    descs = [r["desc"][0] for r in res]
+    qonfs = [r[desc_conf][0] for r in res]
+    cpu = lambda ts: tuple(t.detach().cpu() for t in ts)
+    corres = extract_correspondences(descs, qonfs, subsample=subsample, device=device)
+    conf_score = (C11.mean() * C12.mean() * C21.mean() * C22.mean()).sqrt().sqrt()
+    score = (float(conf_score), float(corres[2].sum()), len(corres[2]))
+    return {files[0]: cpu((X11, C11, X21, C21)), files[1]: cpu((X22, C22, X12, C12)), files[2]: (score, cpu(corres))}
+
+
+def _exchange_pair_results(mine, cache_path, device):
+    """Every rank ends up with every rank's new cache entries.  The payload (pointmaps, confidences, the
+    variable-length correspondence lists) travels as ONE flat float32 vector per rank through
+    dist.all_gather_varlen; a small object all-gather carries the layout (relative paths, shapes, scores)."""
+    import torch.distributed as tdist
+    from . import dist as sdist
+    layout, chunks = [], []
+    for path, obj in mine.items():
+        rel = os.path.relpath(path, cache_path)
+        if isinstance(obj[0], tuple):      # correspondence entry: ((score, sum, count), (xy1, xy2, confs))
+            score, tensors = obj
+        else:
+            score, tensors = None, obj
+        layout.append((rel, score, [tuple(t.shape) for t in tensors]))
+        chunks.extend(t.reshape(-1).float() for t in tensors)
+    flat = torch.cat(chunks) if chunks else torch.zeros(0)
+    backend_dev = device if tdist.get_backend() == "nccl" else "cpu"
+    parts = sdist.all_gather_varlen(flat.to(backend_dev))
+    layouts = [None] * tdist.get_world_size()
+    tdist.all_gather_object(layouts, layout)
+    for r, (lay, buf) in enumerate(zip(layouts, parts)):
+        if r == tdist.get_rank():
+            continue
+        buf = buf.cpu(); off = 0
+        for rel, score, shapes in lay:
+            tensors = []
+            for shp in shapes:
+                n = 1
+                for d in shp:
+                    n *= d
+                tensors.append(buf[off:off + n].reshape(shp).clone()); off += n
+            path = os.path.join(cache_path, rel)
+            if not os.path.isfile(path):
+                torch.save(tuple(tensors) if score is None else (score, tuple(tensors)), _mkdir_for(path))
+
+
+def forward_mast3r(pairs, model, cache_path, desc_conf="desc_conf", device="cuda:0", subsample=8, shard=True,
+                   **matching_kw):
     """pairs: iterable of (img1, img2) dicts with 'instance' (Mast3r's pair list).  Returns (res_paths, cache_path)
     with res_paths[(instance1, instance2)] = ((path1, path2), path_corres) -- the `tmp_pairs` of
-    prepare_canonical_data.  Pairs already in the cache (in either order) are not inferred again."""
-    res_paths = {}
+    prepare_canonical_data.  Pairs already in the cache (in either order) are not inferred again.
+
+    Under torch.distributed (one process per GPU) the pairs that still need inference are dealt round-robin to the
+    ranks (the pairs are independent: no collective on the data path); afterwards the new cache entries are
+    all-gathered (variable length: the correspondence lists differ per pair) so that every rank's cache -- shared
+    directory or rank-private -- is complete and every rank returns the same res_paths.  shard=False: every rank
+    infers every pair (the single-process behaviour)."""
+    from . import dist as sdist
+    rank, world = sdist.rank_world()
+    if not shard:
+        rank, world = 0, 1
+    res_paths, todo = {}, []
     for img1, img2 in pairs:
         n1, n2 = img1["instance"], img2["instance"]
         if (n2, n1) in res_paths or (n1, n2) in res_paths:
             continue   # the symmetrized list holds both orders; one symmetric inference serves both
-        i1, i2 = hash_md5(n1), hash_md5(n2)
-        path1 = os.path.join(cache_path, "forward", i1, i2 + ".pth")
-        path2 = os.path.join(cache_path, "forward", i2, i1 + ".pth")
-        cdir = os.path.join(cache_path, f"corres_conf={desc_conf}_subsample={subsample}")
-        path_corres = os.path.join(cdir, f"{i1}-{i2}.pth")
-        path_corres2 = os.path.join(cdir, f"{i2}-{i1}.pth")
+        files = _pair_files(cache_path, n1, n2, desc_conf, subsample)
+        path1, path2, path_corres, path_corres2 = files
         if os.path.isfile(path_corres2) and not os.path.isfile(path_corres):
             score, (xy1, xy2, confs) = torch.load(path_corres2)
             torch.save((score, (xy2, xy1, confs)), _mkdir_for(path_corres))
-        if not all(os.path.isfile(p) for p in (path1, path2, path_corres)):
-            if model is None:
-                continue
-            res = model.symmetric_inference(img1, img2, device)
-            X11, X21, X22, X12 = [r["pts3d"][0] for r in res]
-            C11, C21, C22, C12 = [r["conf"][0] for r in res]
-            descs = [r["desc"][0] for r in res]
-            qonfs = [r[desc_conf][0] for r in res]
-            cpu = lambda ts: tuple(t.detach().cpu() for t in ts)
-            torch.save(cpu((X11, C11, X21, C21)), _mkdir_for(path1))
-            torch.save(cpu((X22, C22, X12, C12)), _mkdir_for(path2))
-            corres = extract_correspondences(descs, qonfs, subsample=subsample, device=device)
-            conf_score = (C11.mean() * C12.mean() * C21.mean() * C22.mean()).sqrt().sqrt()
-            score = (float(conf_score), float(corres[2].sum()), len(corres[2]))
-            torch.save((score, cpu(corres)), _mkdir_for(path_corres))
         res_paths[n1, n2] = (path1, path2), path_corres
+        if not all(os.path.isfile(p) for p in (path1, path2, path_corres)):
+            todo.append((img1, img2, files))
+    mine = {}
+    if world > 1:
+        # every rank must have taken its inventory of the (possibly shared) cache before anyone adds files to it:
+        # the round-robin deal below is only consistent if all ranks see the same `todo`
+        import torch.distributed as tdist
+        tdist.barrier()
+    if model is not None:
+        for k in sdist.shard_pairs(len(todo), rank, world):
+            img1, img2, files = todo[k]
+            entries = _infer_pair(img1, img2, model, files, desc_conf, device, subsample)
+            for path, obj in entries.items():
+                torch.save(obj, _mkdir_for(path))
+            mine.update(entries)
+        if world > 1:
+            _exchange_pair_results(mine, cache_path, device)
+    # pairs that could not be completed (no model, nothing cached) are not reported
+    res_paths = {k: v for k, v in res_paths.items() if all(os.path.isfile(p) for p in (*v[0], v[1]))}
     return res_paths, cache_path

@@ -122,3 +122,167 @@ def test_sharded_exchanges_world2(tmp_path):
     out = str(tmp_path / "a2a")
     mp.spawn(_a2a_worker, args=(2, port, out), nprocs=2, join=True)
     assert [open(f"{out}.{r}").read() for r in range(2)] == ["ok", "ok"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Path A under torch.distributed: the pairs of the complete graph are dealt round-robin to the ranks and the new
+# cache entries all-gathered with variable lengths (starst3r_amd.forward.forward_mast3r).
+# ---------------------------------------------------------------------------------------------------------------
+def _cpu_extract_correspondences(feats, qonfs, subsample=8, device="cpu"):
+    """stand-in for the MFMA matching on this GPU-less box: the numpy oracle, same merge and confidence rule"""
+    from oracle import nn_oracle
+    from starst3r_amd import matching
+    f = [x.cpu().numpy() for x in feats]; q = [x.cpu().numpy() for x in qonfs]
+    idx1, idx2, q1, q2 = [], [], [], []
+    for A, B, QA, QB in ((f[0], f[1], q[0], q[1]), (f[3], f[2], q[3], q[2])):
+        a12, b12 = nn_oracle.fast_reciprocal_NNs(A, B, subsample)
+        b21, a21 = nn_oracle.fast_reciprocal_NNs(B, A, subsample)
+        i1 = np.concatenate([a12, a21]).astype(np.int64); i2 = np.concatenate([b12, b21]).astype(np.int64)
+        idx1.append(i1); idx2.append(i2); q1.append(QA.reshape(-1)[i1]); q2.append(QB.reshape(-1)[i2])
+    H1, W1 = f[0].shape[:2]; H2, W2 = f[2].shape[:2]
+    xy1, xy2, index = matching.merge_corres(torch.tensor(np.concatenate(idx1)), torch.tensor(np.concatenate(idx2)),
+                                            (H1, W1), (H2, W2), ret_xy=True, ret_index=True)
+    confs = torch.tensor(np.sqrt(np.concatenate(q1) * np.concatenate(q2)))[index]
+    return xy1.float(), xy2.float(), confs.float()
+
+
+def _pairs_of(n):
+    imgs = [dict(instance=f"{i}.png", idx=i) for i in range(n)]
+    return [(imgs[i], imgs[j]) for i in range(n) for j in range(i + 1, n)]
+
+
+def _forward_worker(rank, world, port, base):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from starst3r_amd import forward
+    from starst3r_amd.synth_model import SyntheticNetwork
+    forward.extract_correspondences = _cpu_extract_correspondences
+    net = SyntheticNetwork(n_views=4, width=64, height=48, seed=1)
+    cache = os.path.join(base, f"rank{rank}")            # rank-private caches: the exchange has to fill them
+    res, _ = forward.forward_mast3r(_pairs_of(4), net, cache, device="cpu", subsample=8)
+    assert net.calls == 3, net.calls                     # 6 pairs over 2 ranks
+    assert len(res) == 6
+    torch.save({k: (torch.load(v[0][0]), torch.load(v[0][1]), torch.load(v[1])) for k, v in res.items()},
+               os.path.join(base, f"out{rank}.pth"))
+    # a second call finds everything cached: no inference, no payload
+    res2, _ = forward.forward_mast3r(_pairs_of(4), net, cache, device="cpu", subsample=8)
+    assert net.calls == 3 and list(res2) == list(res)
+    torch.distributed.destroy_process_group()
+
+
+def test_pair_sharding_fills_every_ranks_cache(tmp_path):
+    from starst3r_amd import forward
+    from starst3r_amd.synth_model import SyntheticNetwork
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_forward_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # single-process reference with the same stand-in matcher
+    keep = forward.extract_correspondences
+    forward.extract_correspondences = _cpu_extract_correspondences
+    try:
+        net = SyntheticNetwork(n_views=4, width=64, height=48, seed=1)
+        res, _ = forward.forward_mast3r(_pairs_of(4), net, str(tmp_path / "single"), device="cpu", subsample=8)
+    finally:
+        forward.extract_correspondences = keep
+    assert net.calls == 6
+    outs = [torch.load(tmp_path / f"out{r}.pth") for r in range(2)]
+
+    def same(a, b):
+        if torch.is_tensor(a):
+            return torch.equal(a, b)
+        if isinstance(a, (tuple, list)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b
+    for k, v in res.items():
+        want = (torch.load(v[0][0]), torch.load(v[0][1]), torch.load(v[1]))
+        for r in range(2):
+            assert same(outs[r][k], want), (k, r)
+    assert same(sdist.all_gather_varlen(torch.arange(5.0)), [torch.arange(5.0)])   # single process: identity
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The rank bookkeeping of gs.run_3dgs_optim itself (view shard, per-view regularisers, gradient / loss all-reduce,
+# step counter, identical replica updates) with only the C calls replaced by the CPU oracle.
+# ---------------------------------------------------------------------------------------------------------------
+class _CpuScene:
+    def __init__(self, g, w2c, Ks, gt):
+        self.device = "cpu"
+        self.imgs = [gt[v] for v in range(gt.shape[0])]
+        self._w2c = torch.tensor(w2c); self.intrinsics = torch.tensor(Ks)
+        self.dense_pts = [torch.tensor(g["means"])]; self.dense_cols = [torch.zeros(N, 3)]
+
+    dense_pts_flat = property(lambda self: self.dense_pts[0])
+    dense_cols_flat = property(lambda self: self.dense_cols[0])
+    w2c = property(lambda self: self._w2c)
+
+
+def _mock_ops(monkey_ops, g_keys=("means", "quats", "scales", "opacities", "shN")):
+    """replace the two C calls of the non-fused branch of run_3dgs_optim by the oracle"""
+    calls = dict(fwd_bwd=0, adam=0)
+
+    def train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W_, H_, ssim_fac, opac_fac, scale_fac, grads, loss_out):
+        calls["fwd_bwd"] += 1
+        g = {k: P[k].numpy() for k in g_keys}
+        C = w2c.shape[0]
+        gr, ls = oracle_local_step(g, w2c.numpy(), Ks.numpy(), gt.numpy(), list(range(C)), ssim_fac, opac_fac, scale_fac)
+        grads.copy_(torch.from_numpy(gr).to(grads.dtype)); loss_out[0] = ls
+        return dict(n_visible=0, n_isects=0, n_isects_ref=0, arena_bytes=0)
+
+    def adam_step(ctx, P, grads, m, v, lr, b1, b2, eps, step):
+        calls["adam"] += 1
+        off = 0
+        for key, w in (("means", 3), ("quats", 4), ("scales", 3), ("opacities", 1)):
+            n = w * N
+            p = P[key].numpy().reshape(-1); mm = m[off:off + n].numpy(); vv = v[off:off + n].numpy()
+            go.adam(p, grads[off:off + n].numpy(), mm, vv, lr, b1, b2, eps, step); off += n
+        p = np.ascontiguousarray(P["shN"].numpy()[:, :4]).reshape(-1); n = 12 * N
+        mm = m[off:off + n].numpy(); vv = v[off:off + n].numpy()
+        go.adam(p, grads[off:off + n].numpy(), mm, vv, lr, b1, b2, eps, step)
+        P["shN"][:, :4] = torch.from_numpy(p.reshape(N, 4, 3))
+    def train_step(ctx, P, w2c, Ks, campos, gt, W_, H_, ssim_fac, opac_fac, scale_fac, grads, m, v, lr, b1, b2, eps,
+                   step, loss_out):     # the fused single-process call: the same two pieces, no exchange in between
+        st = train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W_, H_, ssim_fac, opac_fac, scale_fac, grads, loss_out)
+        adam_step(ctx, P, grads, m, v, lr, b1, b2, eps, step)
+        return st
+    monkey_ops.train_fwd_bwd = train_fwd_bwd
+    monkey_ops.adam_step = adam_step
+    monkey_ops.train_step = train_step
+    monkey_ops.get_context = lambda device: type("Ctx", (), {"native_comm": False, "device": "cpu"})()
+    return calls
+
+
+def _run_optim(world_tag):
+    from starst3r_amd import gs, ops
+    calls = _mock_ops(ops)
+    g, w2c, Ks, gt = scene()
+    sc = _CpuScene(g, w2c, Ks, gt.astype(np.float32))
+    gs.init_3dgs(sc)
+    with torch.no_grad():
+        for k in ("means", "quats", "scales", "opacities", "shN"):
+            sc.gaussians[k].data.copy_(torch.tensor(g[k]))
+    losses = gs.run_3dgs_optim(sc, 3)
+    return sc, losses, calls
+
+
+def _optim_worker(rank, world, port, base):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    sc, losses, calls = _run_optim(f"w{world}")
+    assert calls == dict(fwd_bwd=3, adam=3) and sc._gs_optim.step == 3
+    torch.save(dict(losses=losses, **{k: v.data.clone() for k, v in sc.gaussians.items()}),
+               os.path.join(base, f"optim{rank}.pth"))
+    torch.distributed.destroy_process_group()
+
+
+def test_run_3dgs_optim_rank_bookkeeping_matches_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_optim_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"optim{r}.pth") for r in range(2))
+    sc, losses, calls = _run_optim("single")
+    assert calls == dict(fwd_bwd=3, adam=3)
+    for k in ("means", "quats", "scales", "opacities", "shN"):
+        assert torch.equal(r0[k], r1[k]), k                                   # replicas identical, bit for bit
+        np.testing.assert_allclose(r0[k].numpy(), sc.gaussians[k].data.numpy(), rtol=0, atol=2e-6, err_msg=k)
+    assert r0["losses"] == r1["losses"] and len(r0["losses"]) == 3           # every rank returns the summed loss
+    np.testing.assert_allclose(r0["losses"], losses, rtol=1e-6)
