@@ -337,6 +337,9 @@ int st3r_canon_view(st3r_ctx* ctx, void* stream, int n, int H, int W, int subsam
                     const float* confs, float* canon, float* canon2, float* cconf);
 int st3r_focal_weiszfeld(st3r_ctx* ctx, void* stream, int H, int W, const float* canon, float ppx, float ppy,
                          float min_focal, float max_focal, float* focal_out);
+/* the same for n_views images of one size in ONE launch: canon [n_views,H,W,3] -> focal_out [n_views] */
+int st3r_focal_weiszfeld_batch(st3r_ctx* ctx, void* stream, int n_views, int H, int W, const float* canon, float ppx,
+                               float ppy, float min_focal, float max_focal, float* focal_out);
 int st3r_anchor_offsets(st3r_ctx* ctx, void* stream, int64_t n, int H, int W, int subsample, const float* canon2,
                         const float* xy, int32_t* idx_out, float* off_out);
 

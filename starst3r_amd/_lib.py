@@ -62,6 +62,7 @@ SIGNATURES = {
     "st3r_dense_clean": [vp, vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp],
     "st3r_canon_view": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "st3r_focal_weiszfeld": [vp, vp, i32, i32, vp, f32, f32, f32, f32, vp],
+    "st3r_focal_weiszfeld_batch": [vp, vp, i32, i32, i32, vp, f32, f32, f32, f32, vp],
     "st3r_anchor_offsets": [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp],
     "st3r_gs_raster_train": [vp, vp, i32, i32, vp, vp, i32, i32, f32, vp, vp, C.POINTER(i64)],
     "st3r_gs_render": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, C.POINTER(i64)],

@@ -73,16 +73,25 @@ def prepare_canonical_data(imgs, tmp_pairs, subsample, order_imgs=False, min_con
         canon4, cconf = canonical_view(torch.stack(ptmaps11), torch.stack(confs11), subsample, mode, ctx=ctx)
         H, W = cconf.shape
         pp = torch.tensor([W / 2, H / 2], device=device)
-        focal = ops.focal_weiszfeld(ctx, canon4[..., :3].contiguous(), (W / 2, H / 2), 0.5, 3.5)
         core_depth = canon4[subsample // 2::subsample, subsample // 2::subsample, 2].contiguous()
         canon2 = canon4[..., 3].contiguous()
         idxs, offsets = {}, {}
         for other, (xy, _c) in pixels.items():
             idx, off = ops.anchor_offsets(ctx, canon2, xy, subsample)
             idxs[other], offsets[other] = idx.long(), off
-        canonical_views[img] = (pp, (H, W), focal.view(1), core_depth, pixels, idxs, offsets)
+        canonical_views[img] = [pp, (H, W), canon4[..., :3], core_depth, pixels, idxs, offsets]   # focal: below
         if canon_out is not None:
             canon_out[img] = (canon2, cconf)
+    # focals of all images: one launch per image size (st3r_focal_weiszfeld_batch), not one per image
+    by_size = {}
+    for img in imgs:
+        by_size.setdefault(canonical_views[img][1], []).append(img)
+    for (H, W), group in by_size.items():
+        focals = ops.focal_weiszfeld_batch(ctx, torch.stack([canonical_views[i][2] for i in group]).contiguous(),
+                                           (W / 2, H / 2), 0.5, 3.5)
+        for k, i in enumerate(group):
+            canonical_views[i][2] = focals[k:k + 1].view(1)
+    canonical_views = {k: tuple(v) for k, v in canonical_views.items()}
     return tmp_pairs, pairwise_scores, canonical_views, canonical_paths, preds_21
 
 

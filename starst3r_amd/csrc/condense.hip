@@ -57,30 +57,47 @@ __global__ __launch_bounds__(256) void k_canon_angle(int n, int H, int W, int S,
     canon2[p] = 1.0f + depth / canon[3 * c + 2];
 }
 
-#define FT 1024
-__device__ __forceinline__ float block_sum_ft(float v, float* red) {
-    // fixed-order tree over the workgroup
-    red[threadIdx.x] = v;
+// dust3r estimate_focal_knowing_depth(focal_mode='weiszfeld') [U] for ALL views in one launch.
+// Pass 0 is the closed form f = mean(xy/z . pixel) / mean(|xy/z|^2); passes 1..10 repeat it with weights 1 / distance.
+// Each pass ends in a reduction over the whole image, so a view is spread over G workgroups that meet after every pass
+// (round 1 ran one 1024-thread workgroup per view and one launch per view: 1.14 ms x views, all of it dependent
+// latency on one CU).  The meeting is a counter barrier per view: lane 0 publishes the workgroup's partial sums as ONE
+// 8-byte word (relaxed agent-scope store: write-through, flag-free -- every word of `partials` is written once per
+// launch), drains it, bumps the view's counter and polls it; afterwards every workgroup adds the G partials in the
+// same fixed order, so all of them continue with the same focal bit for bit (and the result is reproducible).
+// All G x views workgroups are resident at once (G is chosen so that there are at most 1024 of them).
+#define FB_THREADS 256
+#define FB_MAX_G 64
+
+__device__ __forceinline__ float2 block_sum2_fb(float a, float b, float (*red)[FB_THREADS]) {
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
     __syncthreads();
-    for (int s = FT / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    for (int s = FB_THREADS / 2; s > 0; s >>= 1) {   // fixed-order tree over the workgroup
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
         __syncthreads();
     }
-    const float t = red[0];
+    const float2 t = make_float2(red[0][0], red[1][0]);
     __syncthreads();
     return t;
 }
 
-__global__ __launch_bounds__(FT) void k_focal_weiszfeld(int H, int W, const float* __restrict__ canon, float ppx,
-                                                        float ppy, float min_focal, float max_focal,
-                                                        float* __restrict__ focal_out) {
-    __shared__ float red[FT];
+__global__ __launch_bounds__(FB_THREADS) void k_focal_weiszfeld(int n_views, int G, int H, int W,
+                                                                const float* __restrict__ canon_all, float ppx,
+                                                                float ppy, float min_focal, float max_focal,
+                                                                unsigned long long* partials, unsigned* counters,
+                                                                float* __restrict__ focal_out) {
+    __shared__ float red[2][FB_THREADS];
+    __shared__ float s_focal;
+    const int view = blockIdx.y, wg = blockIdx.x;
     const int HW = H * W;
-    // pass 0: closed form  f = mean(xy/z . pixel) / mean(|xy/z|^2);  passes 1..10: the same with weights 1 / distance
+    const float* canon = canon_all + (size_t)view * HW * 3;
     float focal = 0.f;
     for (int it = 0; it <= 10; ++it) {
         float num = 0.f, den = 0.f;
-        for (int p = threadIdx.x; p < HW; p += FT) {
+        for (int p = wg * FB_THREADS + threadIdx.x; p < HW; p += G * FB_THREADS) {
             const int y = p / W, x = p - y * W;
             const float u = (float)x - ppx, v = (float)y - ppy;
             const float z = canon[3 * p + 2];
@@ -95,12 +112,35 @@ __global__ __launch_bounds__(FT) void k_focal_weiszfeld(int H, int W, const floa
             }
             num += w * dpx; den += w * dxx;
         }
-        const float N = block_sum_ft(num, red), D = block_sum_ft(den, red);
-        focal = (N / (float)HW) / (D / (float)HW);
+        const float2 t = block_sum2_fb(num, den, red);
+        unsigned long long* slot = partials + ((size_t)it * n_views + view) * G;
+        if (threadIdx.x == 0) {
+            const unsigned long long word = ((unsigned long long)__float_as_uint(t.y) << 32) | __float_as_uint(t.x);
+            __hip_atomic_store(slot + wg, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the word has left before the arrival is counted
+            __hip_atomic_fetch_add(counters + view, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)G * (unsigned)(it + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(counters + view, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 24)) __builtin_trap();   // every workgroup of the grid is resident: cannot happen
+            }
+        }
+        __syncthreads();
+        // the G partials, added in a fixed order (identical in every workgroup)
+        float pn = 0.f, pd = 0.f;
+        if ((int)threadIdx.x < G) {
+            const unsigned long long word = __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pn = __uint_as_float((unsigned)word); pd = __uint_as_float((unsigned)(word >> 32));
+        }
+        const float2 tot = block_sum2_fb(pn, pd, red);
+        if (threadIdx.x == 0) s_focal = (tot.x / (float)HW) / (tot.y / (float)HW);
+        __syncthreads();
+        focal = s_focal;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && wg == 0) {
         const float base = (float)max(H, W) / (2.0f * 0.57735026918962576f);   // 2 tan(30 deg)
-        focal_out[0] = fminf(fmaxf(focal, min_focal * base), max_focal * base);
+        focal_out[view] = fminf(fmaxf(focal, min_focal * base), max_focal * base);
     }
 }
 
@@ -130,13 +170,30 @@ ST3R_EXPORT int st3r_canon_view(st3r_ctx* ctx, void* stream, int n, int H, int W
     return ST3R_OK;
 }
 
-ST3R_EXPORT int st3r_focal_weiszfeld(st3r_ctx* ctx, void* stream, int H, int W, const float* canon, float ppx,
-                                     float ppy, float min_focal, float max_focal, float* focal_out) {
-    ARG_CHECK(ctx && H > 0 && W > 0 && canon && focal_out && min_focal > 0.f && max_focal >= min_focal);
-    hipLaunchKernelGGL(k_focal_weiszfeld, dim3(1), dim3(FT), 0, (hipStream_t)stream, H, W, canon, ppx, ppy, min_focal,
-                       max_focal, focal_out);
+ST3R_EXPORT int st3r_focal_weiszfeld_batch(st3r_ctx* ctx, void* stream, int n_views, int H, int W, const float* canon,
+                                           float ppx, float ppy, float min_focal, float max_focal, float* focal_out) {
+    ARG_CHECK(ctx && n_views > 0 && n_views <= 1024 && H > 0 && W > 0 && canon && focal_out && min_focal > 0.f &&
+              max_focal >= min_focal);
+    hipStream_t s = (hipStream_t)stream;
+    // G workgroups per view: enough to spread an image over many CUs, few enough that the whole grid is resident
+    int G = min(FB_MAX_G, max(1, 1024 / n_views));
+    G = min(G, max(1, ceil_div((int64_t)H * W, FB_THREADS)));
+    const size_t part_bytes = sizeof(unsigned long long) * 11 * (size_t)n_views * G;
+    const size_t cnt_off = (part_bytes + 255) & ~(size_t)255;
+    void* p;
+    int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, cnt_off + sizeof(unsigned) * (size_t)n_views, &p);
+    if (rc) return rc;
+    unsigned* counters = (unsigned*)((char*)p + cnt_off);
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * (size_t)n_views, s));
+    hipLaunchKernelGGL(k_focal_weiszfeld, dim3(G, n_views), dim3(FB_THREADS), 0, s, n_views, G, H, W, canon, ppx, ppy,
+                       min_focal, max_focal, (unsigned long long*)p, counters, focal_out);
     LAUNCH_CHECK();
     return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_focal_weiszfeld(st3r_ctx* ctx, void* stream, int H, int W, const float* canon, float ppx,
+                                     float ppy, float min_focal, float max_focal, float* focal_out) {
+    return st3r_focal_weiszfeld_batch(ctx, stream, 1, H, W, canon, ppx, ppy, min_focal, max_focal, focal_out);
 }
 
 ST3R_EXPORT int st3r_anchor_offsets(st3r_ctx* ctx, void* stream, int64_t n, int H, int W, int subsample,

@@ -274,6 +274,15 @@ def focal_weiszfeld(ctx, canon, pp, min_focal=0.5, max_focal=3.5):
     return out
 
 
+def focal_weiszfeld_batch(ctx, canons, pp, min_focal=0.5, max_focal=3.5):
+    """The same for a stack of images of one size in one launch: canons [n,H,W,3] -> tensor [n]."""
+    n, H, W = canons.shape[:3]
+    out = torch.empty(n, device=canons.device)
+    _lib.check(_lib.lib().st3r_focal_weiszfeld_batch(ctx.handle, _stream(), n, H, W, _p(canons), float(pp[0]),
+                                                     float(pp[1]), min_focal, max_focal, _p(out)))
+    return out
+
+
 def anchor_offsets(ctx, canon2, xy, subsample):
     """Mast3r anchor_depth_offsets [U] for one list of correspondence pixels xy [n,2] -> (idx int32 [n], off [n])."""
     H, W = canon2.shape

@@ -101,9 +101,14 @@ class _RankScene:
 
 def test_cfg4_rank_workload_5M_gaussians_8_views_4k_with_pruning():
     """configs[4], one rank of eight: 5 M Gaussians x 8 views of 3840x2160 through Scene-level run_3dgs_optim with
-    enable_pruning=True across step 600 (the first refinement step of gsplat's MCMC defaults: 500 < step, every
-    100): dead Gaussians are relocated (N is above cap_max = 1 M, so nothing is added), position noise is injected
-    every step, the loss stays finite and decreases, nothing is NaN."""
+    enable_pruning=True (starster/gs.py:146-147,163-164): dead Gaussians are relocated (N is above cap_max = 1 M, so
+    nothing is added), position noise is injected every step, the loss stays finite and decreases, nothing is NaN.
+
+    The refinement window is compressed (first refinement at step 50, then every 25 steps, instead of gsplat's
+    500 / 100) because this workload cannot reach step 500 on ANY implementation of the reference's loop: scales are
+    optimised RAW with lr 1e-3, so the 0.002..0.008 Gaussians of the synthetic scene grow by ~4e-5
+    per step and the tile intersections with them -- measured here (tools/diag_cfg4.py): 2.7e8 at step 0, 9.3e8 at
+    step 125, 2.1e9 at step 200, past 2^31 (the int32 limit of one call, gsplat's too) at step 203."""
     from starst3r_amd import gs, ops
     ctx = ops.get_context(DEV)
     n, v, w, h = 5_000_000, 8, 3840, 2160
@@ -121,13 +126,24 @@ def test_cfg4_rank_workload_5M_gaussians_8_views_4k_with_pruning():
             sc.gaussians[k].data.copy_(torch.tensor(g[k], device=DEV))
         sc.gaussians["opacities"].data[::1000] = -7.0          # 5 000 Gaussians the strategy considers dead
     n_dead = int((torch.sigmoid(sc.gaussians["opacities"].data) <= 0.005).sum())
-    losses = gs.run_3dgs_optim(sc, 610, enable_pruning=True)
+    sc.strategy.refine_start_iter, sc.strategy.refine_every = 49, 25
+    relocated = []
+    orig = ops.mcmc_relocate
+
+    def spy(*a, **k):
+        relocated.append(orig(*a, **k))
+        return relocated[-1]
+    ops.mcmc_relocate = spy
+    try:
+        losses = gs.run_3dgs_optim(sc, 110, enable_pruning=True)     # refinements at steps 50, 75, 100
+    finally:
+        ops.mcmc_relocate = orig
     L = np.asarray(losses)
-    assert len(L) == 610 and np.isfinite(L).all() and L[-1] < L[0]
-    assert sc.strategy_state["n_relocated"] >= n_dead * 0.9 and sc.strategy_state["n_added"] == 0
+    assert len(L) == 110 and np.isfinite(L).all() and L[-1] < L[0]
+    assert len(relocated) == 3 and relocated[0] >= n_dead and sc.strategy_state["n_added"] == 0
     assert sc.gaussians["means"].shape[0] == n
     assert int((torch.sigmoid(sc.gaussians["opacities"].data) <= 0.005 - 1e-6).sum()) == 0
     for k in ("means", "quats", "scales", "opacities"):
         assert bool(torch.isfinite(sc.gaussians[k].data).all()), k
     print("cfg[4] rank: isects of the GT render", st0["n_isects"], "arena GB", ctx.arena_bytes() / 1e9,
-          "loss", L[0], "->", L[-1], "relocated", sc.strategy_state["n_relocated"])
+          "loss", L[0], "->", L[-1], "relocated per refinement", relocated)

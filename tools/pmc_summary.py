@@ -36,5 +36,47 @@ def main(paths):
         print(f"| {k} | {n} | " + " | ".join(cells) + " |")
 
 
+# kernels of each stage of the fused train step (the stages bench.py times)
+STAGE_KERNELS = {
+    "blend_bwd": ("k_blend_bwd", "k_gather_vtile"), "blend_fwd": ("k_blend_fwd",), "loss": ("k_ssim_wave", "k_ssim_fused"),
+    "project": ("k_project_sh_fwd", "k_reg_reduce"), "project_bwd": ("k_project_sh_bwd",), "adam": ("k_adam",),
+    "emit": ("k_isect_emit_rects",), "offsets": ("k_isect_offsets32",), "scan": ("k_scan_reduce", "k_scan_blocksums", "k_scan_down"),
+}
+
+
+def traffic_json(paths, out_path, commit, workload):
+    """profiles/pmc_traffic.json for bench.py: HBM bytes per launch and stage = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+    (MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950; both counters in KiB),
+    from separate --pmc passes, together with the workload and the fingerprint of the kernel sources measured."""
+    import json
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    vals = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(set))
+    for p in paths:
+        for r in csv.DictReader(open(p)):
+            k = short(r["Kernel_Name"]).split("<")[0].strip()
+            vals[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+    per_kernel = {}
+    for k in vals:
+        if "FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k]:
+            f = vals[k]["FETCH_SIZE"] / len(calls[k]["FETCH_SIZE"]); w = vals[k]["WRITE_SIZE"] / len(calls[k]["WRITE_SIZE"])
+            per_kernel[k] = dict(fetch_kib=f, write_kib=w, bytes=(2 * f + w) * 1024)
+    stages = {}
+    for st, ks in STAGE_KERNELS.items():
+        b = sum(per_kernel[k]["bytes"] for k in ks if k in per_kernel)
+        if b:
+            stages[st] = b
+    rec = dict(commit=commit, csrc_fingerprint=bench.csrc_fingerprint(), workload=workload,
+               source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2 x FETCH + WRITE) x 1024 per launch",
+               traffic_bytes_per_launch=stages, kernels=per_kernel)
+    json.dump(rec, open(out_path, "w"), indent=1)
+    print("wrote", out_path, {k: round(v / 1e9, 3) for k, v in stages.items()})
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if sys.argv[1] == "--traffic-json":   # pmc_summary.py --traffic-json OUT COMMIT csv...
+        wl = dict(gaussians=1_000_000, views=8, width=1920, height=1080, n_gpus=1)
+        traffic_json(sys.argv[4:], sys.argv[2], sys.argv[3], wl)
+    else:
+        main(sys.argv[1:])

@@ -5,6 +5,7 @@
 #include <string.h>
 #include <rocprim/rocprim.hpp>
 #include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <numeric>
 #include <vector>
@@ -66,9 +67,16 @@ static bool run(st3r_ctx* ctx, size_t n, int bits, int mode, bool check, bool ti
     return ok;
 }
 
-int main() {
+int main(int argc, char** argv) {
     st3r_ctx* ctx; if (st3r_ctx_create(0, &ctx)) { printf("ctx: %s\n", st3r_last_error()); return 1; }
     bool ok = true;
+    if (argc > 1) {   // rsort_probe <abl>: only the two big shapes, kernel ablation flags (timing only)
+        const int abl = atoi(argv[1]);
+        st3r_ctx_set_debug(ctx, abl << 8);
+        run<uint32_t>(ctx, 8000000, 32, 0, false, false);
+        run<uint32_t>(ctx, 26000000, 16, 1, false, false);
+        return 0;
+    }
     for (size_t n : {1ul, 63ul, 64ul, 65ul, 4095ul, 4096ul, 4097ul, 8192ul, 8193ul, 100000ul, 1000003ul})
         for (int mode = 0; mode < 3; ++mode) {
             ok &= run<uint32_t>(ctx, n, 32, mode, true, false);
