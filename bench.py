@@ -352,18 +352,32 @@ def main():
             sdist.attach_native_comm(ctx)      # torch.distributed only ships the 128-byte RCCL id
 
         def step(it):
+            # statistics (which need the record count on the host, i.e. a device synchronisation) only for the first
+            # and the last step; every other step runs without a host round trip, like Scene.run_3dgs_optim
+            stats = it == 0 or it == total - 1
             if FREEZE:
-                return ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1])
+                return ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1],
+                                         want_stats=stats)
             # the whole iteration is ONE C call: fwd/bwd -> st3r_grad_allreduce (RCCL, no-op for one rank) -> Adam
             return ops.train_step(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999,
-                                  1e-8, it + 1, losses[it:it + 1])
+                                  1e-8, it + 1, losses[it:it + 1], want_stats=stats)
+
+    def psnr_local():
+        """mean PSNR of this rank's views against their GT images (renders outside the timed region)"""
+        if mode == "gaussian-sharded":
+            return None
+        with torch.no_grad():
+            rgb, _, _ = ops.render(ctx, P, w2c, Ks, ops.camera_positions(w2c), W, H)
+            mse = ((rgb.clamp(0, 1) - gt) ** 2).reshape(rgb.shape[0], -1).mean(1)
+            return float((-10.0 * torch.log10(mse)).mean())
+    psnr_before = psnr_local()
 
     # Stage timing costs two HIP events per stage and step (~0.15 ms per step for all eleven): the warm-up steps time
     # every stage to find the dominant one, the timed region times only that one (live, on the launch stream).
     ops.set_profiling(ctx, args.warmup > 0)
     ops.stage_ms(ctx)  # reset
     for it in range(args.warmup):
-        stats = step(it)
+        stats = step(it) or stats
     warm_stage = ops.stage_ms(ctx) if args.warmup > 0 else {}
     warm_ms = {k: ms / n for k, (ms, n) in warm_stage.items() if n > 0}
     dom_warm = max(warm_ms, key=warm_ms.get) if warm_ms else None
@@ -378,7 +392,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for it in range(args.warmup, total):
-        stats = step(it)
+        stats = step(it) or stats
         marks[it - args.warmup + 1].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -389,6 +403,7 @@ def main():
     win_ms = [marks[edges[k]].elapsed_time(marks[edges[k + 1]]) / (edges[k + 1] - edges[k]) for k in range(n_win)]
     stage = ops.stage_ms(ctx)
     ops.set_profiling(ctx, False)
+    psnr_after = psnr_local()
     if mode == "gaussian-sharded":   # counts of the own Gaussians over all views ~ those of the own views over all Gaussians
         stats["n_visible"] = int(trainer.reg[2].item()); stats["n_isects_ref"] = int(trainer.reg[3].item())
     if world > 1:
@@ -438,6 +453,8 @@ def main():
                 "mean_tiles_per_visible_gaussian": (I_kept / V) if V else 0.0,
                 "mean_records_per_tile": I_kept / (C_local * tw * th),
                 "loss_first": float(L[0]), "loss_last": float(L[-1]),
+                # training views of rank 0 against their GT, before the first and after the last of the warmup + timed steps
+                "psnr_db_before": psnr_before, "psnr_db_after": psnr_after,
             },
             # five windows of steps/5 consecutive steps inside the one timed region (HIP events on the launch stream)
             "windows": {"ms_per_step": win_ms, "median_ms_per_step": win_sorted[len(win_sorted) // 2],

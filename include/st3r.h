@@ -172,6 +172,13 @@ int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quat
  *                   added reg_views times)
  *   stats_host[4]   optional host int64: n_visible_pairs, n_isects actually sorted/blended (after exact tile
  *                   culling), arena bytes, n_isects of the reference algorithm (gsplat's 3-sigma squares)
+ * Host synchronisation.  The number of tile intersections is produced on the device.  With stats_host != NULL
+ * the call copies it back and synchronises the stream once (exact statistics, exactly sized scratch).  With
+ * stats_host == NULL and a count known from an earlier call on the same (N, C, width, height) the call is fully
+ * asynchronous: scratch is sized from the previous count (+25 %), every kernel reads the count from device
+ * memory, and the count is checked when the NEXT call into this ctx starts -- if a step ever outgrows its
+ * capacity (its surplus records are dropped, never written out of bounds) that next call returns
+ * ST3R_ERR_CAPACITY and the one after it falls back to the synchronous path.
  * The second half is an (optional) all-reduce of `grads` by the caller, then st3r_adam_step.
  * ---------------------------------------------------------------------------------- */
 int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,

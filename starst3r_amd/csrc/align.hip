@@ -49,6 +49,7 @@ struct AlignState {
     float* m; float* v;        // Adam moments [11*C] in the order pps, log_focals, quats, trans, log_sizes
     float* cam;                // [C,CAM_STRIDE]
     float* acc;                // [C*ACC_STRIDE + 4]: gradient sums, then [loss, nan flag]
+    float* part;               // [workgroups of k_align_resid][C*ACC_STRIDE + 1]: their partial sums
     float* losses;             // [niter1 + niter2]
 };
 
@@ -152,40 +153,42 @@ __device__ __forceinline__ float wave_sum_row3(float v) {
     return v;
 }
 
-__device__ __forceinline__ void flush_camera(const CamGrad& c, float* sacc) {
-    const uint64_t has = __ballot(c.img >= 0);
-    if (has == 0) return;
-    const int ref = __builtin_amdgcn_readlane(c.img, __builtin_ctzll(has));
-    const bool uniform = __ballot(c.img >= 0 && c.img != ref) == 0;
-    if (uniform) {
-        float* g = sacc + ref * ACC_STRIDE;
-        const int lane = threadIdx.x & 63;
+// `sw` = THIS WAVE's accumulator array: nothing else writes it, so plain read-modify-writes by one lane per word are
+// enough and the order of the additions is the program order -- gradients are bit-reproducible run to run (round 1
+// added into one array shared by the four waves with LDS float atomics, whose order is not defined).
+__device__ __forceinline__ void flush_camera(const CamGrad& c, float* sw) {
+    uint64_t todo = __ballot(c.img >= 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {   // one trip per distinct camera among the wave's rows (almost always exactly one), in lane order
+        const int ref = __builtin_amdgcn_readlane(c.img, __builtin_ctzll(todo));
+        const bool mine = c.img == ref;
+        float* g = sw + ref * ACC_STRIDE;
 #pragma unroll
         for (int k = 0; k < 17; ++k) {
-            const float v = wave_sum_row3(c.g[k]);   // lanes without a contribution hold zeros
-            if (lane == 48 + (k & 15)) atomicAdd(&g[k], v);   // row 3 holds the totals: 17 distinct addresses
+            const float v = wave_sum_row3(mine ? c.g[k] : 0.f);   // all lanes active here: todo is wave-uniform
+            if (lane == 48 + (k & 15)) g[k] += v;                  // row 3 holds the totals: 17 distinct words
         }
-    } else if (c.img >= 0) {
-        float* g = sacc + c.img * ACC_STRIDE;
-#pragma unroll
-        for (int k = 0; k < 17; ++k) atomicAdd(&g[k], c.g[k]);
+        todo &= ~__ballot(mine);
     }
 }
 
 // stage: 1 = loss_3d rows + dust rows, 2 = loss_2d rows + dust rows
-__global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState S, int stage, float dust_w) {
-    extern __shared__ float sacc[];  // [C*ACC_STRIDE + 1] accumulators, then the camera table [C*CAM_STRIDE]
+__global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState S, int stage, float dust_w, int rpt) {
+    extern __shared__ float sacc[];  // 4 x [C*ACC_STRIDE + 1] accumulators (one per wave), then the camera table [C*CAM_STRIDE]
     const int nacc = P.C * ACC_STRIDE + 1;
-    float* scam = sacc + nacc;
-    for (int i = threadIdx.x; i < nacc; i += blockDim.x) sacc[i] = 0.f;
+    float* scam = sacc + 4 * nacc;
+    float* sw = sacc + (threadIdx.x >> 6) * nacc;
+    for (int i = threadIdx.x; i < 4 * nacc; i += blockDim.x) sacc[i] = 0.f;
     for (int i = threadIdx.x; i < P.C * CAM_STRIDE; i += blockDim.x) scam[i] = S.cam[i];   // overlaps the row index loads
     __syncthreads();
+    const bool running = S.acc[P.C * ACC_STRIDE + 1] == 0.f;   // not stopped by a NaN loss
+    for (int rr = 0; rr < rpt; ++rr) {   // rpt consecutive groups of 256 rows per workgroup (bounds the number of partials)
     CamGrad ca, cb;
     cam_clear(ca); cam_clear(cb);
     float lsum = 0.f;
-    if (S.acc[P.C * ACC_STRIDE + 1] == 0.f) {  // not stopped by a NaN loss
+    if (running) {
         const int n_main = stage == 1 ? P.n_corr : P.n_c2d;
-        const int row = blockIdx.x * blockDim.x + threadIdx.x;
+        const int row = (blockIdx.x * rpt + rr) * blockDim.x + threadIdx.x;
         if (row < n_main) {
             if (stage == 1) {
                 const int a1 = P.corr_a1[row], a2 = P.corr_a2[row];
@@ -284,16 +287,20 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
             }
         }
     }
-    // converged again: wave-level hand-over to the LDS accumulators
-    flush_camera(ca, sacc);
-    flush_camera(cb, sacc);
+    // converged again: wave-level hand-over to the wave's LDS accumulators
+    flush_camera(ca, sw);
+    flush_camera(cb, sw);
     {
         const float v = wave_sum_row3(lsum);
-        if ((threadIdx.x & 63) == 63 && v != 0.f) atomicAdd(&sacc[P.C * ACC_STRIDE], v);
+        if ((threadIdx.x & 63) == 63) sw[P.C * ACC_STRIDE] += v;
     }
+    }   // rr
     __syncthreads();
+    // the workgroup's partial sums (four waves in a fixed order); k_align_update adds the workgroups in order: no float
+    // atomics anywhere, so the whole alignment is bit-reproducible
+    float* part = S.part + (size_t)blockIdx.x * nacc;
     for (int i = threadIdx.x; i < nacc; i += blockDim.x)
-        if (sacc[i] != 0.f) atomicAdd(&S.acc[i], sacc[i]);
+        part[i] = (sacc[i] + sacc[nacc + i]) + (sacc[2 * nacc + i] + sacc[3 * nacc + i]);
 }
 
 __device__ __forceinline__ void quat_to_rot(const float* q, float* R, float* qn, float* inv_norm) {
@@ -306,7 +313,25 @@ __device__ __forceinline__ void quat_to_rot(const float* q, float* R, float* qn,
     qn[0] = x; qn[1] = y; qn[2] = z; qn[3] = w; *inv_norm = inv;
 }
 
+// S.acc[k] = sum over the residual workgroups of their partials, in workgroup order (used when there are too many of
+// them for the single workgroup of k_align_update to add without stretching the iteration)
+__global__ __launch_bounds__(256) void k_align_reduce(AlignState S, int nacc, int n_part) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nacc) return;
+    const float* __restrict__ part = S.part;
+    float a = 0.f;
+    for (int b0 = 0; b0 < n_part; b0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = b0 + j < n_part ? part[(size_t)(b0 + j) * nacc + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    S.acc[k] = a;
+}
+
 struct UpdateArgs {
+    int n_part;        // workgroups of the residual launch whose partial sums are added (in order) first
     int do_backward;   // 0: only build the camera table (first call)
     int stage;         // trainable set: 1 = quats, trans, log_sizes ; 2 = + pps, log_focals
     float lr;          // cosine-scheduled learning rate of this step
@@ -384,7 +409,7 @@ __device__ __forceinline__ void chain_reverse_wave(int lane, int n_edges, const 
 __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState S, UpdateArgs U) {
     __shared__ float sRr[MAXC * 9], sRt[MAXC * 9], stt[MAXC * 3];        // relative / chained rotations, chained translation
     __shared__ float svRt[MAXC * 9], svtt[MAXC * 3];                      // their gradients
-    __shared__ float ssize[MAXC];
+    __shared__ float ssize[MAXC], svgs[MAXC];
     __shared__ float strans[MAXC * 3];   // relative translations and the MST edges, staged once: the three serial chain
     __shared__ int sedge[MAXC * 2];      // walks below are done by one thread and must not wait on global memory
     __shared__ float s_gs, s_vgs, s_min; __shared__ int s_argmin;
@@ -394,6 +419,23 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
     for (int k = i; k < 2 * P.n_edges; k += blockDim.x) sedge[k] = P.edges[k];
     float* flags = S.acc + C * ACC_STRIDE;
     if (U.do_backward && flags[1] != 0.f) return;  // stopped earlier by a NaN loss
+    if (U.do_backward && U.n_part >= 0) {   // gradient sums and loss = the residual workgroups' partials, added in
+                                            // workgroup order (n_part < 0: k_align_reduce has done it)
+        const int nacc = C * ACC_STRIDE + 1;
+        const float* __restrict__ part = S.part;
+        for (int k = i; k < nacc; k += blockDim.x) {
+            float a = 0.f;
+            for (int b0 = 0; b0 < U.n_part; b0 += 8) {   // eight loads in flight, added strictly in workgroup order
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = b0 + j < U.n_part ? part[(size_t)(b0 + j) * nacc + k] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a += v[j];
+            }
+            S.acc[k] = a;
+        }
+        __syncthreads();
+    }
     if (U.do_backward && i == 0) {
         const float loss = flags[0];
         S.losses[U.loss_index] = loss;
@@ -459,7 +501,13 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
             v_ppx = g[13] * W - vto[0] * zc * (W / f);
             v_ppy = g[14] * H - vto[1] * zc * (H / f);
             v_s = v_zc * med * f / bf - vA * gs * med + vB * gs * med;
-            atomicAdd(&s_vgs, vgs_part);
+            svgs[i] = vgs_part;
+        }
+        __syncthreads();
+        if (i == 0) {   // fixed order (an LDS float atomic per camera left the order to the hardware)
+            float a = 0.f;
+            for (int k = 0; k < C; ++k) a += svgs[k];
+            s_vgs = a;
         }
         __syncthreads();
         if (i < 64) chain_reverse_wave(i, P.n_edges, sedge, sRr, strans, sRt, svRt, svtt);
@@ -585,7 +633,19 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
     S.m = work; S.v = work + 11 * C; S.cam = work + 22 * C; S.acc = S.cam + (int64_t)C * CAM_STRIDE;
     S.losses = losses_out;
     HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (size_t)need, s));
-    const size_t sh = sizeof(float) * ((size_t)C * ACC_STRIDE + 1 + (size_t)C * CAM_STRIDE);
+    const size_t sh = sizeof(float) * (4 * ((size_t)C * ACC_STRIDE + 1) + (size_t)C * CAM_STRIDE);
+    if (sh > 64 * 1024)   // more than ~190 views: the four accumulator copies pass the default dynamic-LDS limit
+        HIP_TRY(hipFuncSetAttribute((const void*)k_align_resid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    // one residual workgroup per 256 rows up to 1024 workgroups (then `rpt` groups of 256 rows each); up to 32 partials
+    // are added by k_align_update itself, more by k_align_reduce (one thread per accumulator word)
+    const int max_rows = (n_corr > n_c2d ? n_corr : n_c2d) + n_dust;
+    const int rpt = max_rows > 0 ? ceil_div(ceil_div(max_rows, 256), 1024) : 1;
+    {
+        void* pp;
+        int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, sizeof(float) * 1024 * ((size_t)C * ACC_STRIDE + 1), &pp);
+        if (rc) return rc;
+        S.part = (float*)pp;
+    }
     {   // constants of every anchor, packed once so that the residual kernel has a single dependent load level
         void* pk;
         int rc = st3r_arena_get(ctx, SLOT_NN_PART, sizeof(float4) * 2 * (size_t)(n_anchors > 0 ? n_anchors : 1), &pk);
@@ -595,7 +655,7 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
             hipLaunchKernelGGL(k_align_pack_anchors, dim3(ceil_div(n_anchors, 256)), dim3(256), 0, s, n_anchors, anchor_pix,
                                anchor_idx, anchor_off, anchor_img, core, G, (float4*)pk);
     }
-    UpdateArgs U0 = {0, 1, 0.f, 0, 0, 0};
+    UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0};
     hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U0);
     // The reference returns K / cam2w / depthmaps / pts3d as computed at the START of the last iteration,
     // i.e. one optimiser step behind the returned parameters (optimize_loop builds them before
@@ -616,9 +676,12 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
         const int rows = (stage == 1 ? n_corr : n_c2d) + n_dust;
         for (int it = 0; it < niter; ++it) {
             if (stage == last_stage && it == niter - 1) { int rc = export_results(); if (rc) return rc; }
-            if (rows > 0) hipLaunchKernelGGL(k_align_resid, dim3(ceil_div(rows, 256)), dim3(256), sh, s, P, S, stage, dust_weight);
+            const int n_part = rows > 0 ? ceil_div(rows, 256 * rpt) : 0;
+            if (rows > 0) hipLaunchKernelGGL(k_align_resid, dim3(n_part), dim3(256), sh, s, P, S, stage, dust_weight, rpt);
+            const int nacc = C * ACC_STRIDE + 1;
+            if (n_part > 32) hipLaunchKernelGGL(k_align_reduce, dim3(ceil_div(nacc, 256)), dim3(256), 0, s, S, nacc, n_part);
             UpdateArgs U;
-            U.do_backward = 1; U.stage = stage;
+            U.n_part = n_part > 32 ? -1 : n_part; U.do_backward = 1; U.stage = stage;
             U.lr = (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
             U.step = it + 1; U.loss_index = li++; U.reset_moments = (it == 0);
             hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U);

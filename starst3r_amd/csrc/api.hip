@@ -39,6 +39,7 @@ ST3R_EXPORT int st3r_ctx_destroy(st3r_ctx* ctx) {
     for (int i = 0; i < SLOT_COUNT; ++i)
         if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->count_event) (void)hipEventDestroy(ctx->count_event);
     if (ctx->prof_ev[0][0][0])
         for (int r = 0; r < PROF_RING; ++r)
             for (int st = 0; st < STG_COUNT; ++st)
@@ -183,29 +184,54 @@ int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, con
                               uint64_t* rects_sorted);
 int st3r_isect_emit_rects_impl(hipStream_t s, int N, int C, const int32_t* perm, const int32_t* cum_sorted,
                                const uint64_t* rects_sorted, int tile_w, int tile_h, uint32_t* tile_keys,
-                               int32_t* vals);
+                               int32_t* vals, int64_t cap);
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
                               int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base,
                               uint64_t* rects);
 int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
-                              int32_t* offsets);
+                              int32_t* offsets, const int32_t* n_dev);
 int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint64_t* keys_in, int32_t* vals_in,
                          uint64_t* keys_out, int32_t* vals_out);
 int st3r_sort_depth32_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
                            uint32_t* keys_out, int32_t* vals_out);
 int st3r_sort_tile_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
-                        uint32_t* keys_out, int32_t* vals_out);
+                        uint32_t* keys_out, int32_t* vals_out, const int32_t* n_dev);
 int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
-                        float* rgb, float* alpha, int32_t* last_ids, bool for_backward);
+                        float* rgb, float* alpha, int32_t* last_ids, bool for_backward, bool end_in_offsets);
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats);
+                        const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats,
+                        bool end_in_offsets);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
 static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+
+// The previous asynchronous step left its record count in pinned memory behind an event: pick it up (it completed long
+// ago), remember it as the sizing hint, and fail loudly if that step ran out of capacity (its records past the
+// capacity were dropped, so its gradients were incomplete).
+static int settle_pending_count(st3r_ctx* ctx) {
+    if (!ctx->count_pending) return ST3R_OK;
+    HIP_TRY(hipEventSynchronize(ctx->count_event));
+    ctx->count_pending = 0;
+    const int64_t n = (int64_t)((int32_t*)(ctx->pinned + 8))[0];
+    if (n < 0) {
+        ctx->isect_hint = 0;
+        st3r_set_error("the previous step produced more than 2^31 tile intersections: split the views over more calls / GPUs");
+        return ST3R_ERR_INVALID;
+    }
+    if (n > ctx->count_cap) {
+        ctx->isect_hint = 0;   // the next call takes the synchronous path and sizes its buffers exactly
+        st3r_set_error("the previous step produced %lld tile intersections, more than the %lld its buffers were sized "
+                       "for from the step before (+25 %%): its gradients were incomplete -- repeat it",
+                       (long long)n, (long long)ctx->count_cap);
+        return ST3R_ERR_CAPACITY;
+    }
+    ctx->isect_hint = n;
+    return ST3R_OK;
+}
 
 #define GET(slot, type, count, var)                                                          \
     type* var;                                                                               \
@@ -224,7 +250,7 @@ struct RasterOut {
 static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats,
                            const float* scales, const float* opacities, const float* sh, int sh_stride,
                            const float* viewmats, const float* Ks, const float* campos, int W, int H,
-                           double* reg_sums, int tight, const float* records_in, RasterOut* o) {
+                           double* reg_sums, int tight, const float* records_in, bool allow_async, RasterOut* o) {
     // records_in != NULL: the splat records were projected elsewhere (Gaussian-sharded mode); the projection is
     // replaced by k_records_prepare and the records are used in place
     const int tile = 16;
@@ -237,7 +263,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     }
     GET(SLOT_TILES, int32_t, n_pairs, tiles);
     GET(SLOT_CUM, int32_t, n_pairs, cum);
-    GET(SLOT_OFFSETS, int32_t, (int64_t)C * tile_w * tile_h, offsets);
+    GET(SLOT_OFFSETS, int32_t, (int64_t)C * tile_w * tile_h + 1, offsets);   // + the total (closes the last tile)
     // Two-level sort (see gs_isect.hip): pairs by (camera | depth) first, then the emitted records by
     // their 32-bit (camera, tile) key with a stable sort -- the same final order as gsplat's single
     // 64-bit (camera | tile | depth) sort at roughly a quarter of the sort traffic.
@@ -283,7 +309,27 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     rc = st3r_isect_scan_perm_impl(ctx, s, n_pairs, tiles, perm, cum_d, &total_dev, rects, rects_d);
     st3r_prof_end(ctx, s, STG_SCAN);
     if (rc) return rc;
-    {   // read back the intersection count (and the visible-pair count) -- the one host sync per step
+    // The record count is produced on the device.  Steady state (allow_async and a count from an earlier call): no host
+    // round trip -- the buffers are sized from the previous count (+25 %, +1024), every kernel downstream reads the count
+    // from device memory, and the count travels to pinned memory behind an event that the NEXT call checks (it also
+    // notices, loudly, if this call's count exceeded its capacity).  Otherwise (first call, or the caller wants exact
+    // statistics back): copy + synchronise, as in round 1.
+    const int32_t* n_dev = nullptr;
+    const int64_t sig = ((int64_t)N << 34) ^ ((int64_t)C << 26) ^ ((int64_t)W << 13) ^ (int64_t)H;
+    const bool async = allow_async && ctx->isect_hint > 0 && ctx->hint_sig == sig;
+    if (async) {
+        GET(SLOT_COUNTS, int32_t, 16, counts);
+        HIP_TRY(hipMemcpyAsync(counts, total_dev, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + 8), total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (!ctx->count_event) HIP_TRY(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->count_event, s));
+        n_dev = counts;
+        n_isects = ctx->isect_hint + ctx->isect_hint / 4 + 1024;   // capacity, not the count
+        if (ctx->debug_flags & 8) n_isects = ctx->isect_hint / 2;   // test hook: provoke a capacity overflow
+        if (n_isects > 2147483647LL) n_isects = 2147483647LL;
+        ctx->count_pending = 1; ctx->count_cap = n_isects;
+        o->n_visible = -1; o->n_isects_ref = -1;
+    } else {
         HIP_TRY(hipMemcpyAsync(ctx->pinned, total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (reg_sums) HIP_TRY(hipMemcpyAsync(ctx->pinned + 1, reg_sums + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -294,6 +340,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
         }
         o->n_visible = reg_sums ? (int64_t)((double*)ctx->pinned)[1] : -1;
         o->n_isects_ref = reg_sums ? (int64_t)((double*)ctx->pinned)[2] : n_isects;
+        if (allow_async) { ctx->isect_hint = n_isects; ctx->hint_sig = sig; }
     }
     GET(SLOT_KEYS_A, uint32_t, n_isects, tkeys_a);
     GET(SLOT_KEYS_B, uint32_t, n_isects, tkeys_b);
@@ -301,17 +348,17 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
     if (n_isects > 0) {
         st3r_prof_begin(ctx, s, STG_EMIT);
-        rc = st3r_isect_emit_rects_impl(s, N, C, perm, cum_d, rects_d, tile_w, tile_h, tkeys_a, vals_a);
+        rc = st3r_isect_emit_rects_impl(s, N, C, perm, cum_d, rects_d, tile_w, tile_h, tkeys_a, vals_a, n_isects);
         st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
         const int end_bit = bit_length_u32((uint32_t)((int64_t)C * tile_w * tile_h - 1));
         st3r_prof_begin(ctx, s, STG_SORT);
-        rc = st3r_sort_tile_impl(ctx, s, n_isects, end_bit, tkeys_a, vals_a, tkeys_b, vals_b);
+        rc = st3r_sort_tile_impl(ctx, s, n_isects, end_bit, tkeys_a, vals_a, tkeys_b, vals_b, n_dev);
         st3r_prof_end(ctx, s, STG_SORT);
         if (rc) return rc;
     }
     st3r_prof_begin(ctx, s, STG_OFFSETS);
-    rc = st3r_isect_offsets32_impl(s, n_isects, tkeys_b, C, tile_w, tile_h, offsets);
+    rc = st3r_isect_offsets32_impl(s, n_isects, tkeys_b, C, tile_w, tile_h, offsets, n_dev);
     st3r_prof_end(ctx, s, STG_OFFSETS);
     if (rc) return rc;
     o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->rects = rects; o->n_isects = n_isects;
@@ -348,9 +395,14 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 4, s));
     st3r_prof_next_step(ctx);
     RasterOut ro;
-    int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                             reg_sums, 1, nullptr, &ro);
+    int rc = settle_pending_count(ctx);
     if (rc) return rc;
+    // exact statistics need the count on the host: a caller that passes stats_host pays the synchronisation
+    const bool allow_async = stats_host == nullptr;
+    rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
+                         reg_sums, 1, nullptr, allow_async, &ro);
+    if (rc) return rc;
+    const bool eio = true;   // the fused path's offsets table carries the total as its last entry
     GET(SLOT_RGB, float, n_px * 3, rgb);
     GET(SLOT_ALPHA, float, n_px, alpha);
     GET(SLOT_LAST, int32_t, n_px, last);
@@ -358,7 +410,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     GET(SLOT_VSPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, v_splats);
     st3r_prof_begin(ctx, s, STG_BLEND_FWD);
     rc = st3r_blend_fwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb,
-                             alpha, last, true);
+                             alpha, last, true, eio);
     st3r_prof_end(ctx, s, STG_BLEND_FWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_LOSS);
@@ -367,7 +419,8 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, ro.rects, 1, n_pairs, v_splats);
+                             last, v_rgb, nullptr, ro.cum, (ctx->debug_flags & 2) ? nullptr : ro.rects, 1, n_pairs, v_splats,
+                             eio);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
@@ -383,7 +436,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     LAUNCH_CHECK();
     if (stats_host) {
         stats_host[0] = ro.n_visible; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx);
-        stats_host[3] = ro.n_isects_ref;
+        stats_host[3] = ro.n_isects_ref;   // exact: stats_host selects the synchronous path
     }
     return ST3R_OK;
 }
@@ -405,8 +458,10 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 4, s));  // stays zero: the regularisers belong to the owners
     st3r_prof_next_step(ctx);
     RasterOut ro;
-    int rc = rasterize_front(ctx, s, N, C, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, W,
-                             H, nullptr, 1, records, &ro);
+    int rc = settle_pending_count(ctx);
+    if (rc) return rc;
+    rc = rasterize_front(ctx, s, N, C, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, W, H,
+                         nullptr, 1, records, stats_host == nullptr, &ro);
     if (rc) return rc;
     GET(SLOT_RGB, float, n_px * 3, rgb);
     GET(SLOT_ALPHA, float, n_px, alpha);
@@ -414,7 +469,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     GET(SLOT_VRENDER, float, n_px * 3, v_rgb);
     st3r_prof_begin(ctx, s, STG_BLEND_FWD);
     rc = st3r_blend_fwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb,
-                             alpha, last, true);
+                             alpha, last, true, true);
     st3r_prof_end(ctx, s, STG_BLEND_FWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_LOSS);
@@ -423,7 +478,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, ro.rects, 1, n_pairs, v_records);
+                             last, v_rgb, nullptr, ro.cum, ro.rects, 1, n_pairs, v_records, true);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     const int Hi = H - 10, Wi = W - 10;
@@ -447,12 +502,14 @@ ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const 
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && rgb && alpha);
     hipStream_t s = (hipStream_t)stream;
     RasterOut ro;
-    int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width,
-                             height, nullptr, 0, nullptr, &ro);
+    int rc = settle_pending_count(ctx);
+    if (rc) return rc;
+    rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height,
+                         nullptr, 0, nullptr, false, &ro);
     if (rc) return rc;
     GET(SLOT_LAST, int32_t, (int64_t)C * height * width, last);
     rc = st3r_blend_fwd_impl(ctx, s, C, width, height, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat,
-                             ro.n_isects, rgb, alpha, last, false);
+                             ro.n_isects, rgb, alpha, last, false, true);
     if (rc) return rc;
     if (stats_host) {
         stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = 0;

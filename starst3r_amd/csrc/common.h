@@ -68,6 +68,7 @@ enum ArenaSlot {
     SLOT_REG_PART,
     SLOT_RECTS,
     SLOT_RECTS_D,
+    SLOT_COUNTS,
     SLOT_COUNT
 };
 
@@ -96,6 +97,12 @@ struct st3r_ctx {
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
     int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
+    // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back
+    // still in flight (event), and the capacity the in-flight step was given
+    int64_t isect_hint, count_cap;
+    int64_t hint_sig;   // (N, C, W, H) the hint belongs to: another workload takes the synchronous path
+    int count_pending;
+    hipEvent_t count_event;
     void* comm;     // ncclComm_t of the view-sharded job (NULL: single replica)
     int comm_owned, comm_rank, comm_size;
     int prof_enabled;

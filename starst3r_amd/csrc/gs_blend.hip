@@ -103,7 +103,8 @@ __device__ __forceinline__ TileGeom tile_geom(int C, int W, int H, int tile_w, i
     g.inside = (g.i < H) && (g.j < W);
     g.px = (float)g.j + 0.5f; g.py = (float)g.i + 0.5f;
     g.start = offsets[g.lb];
-    g.end = (g.lb == total - 1) ? n_isects : offsets[g.lb + 1];
+    // n_isects < 0: the offsets array carries one more entry, the total (fused path: the count lives on the device)
+    g.end = (g.lb == total - 1 && n_isects >= 0) ? n_isects : offsets[g.lb + 1];
     return g;
 }
 
@@ -254,7 +255,7 @@ static int hand_off_buffers(st3r_ctx* ctx, int C, int tile_w, int tile_h, int64_
 
 int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
-                        float* rgb, float* alpha, int32_t* last_ids, bool for_backward) {
+                        float* rgb, float* alpha, int32_t* last_ids, bool for_backward, bool end_in_offsets) {
     const int total = C * tile_w * tile_h;
     uint64_t* cmask = nullptr; int64_t words = 0; int32_t* tile_nb = nullptr;
     if (for_backward) {
@@ -262,7 +263,8 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_blend_fwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, (int)n_isects, rgb, alpha, last_ids, cmask, words, tile_nb, ctx->debug_flags & 1);
+                       offsets, flat, end_in_offsets ? -1 : (int)n_isects, rgb, alpha, last_ids, cmask, words, tile_nb,
+                       ctx->debug_flags & 1);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -276,7 +278,7 @@ ST3R_EXPORT int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width,
     ARG_CHECK(splats && offsets && rgb && alpha && last_ids && n_isects >= 0 && n_isects < 2147483647LL);
     ARG_CHECK(n_isects == 0 || flatten_ids);
     return st3r_blend_fwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
-                               flatten_ids, n_isects, rgb, alpha, last_ids, true);
+                               flatten_ids, n_isects, rgb, alpha, last_ids, true, false);
 }
 
 // ------------------------------------------------------------------------------------
@@ -582,7 +584,8 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats) {
+                        const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats,
+                        bool end_in_offsets) {
     if (n_isects == 0) {
         HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
         return ST3R_OK;
@@ -608,12 +611,12 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     const int total = C * tile_w * tile_h;
     if (v_alpha)
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
-                           (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask,
-                           words, tile_nb, cum, rects, tight, vtile, vstamp, stamp);
+                           (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
+                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, vstamp, stamp);
     else
         hipLaunchKernelGGL(k_blend_bwd<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
-                           (const float4*)splats, offsets, flat, (int)n_isects, alpha, last_ids, v_rgb, v_alpha, cmask,
-                           words, tile_nb, cum, rects, tight, vtile, vstamp, stamp);
+                           (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
+                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, vstamp, stamp);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, vstamp, stamp,
                        (float4*)v_splats);
@@ -632,5 +635,5 @@ ST3R_EXPORT int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width,
     ARG_CHECK(n_isects >= 0 && n_isects < 2147483647LL && (n_isects == 0 || flatten_ids));
     return st3r_blend_bwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
                                flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, cum_tiles, nullptr, 0, n_pairs,
-                               v_splats);
+                               v_splats, false);
 }

@@ -278,8 +278,16 @@ ST3R_EXPORT int st3r_gs_offsets(st3r_ctx* ctx, void* stream, int64_t n_isects, c
 // ------------------------------------------------------------------------------------
 // offsets[k] = first sorted position whose 32-bit (camera, tile) key is >= k
 __global__ __launch_bounds__(256) void k_isect_offsets32(int64_t n_isects, const uint32_t* __restrict__ keys,
-                                                         int64_t total, int32_t* __restrict__ offsets) {
+                                                         int64_t total, int32_t* __restrict__ offsets,
+                                                         const int32_t* __restrict__ n_dev) {
+    // n_dev: the record count lives on the device (n_isects is then the launch capacity); offsets has total + 1
+    // entries, the last one = the record count (end of the last tile for the blend kernels)
+    if (n_dev) n_isects = min(n_isects, (int64_t)max(*n_dev, 0));
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_isects == 0) {
+        for (int64_t i = idx; i <= total; i += (int64_t)gridDim.x * blockDim.x) offsets[i] = 0;
+        return;
+    }
     if (idx >= n_isects) return;
     const int64_t id_curr = keys[idx];
     if (idx == 0) {
@@ -290,18 +298,19 @@ __global__ __launch_bounds__(256) void k_isect_offsets32(int64_t n_isects, const
             for (int64_t i = id_prev + 1; i <= id_curr; ++i) offsets[i] = (int32_t)idx;
     }
     if (idx == n_isects - 1)
-        for (int64_t i = id_curr + 1; i < total; ++i) offsets[i] = (int32_t)n_isects;
+        for (int64_t i = id_curr + 1; i <= total; ++i) offsets[i] = (int32_t)n_isects;
 }
 
+// offsets: [C*tiles + 1] (one more than gsplat's table: the total closes the last tile)
 int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
-                              int32_t* offsets) {
+                              int32_t* offsets, const int32_t* n_dev) {
     const int64_t total = (int64_t)C * tile_w * tile_h;
-    if (n_isects == 0) {
-        HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)total, s));
+    if (n_isects == 0 && !n_dev) {
+        HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int32_t) * (size_t)(total + 1), s));
         return ST3R_OK;
     }
-    hipLaunchKernelGGL(k_isect_offsets32, dim3(ceil_div(n_isects, 256)), dim3(256), 0, s, n_isects, keys, total,
-                       offsets);
+    hipLaunchKernelGGL(k_isect_offsets32, dim3(ceil_div(n_isects > 0 ? n_isects : 1, 256)), dim3(256), 0, s, n_isects,
+                       keys, total, offsets, n_dev);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -364,7 +373,10 @@ __global__ __launch_bounds__(256) void k_isect_emit_rects(int N, int64_t n_pairs
                                                           const int32_t* __restrict__ cum_sorted,
                                                           const uint64_t* __restrict__ rects_sorted, int tile_w,
                                                           int tile_h, uint32_t* __restrict__ tile_keys,
-                                                          int32_t* __restrict__ vals) {
+                                                          int32_t* __restrict__ vals, int64_t cap) {
+    // cap: capacity of tile_keys / vals.  With the record count on the device the buffers are sized from the previous
+    // step's count; records past the capacity are dropped here (the host notices the overflow when it reads the count
+    // back before the next step and fails loudly) -- never written out of bounds
     __shared__ uint32_t sk[EMIT_CAP];
     __shared__ int32_t sv[EMIT_CAP];
     const int64_t first = (int64_t)blockIdx.x * blockDim.x;
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(256) void k_isect_emit_rects(int N, int64_t n_pairs
                 for (int tx = x0; tx < x0 + w; ++tx) {
                     const uint32_t key = cam_base + (uint32_t)(ty * tile_w + tx);
                     if (staged) { sk[cur - base] = key; sv[cur - base] = pid; }
-                    else { tile_keys[cur] = key; vals[cur] = pid; }
+                    else if (cur < cap) { tile_keys[cur] = key; vals[cur] = pid; }
                     ++cur;
                 }
         }
@@ -393,18 +405,17 @@ __global__ __launch_bounds__(256) void k_isect_emit_rects(int N, int64_t n_pairs
     if (!staged) return;   // uniform over the block
     __syncthreads();
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        tile_keys[base + i] = sk[i];
-        vals[base + i] = sv[i];
+        if (base + i < cap) { tile_keys[base + i] = sk[i]; vals[base + i] = sv[i]; }
     }
 }
 
 int st3r_isect_emit_rects_impl(hipStream_t s, int N, int C, const int32_t* perm, const int32_t* cum_sorted,
                                const uint64_t* rects_sorted, int tile_w, int tile_h, uint32_t* tile_keys,
-                               int32_t* vals) {
+                               int32_t* vals, int64_t cap) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
     hipLaunchKernelGGL(k_isect_emit_rects, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs, perm, cum_sorted,
-                       rects_sorted, tile_w, tile_h, tile_keys, vals);
+                       rects_sorted, tile_w, tile_h, tile_keys, vals, cap);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

@@ -28,7 +28,8 @@ int st3r_sort_depth32_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit,
 
 // 32-bit (camera, tile) keys, stable: keeps the depth order established by the first level
 int st3r_sort_tile_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
-                        uint32_t* keys_out, int32_t* vals_out) {
+                        uint32_t* keys_out, int32_t* vals_out, const int32_t* n_dev) {
+    if (n_dev) return st3r_radix_sort_u32_devcount(ctx, s, n, n_dev, 0, end_bit, keys_in, vals_in, keys_out, vals_out);
     return st3r_radix_sort_u32(ctx, s, n, 0, end_bit, keys_in, vals_in, keys_out, vals_out);
 }
 

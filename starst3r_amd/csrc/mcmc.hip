@@ -18,7 +18,7 @@
 // bit for bit.
 #include "common.h"
 
-#include <rocprim/rocprim.hpp>
+#include "scan.h"
 
 #define MCMC_NMAX 51
 #define STREAM_RELOCATE 0u
@@ -229,15 +229,14 @@ static int mcmc_scratch(st3r_ctx* ctx, hipStream_t s, int64_t N, int64_t n_rows,
 }
 
 static int scan_weights(st3r_ctx* ctx, hipStream_t s, int64_t N, McmcScratch& sc, bool with_rank) {
-    size_t b1 = 0, b2 = 0;
-    HIP_TRY(rocprim::inclusive_scan(nullptr, b1, sc.cum, sc.cum, (size_t)N, rocprim::plus<uint64_t>(), s));
-    HIP_TRY(rocprim::exclusive_scan(nullptr, b2, sc.dead, sc.rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), s));
+    // inclusive 64-bit prefix sums of the fixed-point weights (in place) and, for the relocation, the exclusive
+    // ranks of the dead Gaussians: hand-written three-phase scans (scan.h)
     void* tmp;
-    int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, b1 > b2 ? b1 : b2, &tmp);
+    int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, st3r_scan::scratch_bytes<uint64_t>(N), &tmp);
     if (rc) return rc;
-    HIP_TRY(rocprim::inclusive_scan(tmp, b1, sc.cum, sc.cum, (size_t)N, rocprim::plus<uint64_t>(), s));
-    if (with_rank)
-        HIP_TRY(rocprim::exclusive_scan(tmp, b2, sc.dead, sc.rank, 0u, (size_t)N, rocprim::plus<uint32_t>(), s));
+    st3r_scan::scan<uint64_t, false>(s, sc.cum, sc.cum, N, tmp);
+    if (with_rank) st3r_scan::scan<uint32_t, true>(s, sc.dead, sc.rank, N, tmp);
+    LAUNCH_CHECK();
     return ST3R_OK;
 }
 

@@ -13,3 +13,7 @@ int st3r_radix_sort_u32(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, 
                         const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out);
 int st3r_radix_sort_u64(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint64_t* keys_in,
                         const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out);
+// item count in device memory (see radix_sort.hip)
+int st3r_radix_sort_u32_devcount(st3r_ctx* ctx, hipStream_t s, int64_t n_cap, const int32_t* n_dev, int begin_bit,
+                                 int end_bit, const uint32_t* keys_in, const int32_t* vals_in, uint32_t* keys_out,
+                                 int32_t* vals_out);

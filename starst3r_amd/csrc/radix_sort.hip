@@ -47,8 +47,10 @@ __device__ __forceinline__ int wave_incl_scan_u32(uint32_t v, int lane) {
 
 template <typename K>
 __global__ __launch_bounds__(HIST_THREADS) void k_rs_hist(const K* __restrict__ keys, int64_t n, int begin_bit,
-                                                          int end_bit, int passes, uint32_t* __restrict__ hist) {
+                                                          int end_bit, int passes, uint32_t* __restrict__ hist,
+                                                          const int32_t* __restrict__ n_dev) {
     __shared__ uint32_t sh[MAX_PASSES * RADIX];
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));   // the item count lives on the device; `n` is the launch capacity
     for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS) sh[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -100,7 +102,9 @@ template <typename K>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, const int32_t* __restrict__ vin,
                                                      K* __restrict__ kout, int32_t* __restrict__ vout, int64_t n,
                                                      int shift, int bits, const uint32_t* __restrict__ hist_base,
-                                                     u64* status, uint32_t* tile_counter) {
+                                                     u64* status, uint32_t* tile_counter,
+                                                     const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));   // count on the device, grid sized for the capacity `n`
     constexpr int IPT = Traits<K>::IPT;
     constexpr int TILE = THREADS * IPT;
     __shared__ K sbuf[TILE];
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
+    if ((int64_t)tile * TILE >= n) return;   // (capacity launch) a ticket past the last tile: uniform over the workgroup
     const int64_t tbase = (int64_t)tile * TILE;
     const int tcount = (int)min((int64_t)TILE, n - tbase);
     const uint32_t dmask = (1u << bits) - 1u;
@@ -236,7 +241,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 template <typename K>
 int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const K* keys_in,
-               const int32_t* vals_in, K* keys_out, int32_t* vals_out) {
+               const int32_t* vals_in, K* keys_out, int32_t* vals_out, const int32_t* n_dev = nullptr) {
     if (n == 0) return ST3R_OK;
     if (end_bit > (int)sizeof(K) * 8) end_bit = (int)sizeof(K) * 8;
     if (begin_bit < 0 || begin_bit >= end_bit) { st3r_set_error("radix sort: empty bit range"); return ST3R_ERR_INVALID; }
@@ -261,7 +266,7 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
     HIP_TRY(hipMemsetAsync(base, 0, meta_bytes, s));
     const int hist_blocks = (int)min((int64_t)1024, (n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
     hipLaunchKernelGGL(k_rs_hist<K>, dim3(hist_blocks), dim3(HIST_THREADS), 0, s, keys_in, n, begin_bit, end_bit, passes,
-                       hist);
+                       hist, n_dev);
     hipLaunchKernelGGL(k_rs_scan_hist, dim3(1), dim3(RADIX), 0, s, hist, passes);
     const K* kin = keys_in;
     const int32_t* vin = vals_in;
@@ -273,7 +278,7 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
         const int shift = begin_bit + RB * ps;
         const int bits = min(RB, end_bit - shift);
         hipLaunchKernelGGL(k_rs_pass<K>, dim3((unsigned)ntiles), dim3(THREADS), 0, s, kin, vin, ko, vin ? vo : nullptr, n,
-                           shift, bits, hist + ps * RADIX, status + (size_t)ps * ntiles * RADIX, counters + ps);
+                           shift, bits, hist + ps * RADIX, status + (size_t)ps * ntiles * RADIX, counters + ps, n_dev);
         kin = ko;
         if (vin) vin = vo;
     }
@@ -291,4 +296,12 @@ int st3r_radix_sort_u32(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, 
 int st3r_radix_sort_u64(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint64_t* keys_in,
                         const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out) {
     return sort_pairs<uint64_t>(ctx, s, n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out);
+}
+
+// the same with the item count in device memory: `n_cap` sizes scratch and grids, the kernels sort the first
+// min(*n_dev, n_cap) items (no host round trip between the kernel that counts the items and the sort)
+int st3r_radix_sort_u32_devcount(st3r_ctx* ctx, hipStream_t s, int64_t n_cap, const int32_t* n_dev, int begin_bit,
+                                 int end_bit, const uint32_t* keys_in, const int32_t* vals_in, uint32_t* keys_out,
+                                 int32_t* vals_out) {
+    return sort_pairs<uint32_t>(ctx, s, n_cap, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, n_dev);
 }

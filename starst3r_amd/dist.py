@@ -123,9 +123,10 @@ def _all_to_all(recv, send):
         recv.copy_(send)
 
 
-def records_to_view_owners(records_local, world, a2a=_all_to_all, recv=None):
+def records_to_view_owners(records_local, world, a2a=_all_to_all, recv=None, out=None):
     """records_local [V, n, K] (own Gaussians, all V = world*C views) -> [C, world*n, K]: all Gaussians (global order)
-    for the C views this rank owns.  Chunk r of the send buffer = views of rank r.  recv: optional receive buffer."""
+    for the C views this rank owns.  Chunk r of the send buffer = views of rank r.  recv / out: optional receive
+    buffer and (for C > 1) the buffer the view-major result is written to -- with both given nothing is allocated."""
     V, n, K = records_local.shape
     C = V // world
     send = records_local.reshape(world, C, n, K)
@@ -133,15 +134,26 @@ def records_to_view_owners(records_local, world, a2a=_all_to_all, recv=None):
     a2a(recv.reshape(-1), send.reshape(-1))
     if C == 1:
         return recv.reshape(1, world * n, K)
-    return recv.permute(1, 0, 2, 3).reshape(C, world * n, K).contiguous()
+    if out is None:
+        out = torch.empty((C, world * n, K), dtype=recv.dtype, device=recv.device)
+    out.reshape(C, world, n, K).copy_(recv.permute(1, 0, 2, 3))
+    return out.reshape(C, world * n, K)
 
 
-def records_to_gaussian_owners(v_records, world, a2a=_all_to_all, recv=None):
-    """v_records [C, world*n, K] (own views, all Gaussians) -> [V, n, K]: all views for the own Gaussians."""
+def records_to_gaussian_owners(v_records, world, a2a=_all_to_all, recv=None, send_buf=None):
+    """v_records [C, world*n, K] (own views, all Gaussians) -> [V, n, K]: all views for the own Gaussians.
+    recv / send_buf: optional preallocated buffers (send_buf only matters for C > 1)."""
     C, N, K = v_records.shape
     n = N // world
     send = v_records.reshape(C, world, n, K)
-    send = send.reshape(world, n, K) if C == 1 else send.permute(1, 0, 2, 3).contiguous()   # [dest rank, C, n, K]
+    if C == 1:
+        send = send.reshape(world, n, K)
+    else:                                                                                  # [dest rank, C, n, K]
+        if send_buf is None:
+            send_buf = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)
+        send_buf = send_buf.reshape(world, C, n, K)
+        send_buf.copy_(send.permute(1, 0, 2, 3))
+        send = send_buf
     if recv is None:
         recv = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)
     recv = recv.reshape(world, C, n, K)                                                    # [source = view owner, C, n, K]
@@ -174,6 +186,9 @@ class ShardedTrainer:
         self.tiles = torch.empty((self.V * self.n,), dtype=torch.int32, device=dev)
         self.recv_fwd = torch.empty((self.C * n_total, 12), device=dev)
         self.recv_bwd = torch.empty((self.V * self.n, 12), device=dev)
+        # view-major / rank-major copies of the exchanged records (only needed with several views per rank)
+        self.mine_buf = torch.empty((self.C * n_total, 12), device=dev) if self.C > 1 else None
+        self.send_bwd = torch.empty((self.C * n_total, 12), device=dev) if self.C > 1 else None
         self.reg = torch.zeros(4, dtype=torch.float64, device=dev)
         self.kreg = torch.tensor([self.V * opac_fac / n_total, self.V * scale_fac / (3 * n_total)], dtype=torch.float64,
                                  device=dev)
@@ -185,11 +200,12 @@ class ShardedTrainer:
         self.reg.zero_()
         rec, _ = ops.project_sh(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
                                 self.Ks, self.campos, self.W, self.H, reg_sums=self.reg, out=(self.rec, self.tiles))
-        mine = records_to_view_owners(rec.reshape(self.V, self.n, 12), self.world, self.a2a, recv=self.recv_fwd)
+        mine = records_to_view_owners(rec.reshape(self.V, self.n, 12), self.world, self.a2a, recv=self.recv_fwd,
+                                      out=self.mine_buf)
         st = ops.raster_train(self.ctx, mine.reshape(-1, 12), self.N, self.C, self.gt, self.W, self.H, self.ssim_fac,
                               self.v_records, loss_out)
         back = records_to_gaussian_owners(self.v_records.reshape(self.C, self.N, 12), self.world, self.a2a,
-                                          recv=self.recv_bwd)
+                                          recv=self.recv_bwd, send_buf=self.send_bwd)
         frac = self.n / self.N    # the regularisers are means over ALL N Gaussians (starster/gs.py:132,134)
         ops.project_sh_bwd(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
                            self.Ks, self.campos, self.W, self.H, rec, back.reshape(-1, 12), reg_views=float(self.V),

@@ -279,10 +279,10 @@ def run_3dgs_optim(
         if fused:   # the whole iteration is one C call (gradient all-reduce inside, over the ctx's communicator)
             ops.train_step(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
                            loss_scale_fac, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step,
-                           losses[step:step + 1])
+                           losses[step:step + 1], want_stats=False)   # no host round trip in steady state
         else:       # gradient all-reduce through the host framework's process group (torch.distributed -> RCCL)
             ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
-                              loss_scale_fac, st.grads, losses[step:step + 1])
+                              loss_scale_fac, st.grads, losses[step:step + 1], want_stats=False)
             _dist.all_reduce_sum(st.grads)
             ops.adam_step(ctx, P, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step)
         if enable_pruning:

@@ -208,28 +208,36 @@ def adam_step(ctx, params, grads, m, v, lr, b1, b2, eps, step):
                                          _p(grads), _p(m), _p(v), lr, b1, b2, eps, step))
 
 
-def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fac, scale_fac, grads, loss_out):
+def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fac, scale_fac, grads, loss_out,
+                  want_stats=True):
+    """want_stats=False: see train_step."""
     N, Cn = params["means"].shape[0], viewmats.shape[0]
     sh = params["shN"]
-    stats = (C.c_int64 * 4)()
+    stats = (C.c_int64 * 4)() if want_stats else None
     _lib.check(_lib.lib().st3r_gs_train_fwd_bwd(
         ctx.handle, _stream(), N, Cn, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
         _p(params["opacities"]), _p(sh), sh_stride_of(sh), _p(viewmats), _p(Ks), _p(campos), _p(gt), W, H, ssim_fac,
         opac_fac, scale_fac, _p(grads), _p(loss_out), stats))
+    if not want_stats:
+        return None
     return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
 
 
 def train_step(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fac, scale_fac, grads, m, v, lr, b1, b2, eps,
-               step, loss_out):
+               step, loss_out, want_stats=True):
     """One whole iteration in one C call: fwd/bwd -> gradient all-reduce over the ctx's RCCL communicator (if
-    one is attached, see dist.attach_native_comm) -> Adam.  loss_out gets this rank's part of the loss."""
+    one is attached, see dist.attach_native_comm) -> Adam.  loss_out gets this rank's part of the loss.
+    want_stats=False: no statistics come back and the call does not synchronise with the device in steady state (the
+    record count stays on the device; see st3r_gs_train_fwd_bwd in include/st3r.h)."""
     N, Cn = params["means"].shape[0], viewmats.shape[0]
     sh = params["shN"]
-    stats = (C.c_int64 * 4)()
+    stats = (C.c_int64 * 4)() if want_stats else None
     _lib.check(_lib.lib().st3r_gs_train_step(
         ctx.handle, _stream(), N, Cn, _p(params["means"]), _p(params["quats"]), _p(params["scales"]),
         _p(params["opacities"]), _p(sh), sh_stride_of(sh), _p(viewmats), _p(Ks), _p(campos), _p(gt), W, H, ssim_fac,
         opac_fac, scale_fac, _p(grads), _p(m), _p(v), lr, b1, b2, eps, step, _p(loss_out), stats))
+    if not want_stats:
+        return None
     return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
 
 

@@ -220,7 +220,8 @@ def _mock_ops(monkey_ops, g_keys=("means", "quats", "scales", "opacities", "shN"
     """replace the two C calls of the non-fused branch of run_3dgs_optim by the oracle"""
     calls = dict(fwd_bwd=0, adam=0)
 
-    def train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W_, H_, ssim_fac, opac_fac, scale_fac, grads, loss_out):
+    def train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W_, H_, ssim_fac, opac_fac, scale_fac, grads, loss_out,
+                      want_stats=True):
         calls["fwd_bwd"] += 1
         g = {k: P[k].numpy() for k in g_keys}
         C = w2c.shape[0]
@@ -240,7 +241,7 @@ def _mock_ops(monkey_ops, g_keys=("means", "quats", "scales", "opacities", "shN"
         go.adam(p, grads[off:off + n].numpy(), mm, vv, lr, b1, b2, eps, step)
         P["shN"][:, :4] = torch.from_numpy(p.reshape(N, 4, 3))
     def train_step(ctx, P, w2c, Ks, campos, gt, W_, H_, ssim_fac, opac_fac, scale_fac, grads, m, v, lr, b1, b2, eps,
-                   step, loss_out):     # the fused single-process call: the same two pieces, no exchange in between
+                   step, loss_out, want_stats=True):   # the fused single-process call: the same two pieces, no exchange
         st = train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W_, H_, ssim_fac, opac_fac, scale_fac, grads, loss_out)
         adam_step(ctx, P, grads, m, v, lr, b1, b2, eps, step)
         return st

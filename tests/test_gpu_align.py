@@ -174,3 +174,23 @@ def test_reference_signature_optimiser_equals_flat_path_and_warm_starts():
         for v in range(4):
             assert torch.equal(p6[k][v].reshape(-1).cpu(), params[k][v].reshape(-1).cpu()), (k, v)
     assert not torch.equal(p6["core_depth"][4].cpu(), params["core_depth"][3].cpu())
+
+
+def test_alignment_is_bit_reproducible():
+    """No float atomics on path B (per-wave LDS accumulators, per-workgroup partials added in order, fixed-order
+    chain sums): two runs of the full 500+200 schedule agree bit for bit -- gauge directions included, where the
+    reference's own trajectory is rounding noise -- and so does a 200-view problem that takes the large-LDS path."""
+    from starst3r_amd import synth_align
+    z, flat = load("align_c4_badpair")
+    a_res, a_par = run_hip(flat, niter1=500, niter2=200)
+    b_res, b_par = run_hip(flat, niter1=500, niter2=200)
+    for k in ("intrinsics", "cam2w", "depthmaps", "pts3d", "losses"):
+        assert np.array_equal(a_res[k].view(np.uint32), b_res[k].view(np.uint32)), k
+    for k in ("pps", "log_focals", "quats", "trans", "log_sizes"):
+        assert np.array_equal(a_par[k].view(np.uint32), b_par[k].view(np.uint32)), k
+    big = synth_align.flatten(synth_align.make_problem(n_views=200, n_corr=60, seed=4))
+    r1, _ = run_hip(big, niter1=20, niter2=10)
+    r2, _ = run_hip(big, niter1=20, niter2=10)
+    assert np.isfinite(r1["losses"]).all() and np.isfinite(r1["cam2w"]).all()
+    assert np.array_equal(r1["cam2w"].view(np.uint32), r2["cam2w"].view(np.uint32))
+    assert np.array_equal(r1["losses"].view(np.uint32), r2["losses"].view(np.uint32))

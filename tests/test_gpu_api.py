@@ -62,3 +62,56 @@ def test_autograd_through_render_matches_oracle():
         assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 1e-9, k
     a = scene.gaussians["shN"].grad.cpu().numpy()
     assert np.abs(a[:, :4] - ref["sh"]).max() <= 1e-3 * np.abs(ref["sh"]).max() and np.abs(a[:, 4:]).max() == 0
+
+
+def test_async_steps_equal_synchronous_steps_and_overflow_is_loud():
+    """st3r_gs_train_fwd_bwd without stats_host keeps the record count on the device (no host synchronisation in
+    steady state): gradients and losses of such steps are bit-identical to those of synchronous steps on the same
+    inputs; a step that outgrows the capacity derived from the previous count makes the NEXT call fail with
+    ST3R_ERR_CAPACITY, after which the context recovers on the synchronous path."""
+    import numpy as np
+    from starst3r_amd import _lib, ops, synth
+    ctx = ops.Context("cuda:0")     # a private context: the record-count hint is per context
+    N, V, W, H = 20000, 3, 320, 240
+    g, w2c, Ks = synth.make_scene(N, V, W, H, seed=5, scale_lo=0.004, scale_hi=0.03)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda:0")
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    P0 = {k: dev(v) for k, v in g.items()}
+    rgb, _, _ = ops.render(ctx, P0, vm, K, campos, W, H)
+    gt = torch.clamp(rgb + 0.05 * torch.randn_like(rgb), 0, 1).contiguous()
+
+    def run(want_stats, steps=6):
+        P = {k: v.clone() for k, v in P0.items()}
+        grads = torch.empty(23 * N, device="cuda:0"); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+        losses = torch.zeros(steps, device="cuda:0")
+        snaps = []
+        for it in range(steps):
+            ops.train_step(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1,
+                           losses[it:it + 1], want_stats=want_stats or it == 0)   # the first step establishes the hint
+            snaps.append(grads.clone())
+        torch.cuda.synchronize()
+        return P, snaps, losses
+    Ps, gs_sync, ls = run(True)
+    Pa, gs_async, la = run(False)
+    for a, b in zip(gs_sync, gs_async):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert torch.equal(ls, la)
+    for k in Ps:
+        assert torch.equal(Ps[k], Pa[k]), k
+    # overflow: the test hook halves the capacity of the asynchronous steps
+    P = {k: v.clone() for k, v in P0.items()}
+    grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+    ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)                     # sync: hint
+    ops.set_debug(ctx, 8)
+    ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss, want_stats=False)   # overflows quietly
+    ops.set_debug(ctx, 0)
+    with pytest.raises(_lib.St3rError) as e:
+        ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss, want_stats=False)
+    assert "more than" in str(e.value)
+    ref = torch.empty_like(grads)
+    ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, ref, loss, want_stats=False)     # recovered (sync)
+    ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss, want_stats=False)   # async again
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int32), grads.view(torch.int32)) and torch.equal(ref.view(torch.int32), gs_sync[0].view(torch.int32))
+    ctx.close()
