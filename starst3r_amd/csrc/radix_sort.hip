@@ -49,36 +49,38 @@ template <typename K>
 __global__ __launch_bounds__(HIST_THREADS) void k_rs_hist(const K* __restrict__ keys, int64_t n, int begin_bit,
                                                           int end_bit, int passes, uint32_t* __restrict__ hist,
                                                           const int32_t* __restrict__ n_dev) {
-    __shared__ uint32_t sh[MAX_PASSES * RADIX];
+    // one private copy of the histograms per wave: LDS atomics of different waves never meet on an address
+    __shared__ uint32_t sh[HIST_THREADS / 64][MAX_PASSES * RADIX];
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));   // the item count lives on the device; `n` is the launch capacity
-    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS) sh[i] = 0;
+    for (int i = threadIdx.x; i < (HIST_THREADS / 64) * MAX_PASSES * RADIX; i += HIST_THREADS) (&sh[0][0])[i] = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    uint32_t* mine = sh[threadIdx.x >> 6];
     constexpr int CH = HIST_THREADS * HIST_ITEMS;
     for (int64_t base = (int64_t)blockIdx.x * CH; base < n; base += (int64_t)gridDim.x * CH) {
-#pragma unroll 4
-        for (int i = 0; i < HIST_ITEMS; ++i) {
+        K k[HIST_ITEMS];
+#pragma unroll
+        for (int i = 0; i < HIST_ITEMS; ++i) {   // all loads of the chunk in flight before the first atomic
             const int64_t idx = base + i * HIST_THREADS + threadIdx.x;
-            const bool valid = idx < n;
-            const K k = valid ? keys[idx] : K(0);
-            const u64 act = __ballot(valid);
-            if (act == 0) continue;
-            for (int p = 0; p < passes; ++p) {
-                const int shift = begin_bit + RB * p;
-                const int bits = min(RB, end_bit - shift);
-                const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
-                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);   // first ACTIVE lane of the wave
-                if (__ballot(valid && d == d0) == act) {
-                    if (lane == (int)__builtin_ctzll(act)) atomicAdd(&sh[p * RADIX + d0], (uint32_t)__popcll(act));
-                } else if (valid) {
-                    atomicAdd(&sh[p * RADIX + d], 1u);
+            k[i] = idx < n ? keys[idx] : K(0);
+        }
+#pragma unroll
+        for (int i = 0; i < HIST_ITEMS; ++i) {
+            if (base + i * HIST_THREADS + threadIdx.x < n) {
+                for (int p = 0; p < passes; ++p) {
+                    const int shift = begin_bit + RB * p;
+                    const int bits = min(RB, end_bit - shift);
+                    atomicAdd(&mine[p * RADIX + ((uint32_t)(k[i] >> shift) & ((1u << bits) - 1u))], 1u);
                 }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS)
-        if (sh[i]) atomicAdd(&hist[i], sh[i]);
+    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < HIST_THREADS / 64; ++w) t += sh[w][i];
+        if (t) atomicAdd(&hist[i], t);
+    }
 }
 
 // hist[p][d] <- exclusive prefix over d (one workgroup of 256 threads)

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name).split("(")[0]
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").split("(")[0]
     return name
 
 

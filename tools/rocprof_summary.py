@@ -26,7 +26,7 @@ def rows_from_csv(path):
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name if len(name) < 70 else name[:67] + "..."
 
 
