@@ -5,9 +5,6 @@
 #pragma once
 #include "common.h"
 
-// scratch bytes needed in SLOT_SORT_TMP for n items of key size key_bytes (both ping-pong buffers included)
-size_t st3r_radix_sort_scratch_bytes(int64_t n, int key_bytes, int begin_bit, int end_bit);
-
 // keys_in/vals_in are left untouched; the result lands in keys_out/vals_out.  vals may be NULL (keys only).
 int st3r_radix_sort_u32(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint32_t* keys_in,
                         const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out);

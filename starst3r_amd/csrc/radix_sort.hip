@@ -6,7 +6,7 @@
 //   k_rs_hist        one pass over the keys: 256-bin histograms of ALL digits at once (LDS atomics; a wave whose
 //                    lanes agree on a digit -- the rule for the high digits of depth / tile keys -- adds once);
 //   k_rs_scan_hist   exclusive scan of each histogram = global base of every bin;
-//   k_rs_pass        one launch per 8-bit digit.  A workgroup (8 waves) owns a tile of 8192 (32-bit keys) or 4096
+//   k_rs_pass        one launch per 8-bit digit.  A workgroup (16 waves) owns a tile of 16384 (32-bit keys) or 8192
 //                    (64-bit keys) consecutive items.  Ranking is wave-local and stable: wave w holds items
 //                    [w*64*IPT, (w+1)*64*IPT) of the tile as IPT rows of 64 consecutive items; per row the lanes
 //                    find their equals with 8 ballots (match-any), rank = running wave count of the digit (LDS) +
@@ -23,7 +23,10 @@ namespace {
 
 constexpr int RB = 8;
 constexpr int RADIX = 1 << RB;
-constexpr int THREADS = 512;
+#ifndef RS_THREADS
+#define RS_THREADS 1024   // 512 measured 4 % slower per pass on MI355X (tools/abl3.sh)
+#endif
+constexpr int THREADS = RS_THREADS;
 constexpr int WAVES = THREADS / 64;
 constexpr int HIST_THREADS = 256;
 constexpr int HIST_ITEMS = 16;

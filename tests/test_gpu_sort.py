@@ -30,7 +30,7 @@ def _keys(rng, n, bits, mode, dtype):
     return k.astype(dtype)
 
 
-SIZES = [0, 1, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 100_003, 1_000_003]
+SIZES = [0, 1, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16383, 16384, 16385, 32769, 100_003, 1_000_003]
 
 
 @pytest.mark.parametrize("kb,bits", [(4, 32), (4, 17), (4, 16), (4, 3), (8, 49), (8, 36), (8, 64)])

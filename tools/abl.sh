@@ -5,11 +5,11 @@ set -u
 if [ "$1" = build ]; then
   shift; rm -rf build_variants; mkdir -p build_variants; i=0
   for D in "$@"; do
-    i=$((i+1)); touch starst3r_amd/csrc/gs_blend.hip starst3r_amd/csrc/loss.hip starst3r_amd/csrc/api.hip
+    i=$((i+1)); touch starst3r_amd/csrc/*.hip
     ST3R_DEFS="$D" python -m starst3r_amd.build > /dev/null 2>&1 || echo "build failed: $D"
     cp starst3r_amd/libst3r_hip.so build_variants/v$i.so; echo "$D" > build_variants/v$i.txt
   done
-  touch starst3r_amd/csrc/gs_blend.hip starst3r_amd/csrc/loss.hip starst3r_amd/csrc/api.hip; python -m starst3r_amd.build > /dev/null 2>&1
+  touch starst3r_amd/csrc/*.hip; python -m starst3r_amd.build > /dev/null 2>&1
 else
   cp starst3r_amd/libst3r_hip.so /tmp/orig.so
   for f in build_variants/v*.so; do
