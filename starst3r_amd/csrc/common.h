@@ -52,7 +52,6 @@ enum ArenaSlot {
     SLOT_CMASK,
     SLOT_TILE_NB,
     SLOT_VTILE,
-    SLOT_VSTAMP,
     SLOT_DKEYS_A,
     SLOT_DKEYS_B,
     SLOT_DVALS_A,

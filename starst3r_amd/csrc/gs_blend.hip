@@ -40,9 +40,11 @@
 //
 // Cost split of the backward at SYNTH-1M (ablations on a frozen scene, tools/abl.sh): phase 1 + 2 arithmetic
 // 1.25 ms, staging + flush 0.9 ms, gather 0.27 ms.  The non-arithmetic part is a per-workgroup chain of dependent
-// loads (id -> record, id -> slot base) behind barriers; it is neither shortened by more workgroups per CU nor by
-// denser writes (slots addressed by sorted position plus an index indirection, the stamp inside the slot, 64-byte
-// slots: all measured equal or slower).  The file is compiled without packed-fp32 code generation.
+// loads (id -> record, id -> slot base) behind barriers; it is neither shortened by more workgroups per CU, nor by
+// slots addressed by sorted position plus an index indirection, nor by spreading staging and flush over all four
+// waves with the fetches prefetched a round ahead (+5 %: the three extra waves issue the staging code too, and issue
+// slots are what the kernel is short of).  What did help (-5.6 %): a 40-byte slot with the stamp inside (9 sums + stamp,
+// five 8-byte stores) instead of 48 bytes plus a side array of stamps.  Compiled without packed-fp32 code generation.
 //
 // Arithmetic note.  sigma is evaluated as P = dx*(qa*dx + qb*dy) + qc*dy*dy with
 // (qa,qb,qc) = -log2(e) * (a/2, b, c/2) folded at staging time, so exp(-sigma) = exp2(P) is
@@ -315,7 +317,7 @@ __device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, 
     k0 = h0 + h1; k1 = h2 + h3; k2 = h4 + z1;
 }
 #define ACC_VALS 9      // S_x S_y S_o S_xx S_xy S_yy S_r S_g S_b per staged record and wave
-#define VT_STRIDE 12    // per-(record, tile) slot: 9 partial gradients (+3 pad) = 3 x 16 B; stamps live in a side array
+#define VT_STRIDE 10    // per-(record, tile) slot: 9 partial gradients + the stamp = 5 x 8 B
 #ifndef HB
 #define HB 64           // records staged per backward round (a fraction of a forward batch of 256)
 #endif
@@ -401,8 +403,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const int32_t* __restrict__ tile_nb,
                                                    const int32_t* __restrict__ cum,
                                                    const uint64_t* __restrict__ rects, int tight,
-                                                   float* __restrict__ vtile, int32_t* __restrict__ vstamp,
-                                                   int stamp) {
+                                                   float* __restrict__ vtile, int stamp) {
     // staged records, same q-form as the forward's but as three arrays (measured: the forward is faster with one
     // 48-byte record per staged index, this kernel with the split layout)
     __shared__ float4 sA[HB];   // x y opacity qa
@@ -545,40 +546,69 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             // record constants: v_sigma = -opacity g_o;  v_mean2d = v_sigma (a dx + b dy, b dx + c dy);
             // v_conic = v_sigma (dx^2 / 2, dx dy, dy^2 / 2)
             const float sx = -my_op * acc[0], sy = -my_op * acc[1];
-            float4* dst = reinterpret_cast<float4*>(vtile + (int64_t)my_u * VT_STRIDE);
-            vstamp[my_u] = stamp;
-            dst[0] = make_float4(my_ca * sx + my_cbb * sy, my_cbb * sx + my_cc * sy, acc[2], -0.5f * my_op * acc[3]);
-            dst[1] = make_float4(-my_op * acc[4], -0.5f * my_op * acc[5], acc[6], acc[7]);
-            dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+            float2* dst = reinterpret_cast<float2*>(vtile + (int64_t)my_u * VT_STRIDE);
+            dst[0] = make_float2(my_ca * sx + my_cbb * sy, my_cbb * sx + my_cc * sy);
+            dst[1] = make_float2(acc[2], -0.5f * my_op * acc[3]);
+            dst[2] = make_float2(-my_op * acc[4], -0.5f * my_op * acc[5]);
+            dst[3] = make_float2(acc[6], acc[7]);
+            dst[4] = make_float2(acc[8], __int_as_float(stamp));
         }
     }
 }
 
-// v_splats[pid] = sum over the pair's tiles of the slots stamped by this backward call, in slot order
-// (deterministic given the slots).  One thread per (camera, gaussian) pair.
+// v_splats[pid] = sum over the pair's tiles of the slots stamped by this backward call, in slot order (deterministic
+// given the slots).  A workgroup owns 256 consecutive (camera, gaussian) pairs, whose slots are one contiguous range.
+// The range is streamed through LDS 256 slots at a time with lane = slot (coalesced reads, no per-lane trip counts on
+// the HBM side; the next 256 slots are in flight while the current ones are summed); then lane = pair adds the rows
+// of its own slots in slot order.  Measured at SYNTH-1M: 0.26 ms, one thread per pair walking its slots 0.35 ms.
 __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int32_t* __restrict__ cum,
-                                                      const float* __restrict__ vtile,
-                                                      const int32_t* __restrict__ vstamp, int stamp,
+                                                      const float* __restrict__ vtile, int stamp,
                                                       float4* __restrict__ v_splats) {
-    const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pid >= n_pairs) return;
-    const int end = cum[pid];
-    const int start = pid == 0 ? 0 : cum[pid - 1];
+    constexpr int ROW = ACC_VALS;   // odd stride: rows of neighbouring slots fall into different banks
+    __shared__ int sCum[257];
+    __shared__ float sVal[256 * ROW];
+    const int tid = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * 256;
+    const int np = (int)min((int64_t)256, n_pairs - p0);
+    if (tid == 0) sCum[0] = p0 == 0 ? 0 : cum[p0 - 1];
+    sCum[tid + 1] = cum[p0 + min(tid, np - 1)];
+    __syncthreads();
+    const int s0 = sCum[0], s1 = sCum[np];
+    const int my_start = sCum[tid], my_end = tid < np ? sCum[tid + 1] : sCum[tid];
     float acc[ACC_VALS];
 #pragma unroll
     for (int k = 0; k < ACC_VALS; ++k) acc[k] = 0.f;
-    for (int u = start; u < end; ++u) {
-        if (vstamp[u] == stamp) {  // the payload is only fetched for slots written by this backward call
-            const float4* src = reinterpret_cast<const float4*>(vtile + (int64_t)u * VT_STRIDE);
-            const float4 a = src[0], b = src[1];
-            const float c = vtile[(int64_t)u * VT_STRIDE + 8];
-            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c;
+    float2 q0, q1, q2, q3, q4;
+    auto fetch = [&](int u) {
+        q0 = q1 = q2 = q3 = q4 = make_float2(0.f, 0.f);   // stamp 0 = never written
+        if (u < s1) {
+            const float2* src = reinterpret_cast<const float2*>(vtile + (int64_t)u * VT_STRIDE);
+            q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; q4 = src[4];
         }
+    };
+    fetch(s0 + tid);
+    for (int base = s0; base < s1; base += 256) {
+        const bool live = __float_as_int(q4.y) == stamp;
+        float* row = sVal + tid * ROW;
+        row[0] = live ? q0.x : 0.f; row[1] = live ? q0.y : 0.f; row[2] = live ? q1.x : 0.f;
+        row[3] = live ? q1.y : 0.f; row[4] = live ? q2.x : 0.f; row[5] = live ? q2.y : 0.f;
+        row[6] = live ? q3.x : 0.f; row[7] = live ? q3.y : 0.f; row[8] = live ? q4.x : 0.f;
+        __syncthreads();
+        fetch(base + 256 + tid);
+        const int lo = max(my_start, base) - base, hi = min(my_end, base + 256) - base;
+        for (int r = lo; r < hi; ++r) {
+            const float* src = sVal + r * ROW;
+#pragma unroll
+            for (int k = 0; k < ACC_VALS; ++k) acc[k] += src[k];
+        }
+        __syncthreads();
     }
-    v_splats[pid * 3 + 0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    v_splats[pid * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    v_splats[pid * 3 + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+    if (tid < np) {
+        const int64_t pid = p0 + tid;
+        v_splats[pid * 3 + 0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        v_splats[pid * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        v_splats[pid * 3 + 2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+    }
 }
 
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
@@ -600,25 +630,22 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * VT_STRIDE * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
     float* vtile = (float*)p;
-    rc = st3r_arena_get2(ctx, SLOT_VSTAMP, sizeof(int32_t) * (size_t)n_isects, &p, &grown);
-    if (rc) return rc;
     if (grown || ctx->bwd_stamp >= 2147483000) {
-        HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VSTAMP], s));
+        HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VTILE], s));
         ctx->bwd_stamp = 0;
     }
-    int32_t* vstamp = (int32_t*)p;
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
     if (v_alpha)
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
-                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, vstamp, stamp);
+                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, stamp);
     else
         hipLaunchKernelGGL(k_blend_bwd<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
-                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, vstamp, stamp);
+                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, stamp);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, vstamp, stamp,
+    hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp,
                        (float4*)v_splats);
     LAUNCH_CHECK();
     return ST3R_OK;
