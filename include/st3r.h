@@ -179,6 +179,11 @@ int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quat
  * memory, and the count is checked when the NEXT call into this ctx starts -- if a step ever outgrows its
  * capacity (its surplus records are dropped, never written out of bounds) that next call returns
  * ST3R_ERR_CAPACITY and the one after it falls back to the synchronous path.
+ * More than 2^31 tile intersections (the counts are int32; 5 M Gaussians x 8 views at 4K get there): the call walks
+ * its views in chunks -- each a complete rasterize -> loss -> backward whose parameter gradients add up, the loss
+ * being a sum over views -- doubling the chunk count until every chunk fits; the count sticks to the ctx and chunked
+ * calls always take the synchronous path.  Found on the asynchronous path, the overflow makes the NEXT call return
+ * ST3R_ERR_CAPACITY (that step's gradients were incomplete: repeat it) and later calls are chunked.
  * The second half is an (optional) all-reduce of `grads` by the caller, then st3r_adam_step.
  * ---------------------------------------------------------------------------------- */
 int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means, const float* quats,

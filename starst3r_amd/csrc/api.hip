@@ -204,6 +204,11 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
                         const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats,
                         bool end_in_offsets);
+int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
+                             const float* opacities, const float* sh, int sh_stride, const float* viewmats,
+                             const float* Ks, const float* campos, int width, int height, float eps2d,
+                             const float* splats, const float* v_splats, float reg_views, float opac_fac,
+                             float scale_fac, float* grads, bool accumulate);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -219,8 +224,11 @@ static int settle_pending_count(st3r_ctx* ctx) {
     const int64_t n = (int64_t)((int32_t*)(ctx->pinned + 8))[0];
     if (n < 0) {
         ctx->isect_hint = 0;
-        st3r_set_error("the previous step produced more than 2^31 tile intersections: split the views over more calls / GPUs");
-        return ST3R_ERR_INVALID;
+        ctx->view_chunks = (ctx->view_chunks > 0 ? ctx->view_chunks : 1) * 2;
+        st3r_set_error("the previous step produced more than 2^31 tile intersections: its gradients were incomplete -- "
+                       "repeat it (st3r_gs_train_fwd_bwd / st3r_gs_train_step now walk the views in %d chunks)",
+                       ctx->view_chunks);
+        return ST3R_ERR_CAPACITY;
     }
     if (n > ctx->count_cap) {
         ctx->isect_hint = 0;   // the next call takes the synchronous path and sizes its buffers exactly
@@ -336,7 +344,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
         n_isects = (int64_t)((int32_t*)ctx->pinned)[0];
         if (n_isects < 0) {   // the tile counts are summed in int32
             st3r_set_error("more than 2^31 tile intersections in one call: split the views over more calls / GPUs");
-            return ST3R_ERR_INVALID;
+            return ST3R_SPLIT_VIEWS;   // st3r_gs_train_fwd_bwd retries with the views in chunks; others report invalid
         }
         o->n_visible = reg_sums ? (int64_t)((double*)ctx->pinned)[1] : -1;
         o->n_isects_ref = reg_sums ? (int64_t)((double*)ctx->pinned)[2] : n_isects;
@@ -377,30 +385,17 @@ __global__ void k_finalize_loss(int C, const double* __restrict__ sums, const do
     }
 }
 
-ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means,
-                                      const float* quats, const float* scales, const float* opacities,
-                                      const float* sh, int sh_stride, const float* viewmats, const float* Ks,
-                                      const float* campos, const float* gt_images, int width, int height,
-                                      float ssim_fac, float opac_fac, float scale_fac, float* grads,
-                                      float* loss_out, int64_t* stats_host) {
-    ARG_CHECK(ctx && N > 0 && C > 0 && C <= ST3R_MAX_VIEWS && width > 0 && height > 0 && sh_stride >= 12);
-    ARG_CHECK((int64_t)N * C < 2147483647LL);   // pair ids, tile counts and their scans are int32
-    ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && gt_images && grads && loss_out);
-    hipStream_t s = (hipStream_t)stream;
-    const int W = width, H = height;
+// The views [c0, c0 + C) of one training call: rasterize -> loss -> backward; the parameter gradients are written
+// (accumulate = false) or added (later view chunks of the same call).
+static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats,
+                       const float* scales, const float* opacities, const float* sh, int sh_stride,
+                       const float* viewmats, const float* Ks, const float* campos, const float* gt_images, int W, int H,
+                       float ssim_fac, float opac_fac, float scale_fac, double* sums, double* reg_sums, bool allow_async,
+                       bool accumulate, float* grads, RasterOut* ro_out) {
     const int64_t n_pairs = (int64_t)N * C, n_px = (int64_t)C * H * W;
-    GET(SLOT_SMALL, double, 2 * (size_t)C + 8, small);
-    double* sums = small;              // [C,2]
-    double* reg_sums = small + 2 * C;  // [4]: sum sigmoid(o), sum exp(s), visible pairs, reference intersections
-    HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 4, s));
-    st3r_prof_next_step(ctx);
     RasterOut ro;
-    int rc = settle_pending_count(ctx);
-    if (rc) return rc;
-    // exact statistics need the count on the host: a caller that passes stats_host pays the synchronisation
-    const bool allow_async = stats_host == nullptr;
-    rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                         reg_sums, 1, nullptr, allow_async, &ro);
+    int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
+                             reg_sums, 1, nullptr, allow_async, &ro);
     if (rc) return rc;
     const bool eio = true;   // the fused path's offsets table carries the total as its last entry
     GET(SLOT_RGB, float, n_px * 3, rgb);
@@ -424,10 +419,65 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
-    rc = st3r_gs_project_sh_bwd(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
-                                H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads);
+    rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
+                                  0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, accumulate);
     st3r_prof_end(ctx, s, STG_PROJECT_BWD);
+    *ro_out = ro;
+    return rc;
+}
+
+ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means,
+                                      const float* quats, const float* scales, const float* opacities,
+                                      const float* sh, int sh_stride, const float* viewmats, const float* Ks,
+                                      const float* campos, const float* gt_images, int width, int height,
+                                      float ssim_fac, float opac_fac, float scale_fac, float* grads,
+                                      float* loss_out, int64_t* stats_host) {
+    ARG_CHECK(ctx && N > 0 && C > 0 && C <= ST3R_MAX_VIEWS && width > 0 && height > 0 && sh_stride >= 12);
+    ARG_CHECK((int64_t)N * C < 2147483647LL);   // pair ids, tile counts and their scans are int32
+    ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && gt_images && grads && loss_out);
+    hipStream_t s = (hipStream_t)stream;
+    const int W = width, H = height;
+    GET(SLOT_SMALL, double, 2 * (size_t)C + 12, small);
+    double* sums = small;              // [C,2]
+    double* reg_sums = small + 2 * C;  // [4]: sum sigmoid(o), sum exp(s), visible pairs, reference intersections
+    double* reg_scratch = reg_sums + 4;   // the same of the later view chunks (their regulariser sums are repeats)
+    st3r_prof_next_step(ctx);
+    int rc = settle_pending_count(ctx);
     if (rc) return rc;
+    // More than 2^31 tile intersections in one call (the counts are int32): the views are walked in chunks, each a
+    // complete rasterize -> loss -> backward whose parameter gradients add up (the loss is a sum over views,
+    // starster/gs.py:149-152).  The chunk count sticks to the context; debug flag 32 starts at two chunks (tests).
+    int chunks = ctx->view_chunks > 0 ? ctx->view_chunks : 1;
+    if ((ctx->debug_flags & 32) && chunks < 2) chunks = 2;
+    if (chunks > C) chunks = C;
+    int64_t st_vis = 0, st_is = 0, st_ref = 0;
+    for (;;) {
+        st_vis = st_is = st_ref = 0;
+        bool first = true;
+        for (int k = 0; k < chunks && !rc; ++k) {
+            const int c0 = (int)((int64_t)k * C / chunks), c1 = (int)((int64_t)(k + 1) * C / chunks);
+            if (c1 == c0) continue;
+            double* rs = first ? reg_sums : reg_scratch;
+            HIP_TRY(hipMemsetAsync(rs, 0, sizeof(double) * 4, s));
+            RasterOut ro;
+            // exact statistics need the count on the host: a caller that passes stats_host pays the synchronisation;
+            // chunked calls size every chunk exactly (the hint of the steady state belongs to one set of views)
+            rc = train_views(ctx, s, N, c1 - c0, means, quats, scales, opacities, sh, sh_stride, viewmats + 16 * c0,
+                             Ks + 9 * c0, campos + 3 * c0, gt_images + (int64_t)c0 * H * W * 3, W, H, ssim_fac, opac_fac,
+                             scale_fac, sums + 2 * c0, rs, stats_host == nullptr && chunks == 1, !first, grads, &ro);
+            if (!rc) { st_vis += ro.n_visible; st_is += ro.n_isects; st_ref += ro.n_isects_ref; }
+            first = false;
+        }
+        if (rc == ST3R_SPLIT_VIEWS && chunks < C) {
+            chunks = chunks * 2 < C ? chunks * 2 : C;
+            rc = ST3R_OK;
+            continue;
+        }
+        break;
+    }
+    if (rc == ST3R_SPLIT_VIEWS) rc = ST3R_ERR_INVALID;   // a single view above 2^31 (message set where it was found)
+    if (rc) return rc;
+    if (chunks > 1) ctx->view_chunks = chunks;
     const int Hi = H - 10, Wi = W - 10;
     const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
     hipLaunchKernelGGL(k_finalize_loss, dim3(1), dim3(64), 0, s, C, sums, reg_sums, 1.0 / ((double)H * W * 3),
@@ -435,8 +485,8 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
                        (double)opac_fac / N, (double)scale_fac / (3.0 * N), loss_out);
     LAUNCH_CHECK();
     if (stats_host) {
-        stats_host[0] = ro.n_visible; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx);
-        stats_host[3] = ro.n_isects_ref;   // exact: stats_host selects the synchronous path
+        stats_host[0] = st_vis; stats_host[1] = st_is; stats_host[2] = st3r_ctx_arena_bytes(ctx);
+        stats_host[3] = st_ref;   // exact: stats_host selects the synchronous path
     }
     return ST3R_OK;
 }
@@ -462,6 +512,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     if (rc) return rc;
     rc = rasterize_front(ctx, s, N, C, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, W, H,
                          nullptr, 1, records, stats_host == nullptr, &ro);
+    if (rc == ST3R_SPLIT_VIEWS) rc = ST3R_ERR_INVALID;
     if (rc) return rc;
     GET(SLOT_RGB, float, n_px * 3, rgb);
     GET(SLOT_ALPHA, float, n_px, alpha);
@@ -506,6 +557,7 @@ ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const 
     if (rc) return rc;
     rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height,
                          nullptr, 0, nullptr, false, &ro);
+    if (rc == ST3R_SPLIT_VIEWS) rc = ST3R_ERR_INVALID;
     if (rc) return rc;
     GET(SLOT_LAST, int32_t, (int64_t)C * height * width, last);
     rc = st3r_blend_fwd_impl(ctx, s, C, width, height, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat,

@@ -88,19 +88,23 @@ enum Stage {
 };
 #define PROF_RING 64
 
+#define ST3R_SPLIT_VIEWS 1000   // internal: more than 2^31 tile intersections, the caller may retry with fewer views
+
 struct st3r_ctx {
     int device;
     void* slot_ptr[SLOT_COUNT];
     size_t slot_bytes[SLOT_COUNT];
     int64_t* pinned;  // small pinned host buffer for read-backs
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
-    int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test
+    int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test; 1: backward
+                      // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back
     // still in flight (event), and the capacity the in-flight step was given
     int64_t isect_hint, count_cap;
     int64_t hint_sig;   // (N, C, W, H) the hint belongs to: another workload takes the synchronous path
     int count_pending;
+    int view_chunks;    // > 1: the training calls walk their views in this many chunks (2^31 intersections per chunk)
     hipEvent_t count_event;
     void* comm;     // ncclComm_t of the view-sharded job (NULL: single replica)
     int comm_owned, comm_rank, comm_size;

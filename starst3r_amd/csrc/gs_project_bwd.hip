@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ sh,
     int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     const float* __restrict__ campos, int W, int H, float eps2d, const float4* __restrict__ splats,
-    const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads) {
+    const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads, int accumulate) {
     extern __shared__ float cam[];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float* o = cam + c * CAM_STRIDE;
@@ -224,12 +224,36 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
     const int64_t Nl = N;
     float* gm = grads; float* gq = grads + 3 * Nl; float* gs = grads + 7 * Nl;
     float* go = grads + 10 * Nl; float* gsh = grads + 11 * Nl;
+    if (accumulate) {   // a later view chunk of the same training call: its gradients add to the earlier chunks
+        v_mean[0] += gm[3 * g]; v_mean[1] += gm[3 * g + 1]; v_mean[2] += gm[3 * g + 2];
+        vq0 += gq[4 * g]; vq1 += gq[4 * g + 1]; vq2 += gq[4 * g + 2]; vq3 += gq[4 * g + 3];
+        v_scale[0] += gs[3 * g]; v_scale[1] += gs[3 * g + 1]; v_scale[2] += gs[3 * g + 2];
+        v_opac += go[g];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v_k[i] += gsh[(int64_t)g * 12 + i];
+    }
     gm[3 * g] = v_mean[0]; gm[3 * g + 1] = v_mean[1]; gm[3 * g + 2] = v_mean[2];
     gq[4 * g] = vq0; gq[4 * g + 1] = vq1; gq[4 * g + 2] = vq2; gq[4 * g + 3] = vq3;
     gs[3 * g] = v_scale[0]; gs[3 * g + 1] = v_scale[1]; gs[3 * g + 2] = v_scale[2];
     go[g] = v_opac;
 #pragma unroll
     for (int i = 0; i < 12; ++i) gsh[(int64_t)g * 12 + i] = v_k[i];
+}
+
+int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
+                             const float* opacities, const float* sh, int sh_stride, const float* viewmats,
+                             const float* Ks, const float* campos, int width, int height, float eps2d,
+                             const float* splats, const float* v_splats, float reg_views, float opac_fac,
+                             float scale_fac, float* grads, bool accumulate) {
+    if (N == 0) return ST3R_OK;
+    float reg_o_k = reg_views * opac_fac / (float)N;
+    float reg_s_k = reg_views * scale_fac / (3.0f * (float)N);
+    size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
+    hipLaunchKernelGGL(k_project_sh_bwd, dim3(ceil_div(N, 256)), dim3(256), shmem, s, N, C, means, quats, scales,
+                       opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d, (const float4*)splats,
+                       (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+    return ST3R_OK;
 }
 
 ST3R_EXPORT int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C, const float* means,
@@ -240,14 +264,7 @@ ST3R_EXPORT int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C
                                        float opac_fac, float scale_fac, float* grads) {
     ARG_CHECK(ctx && N >= 0 && C > 0 && C <= ST3R_MAX_VIEWS && sh_stride >= 12);
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && v_splats && grads);
-    if (N == 0) return ST3R_OK;
-    hipStream_t s = (hipStream_t)stream;
-    float reg_o_k = reg_views * opac_fac / (float)N;
-    float reg_s_k = reg_views * scale_fac / (3.0f * (float)N);
-    size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
-    hipLaunchKernelGGL(k_project_sh_bwd, dim3(ceil_div(N, 256)), dim3(256), shmem, s, N, C, means, quats, scales,
-                       opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d, (const float4*)splats,
-                       (const float4*)v_splats, reg_o_k, reg_s_k, grads);
-    LAUNCH_CHECK();
-    return ST3R_OK;
+    return st3r_project_sh_bwd_impl((hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats,
+                                    Ks, campos, width, height, eps2d, splats, v_splats, reg_views, opac_fac, scale_fac,
+                                    grads, false);
 }

@@ -115,3 +115,36 @@ def test_async_steps_equal_synchronous_steps_and_overflow_is_loud():
     torch.cuda.synchronize()
     assert torch.equal(ref.view(torch.int32), grads.view(torch.int32)) and torch.equal(ref.view(torch.int32), gs_sync[0].view(torch.int32))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_view_chunks_give_the_gradients_of_the_whole_call():
+    """A call above 2^31 tile intersections walks its views in chunks (st3r_gs_train_fwd_bwd; here forced by debug
+    flag 32 on a small scene): loss, statistics and parameter gradients equal those of the one-pass call -- the loss
+    is a sum over views (starster/gs.py:149-152); the float sums of the gradients associate differently, hence a
+    tolerance -- and the chunk count sticks to the context."""
+    import numpy as np
+    from starst3r_amd import ops, synth
+    ctx = ops.Context("cuda:0")
+    N, V, W, H = 30000, 5, 320, 240
+    g, w2c, Ks = synth.make_scene(N, V, W, H, seed=11, scale_lo=0.004, scale_hi=0.03)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda:0")
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    P = {k: dev(v) for k, v in g.items()}
+    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
+    gt = torch.clamp(rgb + 0.05 * torch.randn_like(rgb), 0, 1).contiguous()
+    g1 = torch.empty(23 * N, device="cuda:0"); l1 = torch.zeros(1, device="cuda:0")
+    st1 = ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, g1, l1)
+    ops.set_debug(ctx, 32)
+    g2 = torch.full_like(g1, 7.0); l2 = torch.zeros(1, device="cuda:0")
+    st2 = ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, g2, l2)
+    ops.set_debug(ctx, 0)
+    assert st1["n_isects"] == st2["n_isects"] and st1["n_visible"] == st2["n_visible"]
+    assert float(l1) == pytest.approx(float(l2), rel=1e-6)
+    scale = g1.abs().max()
+    assert float((g1 - g2).abs().max() / scale) < 1e-6
+    # sticky: the next call of this context is chunked without the flag (and without statistics), same gradients
+    g3 = torch.empty_like(g1)
+    ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, g3, l2, want_stats=False)
+    assert torch.equal(g2, g3)
