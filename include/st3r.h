@@ -282,6 +282,10 @@ int st3r_mcmc_add(st3r_ctx* ctx, void* stream, int N, int n_new, float* means, f
                   uint32_t step);
 int st3r_mcmc_noise(st3r_ctx* ctx, void* stream, int N, float* means, const float* quats, const float* scales,
                     const float* opacities, float scaler, uint64_t seed, uint32_t step);
+/* The same for the rows [row_offset, row_offset + n) of the Gaussian set (the pointers address the first of them):
+ * the draws are keyed by the global row, so the shards of a Gaussian-sharded job perturb exactly like the whole set. */
+int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset, float* means, const float* quats,
+                         const float* scales, const float* opacities, float scaler, uint64_t seed, uint32_t step);
 
 /* ----------------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, views sharded, Gaussians and Adam state replicated; the one

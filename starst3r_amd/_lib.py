@@ -48,6 +48,7 @@ SIGNATURES = {
     "st3r_mcmc_relocate": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, u64, u32, C.POINTER(i64)],
     "st3r_mcmc_add": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, u64, u32],
     "st3r_mcmc_noise": [vp, vp, i32, vp, vp, vp, vp, f32, u64, u32],
+    "st3r_mcmc_noise_rows": [vp, vp, i32, i64, vp, vp, vp, vp, f32, u64, u32],
     "st3r_comm_unique_id": [C.c_char_p],
     "st3r_comm_init": [vp, i32, i32, C.c_char_p],
     "st3r_comm_attach": [vp, vp, i32, i32],

@@ -167,10 +167,11 @@ __global__ void k_mcmc_last_count(int N, const uint32_t* __restrict__ dead, cons
 __global__ __launch_bounds__(256) void k_mcmc_noise(int N, float* __restrict__ means, const float* __restrict__ quats,
                                                     const float* __restrict__ scales,
                                                     const float* __restrict__ opacities, float scaler, uint32_t step,
-                                                    uint64_t seed) {
+                                                    uint64_t seed, uint32_t row_offset) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
-    const U4 r = philox4x32_10((uint32_t)g, 0u, STREAM_NOISE, step, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // the draw belongs to the Gaussian's global row: a shard of the rows perturbs exactly like the whole set
+    const U4 r = philox4x32_10((uint32_t)g + row_offset, 0u, STREAM_NOISE, step, (uint32_t)seed, (uint32_t)(seed >> 32));
     const float inv24 = 1.0f / 16777216.0f;
     const float u1 = ((float)(r.x >> 8) + 0.5f) * inv24, u2 = ((float)(r.y >> 8) + 0.5f) * inv24;
     const float u3 = ((float)(r.z >> 8) + 0.5f) * inv24, u4 = ((float)(r.w >> 8) + 0.5f) * inv24;
@@ -295,13 +296,19 @@ ST3R_EXPORT int st3r_mcmc_add(st3r_ctx* ctx, void* stream, int N, int n_new, flo
     return ST3R_OK;
 }
 
+ST3R_EXPORT int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset, float* means,
+                                     const float* quats, const float* scales, const float* opacities, float scaler,
+                                     uint64_t seed, uint32_t step) {
+    ARG_CHECK(ctx && n >= 0 && row_offset >= 0 && row_offset + n <= 0xFFFFFFFFLL && means && quats && scales && opacities);
+    if (n == 0) return ST3R_OK;
+    hipLaunchKernelGGL(k_mcmc_noise, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n, means, quats, scales,
+                       opacities, scaler, step, seed, (uint32_t)row_offset);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
 ST3R_EXPORT int st3r_mcmc_noise(st3r_ctx* ctx, void* stream, int N, float* means, const float* quats,
                                 const float* scales, const float* opacities, float scaler, uint64_t seed,
                                 uint32_t step) {
-    ARG_CHECK(ctx && N >= 0 && means && quats && scales && opacities);
-    if (N == 0) return ST3R_OK;
-    hipLaunchKernelGGL(k_mcmc_noise, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, N, means, quats, scales,
-                       opacities, scaler, step, seed);
-    LAUNCH_CHECK();
-    return ST3R_OK;
+    return st3r_mcmc_noise_rows(ctx, stream, N, 0, means, quats, scales, opacities, scaler, seed, step);
 }

@@ -102,10 +102,13 @@ def detach_native_comm(ctx):
 # ----------------------------------------------------------------------------------------------------------
 
 def shard_gaussians(N, rank, world):
-    if N % world:
-        raise ValueError(f"the Gaussian-sharded mode needs N ({N}) divisible by the number of ranks ({world})")
-    n = N // world
-    return rank * n, (rank + 1) * n
+    """Rows [lo, hi) of rank `rank`: contiguous, balanced (sizes differ by at most one when world does not divide N --
+    the MCMC growth steps do not keep N divisible)."""
+    return N * rank // world, N * (rank + 1) // world
+
+
+def shard_counts(N, world):
+    return [N * (r + 1) // world - N * r // world for r in range(world)]
 
 
 def shard_views_contiguous(n_views, rank, world):
@@ -115,49 +118,84 @@ def shard_views_contiguous(n_views, rank, world):
     return list(range(rank * c, (rank + 1) * c))
 
 
-def _all_to_all(recv, send):
+def _all_to_all(recv, send, recv_splits=None, send_splits=None):
+    """all_to_all_single; the split lists (elements per peer) are None for equal chunks."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():   # also with a single rank: the same RCCL call path
-        dist.all_to_all_single(recv, send)
+        dist.all_to_all_single(recv, send, recv_splits, send_splits)
     else:
         recv.copy_(send)
 
 
-def records_to_view_owners(records_local, world, a2a=_all_to_all, recv=None, out=None):
-    """records_local [V, n, K] (own Gaussians, all V = world*C views) -> [C, world*n, K]: all Gaussians (global order)
+def records_to_view_owners(records_local, world, a2a=_all_to_all, recv=None, out=None, counts=None):
+    """records_local [V, n, K] (own Gaussians, all V = world*C views) -> [C, N, K]: all Gaussians (global order)
     for the C views this rank owns.  Chunk r of the send buffer = views of rank r.  recv / out: optional receive
-    buffer and (for C > 1) the buffer the view-major result is written to -- with both given nothing is allocated."""
+    buffer and (for C > 1) the buffer the view-major result is written to -- with both given nothing is allocated.
+    counts: Gaussians per rank when the shards are uneven (None: every rank holds n)."""
     V, n, K = records_local.shape
     C = V // world
+    even = counts is None or all(c == n for c in counts)
     send = records_local.reshape(world, C, n, K)
-    recv = torch.empty_like(send) if recv is None else recv.reshape(world, C, n, K)   # [source rank, C, n, K]
-    a2a(recv.reshape(-1), send.reshape(-1))
+    if even:
+        recv = torch.empty_like(send) if recv is None else recv.reshape(world, C, n, K)   # [source rank, C, n, K]
+        a2a(recv.reshape(-1), send.reshape(-1))
+        if C == 1:
+            return recv.reshape(1, world * n, K)
+        if out is None:
+            out = torch.empty((C, world * n, K), dtype=recv.dtype, device=recv.device)
+        out.reshape(C, world, n, K).copy_(recv.permute(1, 0, 2, 3))
+        return out.reshape(C, world * n, K)
+    N = sum(counts)
+    recv = torch.empty(C * N * K, dtype=send.dtype, device=send.device) if recv is None else recv.reshape(-1)
+    a2a(recv, send.reshape(-1), [C * c * K for c in counts], [C * n * K] * world)   # source s sends [C, n_s, K]
     if C == 1:
-        return recv.reshape(1, world * n, K)
+        return recv.reshape(1, N, K)
     if out is None:
-        out = torch.empty((C, world * n, K), dtype=recv.dtype, device=recv.device)
-    out.reshape(C, world, n, K).copy_(recv.permute(1, 0, 2, 3))
-    return out.reshape(C, world * n, K)
+        out = torch.empty((C, N, K), dtype=recv.dtype, device=recv.device)
+    out = out.reshape(C, N, K)
+    off = 0
+    for c in counts:
+        out[:, off:off + c].copy_(recv[C * off * K:C * (off + c) * K].reshape(C, c, K))
+        off += c
+    return out
 
 
-def records_to_gaussian_owners(v_records, world, a2a=_all_to_all, recv=None, send_buf=None):
-    """v_records [C, world*n, K] (own views, all Gaussians) -> [V, n, K]: all views for the own Gaussians.
-    recv / send_buf: optional preallocated buffers (send_buf only matters for C > 1)."""
+def records_to_gaussian_owners(v_records, world, a2a=_all_to_all, recv=None, send_buf=None, counts=None, rank=0):
+    """v_records [C, N, K] (own views, all Gaussians) -> [V, n, K]: all views for the own Gaussians.
+    recv / send_buf: optional preallocated buffers (send_buf only matters for C > 1).  counts / rank: uneven shards."""
     C, N, K = v_records.shape
-    n = N // world
-    send = v_records.reshape(C, world, n, K)
+    even = counts is None or all(c == counts[0] for c in counts)
+    if even:
+        n = N // world
+        send = v_records.reshape(C, world, n, K)
+        if C == 1:
+            send = send.reshape(world, n, K)
+        else:                                                                              # [dest rank, C, n, K]
+            if send_buf is None:
+                send_buf = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)
+            send_buf = send_buf.reshape(world, C, n, K)
+            send_buf.copy_(send.permute(1, 0, 2, 3))
+            send = send_buf
+        if recv is None:
+            recv = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)
+        recv = recv.reshape(world, C, n, K)                                                # [source = view owner, C, n, K]
+        a2a(recv.reshape(-1), send.reshape(-1))
+        return recv.reshape(world * C, n, K)
+    n = counts[rank]
     if C == 1:
-        send = send.reshape(world, n, K)
-    else:                                                                                  # [dest rank, C, n, K]
+        send = v_records.reshape(-1)              # the owners' row ranges are already contiguous and in rank order
+    else:
         if send_buf is None:
-            send_buf = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)
-        send_buf = send_buf.reshape(world, C, n, K)
-        send_buf.copy_(send.permute(1, 0, 2, 3))
-        send = send_buf
+            send_buf = torch.empty(C * N * K, dtype=v_records.dtype, device=v_records.device)
+        send = send_buf.reshape(-1)
+        off = 0
+        for c in counts:
+            send[C * off * K:C * (off + c) * K].reshape(C, c, K).copy_(v_records[:, off:off + c])
+            off += c
     if recv is None:
         recv = torch.empty((world, C, n, K), dtype=v_records.dtype, device=v_records.device)
-    recv = recv.reshape(world, C, n, K)                                                    # [source = view owner, C, n, K]
-    a2a(recv.reshape(-1), send.reshape(-1))
+    recv = recv.reshape(-1)[:world * C * n * K]
+    a2a(recv, send, [C * n * K] * world, [C * c * K for c in counts])
     return recv.reshape(world * C, n, K)
 
 
@@ -167,7 +205,7 @@ class ShardedTrainer:
     views this rank owns (shard_views_contiguous)."""
 
     def __init__(self, ctx, params, n_total, w2c_all, Ks_all, gt_local, W, H, rank, world, lr=1e-3,
-                 ssim_fac=0.2, opac_fac=0.01, scale_fac=0.01, a2a=_all_to_all):
+                 ssim_fac=0.2, opac_fac=0.01, scale_fac=0.01, a2a=_all_to_all, counts=None):
         from . import ops
         self.ops, self.ctx, self.P, self.N, self.W, self.H = ops, ctx, params, n_total, W, H
         self.rank, self.world, self.a2a = rank, world, a2a
@@ -176,7 +214,9 @@ class ShardedTrainer:
         self.V = self.w2c.shape[0]
         self.C = self.V // world
         self.n = params["means"].shape[0]
-        assert self.n * world == n_total and self.C * world == self.V and gt_local.shape[0] == self.C
+        self.counts = list(counts) if counts is not None else shard_counts(n_total, world)
+        assert sum(self.counts) == n_total and self.counts[rank] == self.n, "shard sizes do not add up to n_total"
+        assert self.C * world == self.V and gt_local.shape[0] == self.C
         dev = params["means"].device
         self.grads = torch.empty(23 * self.n, device=dev)
         self.m = torch.zeros_like(self.grads); self.v = torch.zeros_like(self.grads)
@@ -201,11 +241,11 @@ class ShardedTrainer:
         rec, _ = ops.project_sh(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
                                 self.Ks, self.campos, self.W, self.H, reg_sums=self.reg, out=(self.rec, self.tiles))
         mine = records_to_view_owners(rec.reshape(self.V, self.n, 12), self.world, self.a2a, recv=self.recv_fwd,
-                                      out=self.mine_buf)
+                                      out=self.mine_buf, counts=self.counts)
         st = ops.raster_train(self.ctx, mine.reshape(-1, 12), self.N, self.C, self.gt, self.W, self.H, self.ssim_fac,
                               self.v_records, loss_out)
         back = records_to_gaussian_owners(self.v_records.reshape(self.C, self.N, 12), self.world, self.a2a,
-                                          recv=self.recv_bwd, send_buf=self.send_bwd)
+                                          recv=self.recv_bwd, send_buf=self.send_bwd, counts=self.counts, rank=self.rank)
         frac = self.n / self.N    # the regularisers are means over ALL N Gaussians (starster/gs.py:132,134)
         ops.project_sh_bwd(self.ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], self.w2c,
                            self.Ks, self.campos, self.W, self.H, rec, back.reshape(-1, 12), reg_views=float(self.V),

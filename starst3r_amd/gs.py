@@ -126,28 +126,37 @@ class MCMCStrategy:
     def step_pre_backward(self, params, optimizers, state, step, info):
         return None
 
-    def step_post_backward(self, params, optimizers, state, step, info, lr):
+    def is_refine_step(self, step):
+        return self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0
+
+    def refine(self, params, optimizers, state, step, call):
+        """relocate dead Gaussians + grow by 5 % (needs every Gaussian: the full, replicated tensors)."""
         owner = optimizers["means"]._owner
+        ctx = ops.get_context(params["means"].device)
+        seed = state.get("seed", 0)
+        P = {k: params[k].data for k in GAUSSIAN_KEYS}
+        state["n_relocated"] = ops.mcmc_relocate(ctx, P, owner.m, owner.v, self.min_opacity, seed, call)
+        N = P["means"].shape[0]
+        n_new = max(0, min(self.cap_max, int(1.05 * N)) - N)
+        if n_new > 0:
+            grown = {}
+            for k in GAUSSIAN_KEYS:
+                t = torch.empty((N + n_new,) + tuple(P[k].shape[1:]), dtype=P[k].dtype, device=P[k].device)
+                t[:N].copy_(P[k])
+                grown[k] = t
+            ops.mcmc_add(ctx, grown, N, n_new, self.min_opacity, seed, call)
+            for k in GAUSSIAN_KEYS:  # new leaf tensors, as gsplat re-creates the nn.Parameters
+                params[k] = torch.nn.Parameter(grown[k], requires_grad=True)
+            owner.grow(N + n_new)
+        state["n_added"] = n_new
+
+    def step_post_backward(self, params, optimizers, state, step, info, lr):
         ctx = ops.get_context(params["means"].device)
         seed, call = state.get("seed", 0), state.get("calls", 0)
         state["calls"] = call + 1
         with torch.no_grad():
-            if self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0:
-                P = {k: params[k].data for k in GAUSSIAN_KEYS}
-                state["n_relocated"] = ops.mcmc_relocate(ctx, P, owner.m, owner.v, self.min_opacity, seed, call)
-                N = P["means"].shape[0]
-                n_new = max(0, min(self.cap_max, int(1.05 * N)) - N)
-                if n_new > 0:
-                    grown = {}
-                    for k in GAUSSIAN_KEYS:
-                        t = torch.empty((N + n_new,) + tuple(P[k].shape[1:]), dtype=P[k].dtype, device=P[k].device)
-                        t[:N].copy_(P[k])
-                        grown[k] = t
-                    ops.mcmc_add(ctx, grown, N, n_new, self.min_opacity, seed, call)
-                    for k in GAUSSIAN_KEYS:  # new leaf tensors, as gsplat re-creates the nn.Parameters
-                        params[k] = torch.nn.Parameter(grown[k], requires_grad=True)
-                    owner.grow(N + n_new)
-                state["n_added"] = n_new
+            if self.is_refine_step(step):
+                self.refine(params, optimizers, state, step, call)
             P = {k: params[k].data for k in ("means", "quats", "scales", "opacities")}
             ops.mcmc_noise(ctx, P, lr * self.noise_lr, seed, call)
 
@@ -258,7 +267,8 @@ def run_3dgs_optim(
     g = scene.gaussians
     rank, world = _dist.rank_world()
     if _sharded_layout(scene, world, enable_pruning):
-        return _run_3dgs_optim_sharded(scene, iters, loss_ssim_fac, loss_opacity_fac, loss_scale_fac, verbose)
+        return _run_3dgs_optim_sharded(scene, iters, loss_ssim_fac, loss_opacity_fac, loss_scale_fac, verbose,
+                                       enable_pruning)
     views = _dist.shard_views(len(scene.imgs), rank, world)
     w2c_all = scene.w2c.to(scene.device, torch.float32)
     w2c = w2c_all[views].contiguous()
@@ -294,62 +304,96 @@ def run_3dgs_optim(
 def _sharded_layout(scene, world, enable_pruning):
     """Gaussians AND views sharded (layout 2) is OPT-IN: ST3R_MULTI_GPU=gaussian-sharded (also with
     a single rank: tests).  The default under torch.distributed is the north_star partition -- views sharded,
-    Gaussians replicated, one gradient all-reduce per iteration -- which is also the only layout the MCMC hooks
-    (enable_pruning) run on: they need every Gaussian on every rank."""
+    Gaussians replicated, one gradient all-reduce per iteration.  With enable_pruning the sharded loop re-assembles
+    the full tensors for the refinement steps (every 100 iterations) and shards the grown set again."""
     import os
-    if os.environ.get("ST3R_MULTI_GPU", "replicated") != "gaussian-sharded" or enable_pruning:
+    if os.environ.get("ST3R_MULTI_GPU", "replicated") != "gaussian-sharded":
         return False
-    n_views, N = len(scene.imgs), scene.gaussians["means"].shape[0]
-    return n_views % world == 0 and N % world == 0
+    return len(scene.imgs) % world == 0 and scene.gaussians["means"].shape[0] >= world
 
 
-def _run_3dgs_optim_sharded(scene, iters, ssim_fac, opac_fac, scale_fac, verbose):
+def _gather_rows(full, local, counts, width):
+    """full [N * width] (rows of `width` floats, rank-ordered shards) <- every rank's local rows."""
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        if all(c == counts[0] for c in counts):
+            tdist.all_gather_into_tensor(full.reshape(-1), local.reshape(-1).clone())   # local may be a view of full
+        else:
+            parts = _dist.all_gather_varlen(local.reshape(-1).clone())
+            torch.cat([p.to(full.device) for p in parts], out=full.reshape(-1))
+    else:
+        full.reshape(-1).copy_(local.reshape(-1))
+
+
+def _run_3dgs_optim_sharded(scene, iters, ssim_fac, opac_fac, scale_fac, verbose, enable_pruning=False):
     """run_3dgs_optim on the Gaussian-sharded layout: this rank trains rows [lo, hi) of the (replicated) parameter
     tensors in place, exchanging splat records with the other ranks; at the end the shards are all-gathered so that
-    scene.gaussians and the optimiser state are complete on every rank again."""
-    import torch.distributed as tdist
+    scene.gaussians and the optimiser state are complete on every rank again.
+
+    enable_pruning: the position noise of every iteration is drawn per shard (keyed by the global row, so it equals
+    the replicated draw); on a refinement step the shards are gathered, relocate / grow run on the full tensors --
+    identically on every rank, like in the replicated layout -- and the grown set is sharded again (balanced, sizes
+    differing by at most one).  Between refinement steps nothing is replicated."""
     height, width = scene.imgs[0].shape[:2]
     ctx = ops.get_context(scene.device)
-    st, g = scene._gs_optim, scene.gaussians
+    st = scene._gs_optim
     rank, world = _dist.rank_world()
-    N = g["means"].shape[0]
-    lo, hi = _dist.shard_gaussians(N, rank, world)
-    n = hi - lo
     views = _dist.shard_views_contiguous(len(scene.imgs), rank, world)
     w2c_all = scene.w2c.to(scene.device, torch.float32).contiguous()
     Ks_all = scene.intrinsics.to(scene.device, torch.float32).contiguous()
     gt = _gt_on_device(scene, views)
     keys = ("means", "quats", "scales", "opacities", "shN")
-    P = {k: g[k].data[lo:hi] for k in keys}                    # views: the shard is updated in place
-    tr = _dist.ShardedTrainer(ctx, P, N, w2c_all, Ks_all, gt, width, height, rank, world, lr=st.lr, ssim_fac=ssim_fac,
-                              opac_fac=opac_fac, scale_fac=scale_fac)
-    off = 0
-    for _, w in ADAM_BLOCKS:                                    # this shard's rows of the [23N] moment blocks
-        tr.m[off * n:(off + w) * n].copy_(st.m[off * N + w * lo:off * N + w * hi])
-        tr.v[off * n:(off + w) * n].copy_(st.v[off * N + w * lo:off * N + w * hi])
-        off += w
-    tr.t = st.step
+
+    def shard():
+        """trainer over this rank's rows of the current full tensors (views into them: updated in place)"""
+        g = scene.gaussians
+        N = g["means"].shape[0]
+        counts = _dist.shard_counts(N, world)
+        lo, hi = _dist.shard_gaussians(N, rank, world)
+        n = hi - lo
+        P = {k: g[k].data[lo:hi] for k in keys}
+        tr = _dist.ShardedTrainer(ctx, P, N, w2c_all, Ks_all, gt, width, height, rank, world, lr=st.lr,
+                                  ssim_fac=ssim_fac, opac_fac=opac_fac, scale_fac=scale_fac, counts=counts)
+        off = 0
+        for _, w in ADAM_BLOCKS:                                    # this shard's rows of the [23N] moment blocks
+            tr.m[off * n:(off + w) * n].copy_(st.m[off * N + w * lo:off * N + w * hi])
+            tr.v[off * n:(off + w) * n].copy_(st.v[off * N + w * lo:off * N + w * hi])
+            off += w
+        tr.t = st.step
+        return tr, P, N, n, lo, counts
+
+    def unshard(tr, P, N, n, counts):
+        """every rank's rows back into the full tensors and moment blocks"""
+        g = scene.gaussians
+        st.step = tr.t
+        for k in keys:
+            _gather_rows(g[k].data, P[k], counts, g[k].data[0].numel())
+        off = 0
+        for _, w in ADAM_BLOCKS:
+            _gather_rows(st.m[off * N:(off + w) * N], tr.m[off * n:(off + w) * n], counts, w)
+            _gather_rows(st.v[off * N:(off + w) * N], tr.v[off * n:(off + w) * n], counts, w)
+            off += w
+
+    tr, P, N, n, lo, counts = shard()
     losses = torch.zeros(max(iters, 1), device=scene.device)
     it_range = range(iters)
     if verbose:
         from tqdm import trange
         it_range = trange(iters)
+    strategy, state = scene.strategy, scene.strategy_state
     for step in it_range:
         tr.step(losses[step:step + 1])
-    st.step = tr.t
-    gathered = tdist.is_available() and tdist.is_initialized()
-    def gather(full, local):
-        if gathered:
-            tdist.all_gather_into_tensor(full.reshape(-1), local.reshape(-1).clone())
-        else:
-            full.reshape(-1).copy_(local.reshape(-1))
-    for k in keys:
-        gather(g[k].data, P[k])
-    off = 0
-    for _, w in ADAM_BLOCKS:
-        gather(st.m[off * N:(off + w) * N], tr.m[off * n:(off + w) * n])
-        gather(st.v[off * N:(off + w) * N], tr.v[off * n:(off + w) * n])
-        off += w
+        if enable_pruning:   # MCMCStrategy.step_post_backward, shard-wise
+            seed, call = state.get("seed", 0), state.get("calls", 0)
+            state["calls"] = call + 1
+            with torch.no_grad():
+                if strategy.is_refine_step(step):
+                    unshard(tr, P, N, n, counts)
+                    strategy.refine(scene.gaussians, scene.optimizers, state, step, call)
+                    tr, P, N, n, lo, counts = shard()
+                ops.mcmc_noise(ctx, {k: P[k] for k in ("means", "quats", "scales", "opacities")},
+                               1e-3 * strategy.noise_lr, seed, call, row_offset=lo)
+    unshard(tr, P, N, n, counts)
     _dist.all_reduce_sum(losses)
     return losses[:iters].cpu().tolist()
 

@@ -333,10 +333,12 @@ def mcmc_add(ctx, params, N, n_new, min_opacity, seed, step):
         _p(params["opacities"]), None if sh0 is None else _p(sh0), _p(sh), sh_stride_of(sh), min_opacity, seed, step))
 
 
-def mcmc_noise(ctx, params, scaler, seed, step):
+def mcmc_noise(ctx, params, scaler, seed, step, row_offset=0):
+    """row_offset: global row of params' first Gaussian (a shard of the set draws the noise of its own rows)."""
     N = params["means"].shape[0]
-    _lib.check(_lib.lib().st3r_mcmc_noise(ctx.handle, _stream(), N, _p(params["means"]), _p(params["quats"]),
-                                          _p(params["scales"]), _p(params["opacities"]), scaler, seed, step))
+    _lib.check(_lib.lib().st3r_mcmc_noise_rows(ctx.handle, _stream(), N, int(row_offset), _p(params["means"]),
+                                               _p(params["quats"]), _p(params["scales"]), _p(params["opacities"]),
+                                               scaler, seed, step))
 
 
 def peek(ctx, which, count, dtype=torch.int32):

@@ -124,6 +124,39 @@ def test_sharded_exchanges_world2(tmp_path):
     assert [open(f"{out}.{r}").read() for r in range(2)] == ["ok", "ok"]
 
 
+def _a2a_uneven_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    V, N, K = 4, 11, 3                                  # 11 Gaussians over 2 ranks: shards of 5 and 6
+    C = V // world
+    counts = sdist.shard_counts(N, world)
+    lo, hi = sdist.shard_gaussians(N, rank, world)
+    ok = counts == [5, 6] and hi - lo == counts[rank] and (lo, hi) == ((0, 5), (5, 11))[rank]
+    n = hi - lo
+    owner = lambda g: 0 if g < counts[0] else 1
+    local = torch.stack([torch.stack([_label(rank, v, i) for i in range(n)]) for v in range(V)])     # [V, n, K]
+    mine = sdist.records_to_view_owners(local, world, counts=counts)                                   # [C, N, K]
+    ok &= mine.shape == (C, N, K)
+    for c in range(C):
+        for g in range(N):
+            r = owner(g)
+            ok &= bool(torch.equal(mine[c, g], _label(r, rank * C + c, g - (0, counts[0])[r])))
+    back = sdist.records_to_gaussian_owners(mine * 2.0, world, counts=counts, rank=rank)               # [V, n, K]
+    ok &= bool(torch.equal(back, local * 2.0))
+    with open(f"{out}.{rank}", "w") as f:
+        f.write("ok" if ok else "bad")
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_exchanges_uneven_shards_world2(tmp_path):
+    """N not divisible by the ranks (the MCMC growth steps leave such N): all_to_all_single with split sizes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = str(tmp_path / "a2au")
+    mp.spawn(_a2a_uneven_worker, args=(2, port, out), nprocs=2, join=True)
+    assert [open(f"{out}.{r}").read() for r in range(2)] == ["ok", "ok"]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Path A under torch.distributed: the pairs of the complete graph are dealt round-robin to the ranks and the new
 # cache entries all-gathered with variable lengths (starst3r_amd.forward.forward_mast3r, SURVEY 8(e) row A).

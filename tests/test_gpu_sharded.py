@@ -22,22 +22,29 @@ class A2A:
         self.world, self.box, self.bar = world, [None] * world, threading.Barrier(world)
 
     def rank_fn(self, rank):
-        def a2a(recv, send):
-            self.box[rank] = send.clone()
+        def a2a(recv, send, recv_splits=None, send_splits=None):
+            k = send.numel() // self.world
+            self.box[rank] = (send.clone(), send_splits if send_splits is not None else [k] * self.world)
             torch.cuda.synchronize()
             self.bar.wait()
-            k = send.numel() // self.world
+            off = 0
             for s in range(self.world):
-                recv[s * k:(s + 1) * k].copy_(self.box[s][rank * k:(rank + 1) * k])
+                buf, splits = self.box[s]
+                src = sum(splits[:rank])
+                cnt = splits[rank]
+                assert recv_splits is None or recv_splits[s] == cnt
+                recv[off:off + cnt].copy_(buf[src:src + cnt])
+                off += cnt
             torch.cuda.synchronize()
             self.bar.wait()
         return a2a
 
 
-@pytest.mark.parametrize("world,V", [(2, 4), (4, 4), (2, 2)])
-def test_sharded_equals_replicated(world, V):
+@pytest.mark.parametrize("world,V,N", [(2, 4, 6000), (4, 4, 6000), (2, 2, 6000), (2, 4, 6001), (4, 8, 6002)])
+def test_sharded_equals_replicated(world, V, N):
+    """N not divisible by the ranks: balanced shards whose sizes differ by one (what the MCMC growth leaves behind)."""
     from starst3r_amd import dist as sdist, ops
-    N, W, H, steps = 6000, 160, 96, 6
+    W, H, steps = 160, 96, 6
     g, w2c_np, Ks_np = synth.make_scene(N, V, W, H, seed=9, scale_lo=0.01, scale_hi=0.05)
     P0 = {k: torch.from_numpy(g[k]).to(DEV) for k in ("means", "quats", "scales", "opacities", "shN")}
     w2c = torch.from_numpy(w2c_np).to(DEV); Ks = torch.from_numpy(Ks_np).to(DEV)
@@ -59,7 +66,7 @@ def test_sharded_equals_replicated(world, V):
     torch.cuda.synchronize()
     # sharded: `world` virtual ranks
     bus = A2A(world)
-    n, C = N // world, V // world
+    counts = sdist.shard_counts(N, world)
     shards, losses, g1, errors = [None] * world, [None] * world, [None] * world, []
 
     def run(rank):
@@ -89,7 +96,7 @@ def test_sharded_equals_replicated(world, V):
     off = 0
     for name, wdt in (("means", 3), ("quats", 4), ("scales", 3), ("opacities", 1), ("sh", 12)):
         full = first_grads[off * N:(off + wdt) * N].reshape(N, wdt)
-        got = torch.cat([g1[r][off * n:(off + wdt) * n].reshape(n, wdt) for r in range(world)])
+        got = torch.cat([g1[r][off * counts[r]:(off + wdt) * counts[r]].reshape(counts[r], wdt) for r in range(world)])
         scale = float(full.abs().max())
         assert float((got - full).abs().max()) <= 2e-4 * scale + 1e-12, name
         off += wdt
@@ -166,3 +173,56 @@ def test_scene_run_3dgs_optim_sharded_layout_equals_replicated(monkeypatch):
         assert float(d.max()) <= 2.5e-3 and float((d > 1e-5).float().mean()) < 0.01, k
     dm = (mA - sc._gs_optim.m).abs()
     assert float(dm.max()) <= 1e-3 * float(mA.abs().max()) + 1e-9
+
+
+def test_noise_of_a_shard_is_the_noise_of_its_rows():
+    """st3r_mcmc_noise_rows keys the draws by the global row: perturbing rows [lo, hi) with row_offset = lo equals the
+    same rows of a whole-set call, bit for bit."""
+    from starst3r_amd import ops
+    N, lo, hi = 5000, 1234, 4321
+    g, _, _ = synth.make_scene(N, 1, 64, 64, seed=3)
+    P = {k: torch.from_numpy(g[k]).to(DEV) for k in ("means", "quats", "scales", "opacities")}
+    P["scales"] = torch.log(P["scales"]); P["opacities"] = torch.logit(P["opacities"].clamp(1e-4, 0.5))
+    ctx = ops.get_context(DEV)
+    whole = {k: v.clone() for k, v in P.items()}
+    ops.mcmc_noise(ctx, whole, 5e2, 17, 9)
+    part = {k: v[lo:hi].clone() for k, v in P.items()}
+    ops.mcmc_noise(ctx, part, 5e2, 17, 9, row_offset=lo)
+    assert not torch.equal(whole["means"], P["means"])
+    assert torch.equal(part["means"], whole["means"][lo:hi])
+
+
+def test_scene_sharded_layout_with_pruning_equals_replicated(monkeypatch):
+    """enable_pruning on the Gaussian-sharded layout (forced with one rank; refinement window pulled to the front):
+    gather -> relocate / grow on the full set -> shard again, noise per shard -- the same Gaussian count, losses and
+    parameters as the replicated loop."""
+    import starst3r_amd as st
+    from starst3r_amd.synth_model import SyntheticPairwiseModel
+    keys = ("means", "quats", "scales", "opacities", "shN")
+
+    def run(sharded):
+        model = SyntheticPairwiseModel(width=128, height=96, n_corr=300, seed=2)
+        sc = st.Scene(device="cuda:0")
+        sc.add_images(model, [torch.zeros(3, 96, 128) for _ in range(2)])
+        sc.init_3dgs()
+        sc.strategy.refine_start_iter, sc.strategy.refine_every = 1, 3
+        sc.strategy.cap_max = int(sc.gaussians["means"].shape[0] * 1.08)
+        with torch.no_grad():   # some dead Gaussians for the relocation
+            sc.gaussians["opacities"].data[::7] = -8.0
+        if sharded:
+            monkeypatch.setenv("ST3R_MULTI_GPU", "gaussian-sharded")
+        try:
+            losses = sc.run_3dgs_optim(8, enable_pruning=True)
+        finally:
+            monkeypatch.delenv("ST3R_MULTI_GPU", raising=False)
+        return sc, losses
+    a, la = run(False)
+    b, lb = run(True)
+    assert a.gaussians["means"].shape == b.gaussians["means"].shape
+    assert a.strategy_state["calls"] == b.strategy_state["calls"] == 8
+    assert a.strategy_state["n_added"] == b.strategy_state["n_added"]
+    np.testing.assert_allclose(lb, la, rtol=1e-4)
+    for k in keys:
+        d = (a.gaussians[k].data - b.gaussians[k].data).abs()
+        assert float((d > 1e-4).float().mean()) < 0.01, k
+    assert a._gs_optim.step == b._gs_optim.step == 8
