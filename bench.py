@@ -347,9 +347,19 @@ def main():
         grads = torch.empty(23 * N, device=device)
         m = torch.zeros_like(grads); v = torch.zeros_like(grads)
 
+        native_comm = True
         if world > 1:
             from starst3r_amd import dist as sdist
-            sdist.attach_native_comm(ctx)      # torch.distributed only ships the 128-byte RCCL id
+            try:
+                sdist.attach_native_comm(ctx)      # torch.distributed only ships the 128-byte RCCL id
+                ok = torch.ones(1, device=device)
+            except Exception as e:  # noqa: BLE001 -- e.g. no RCCL the library can bind: reported, not fatal
+                print(f"[bench] rank {rank}: library communicator unavailable ({e})", file=sys.stderr)
+                ok = torch.zeros(1, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks take the same path
+            native_comm = bool(ok.item() > 0)
+            if not native_comm and getattr(ctx, "native_comm", False):
+                sdist.detach_native_comm(ctx)
 
         def step(it):
             # statistics (which need the record count on the host, i.e. a device synchronisation) only for the first
@@ -358,6 +368,12 @@ def main():
             if FREEZE:
                 return ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1],
                                          want_stats=stats)
+            if not native_comm:   # the exchange through the host framework's process group (torch.distributed = RCCL)
+                st_ = ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, losses[it:it + 1],
+                                        want_stats=stats)
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+                ops.adam_step(ctx, P, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1)
+                return st_
             # the whole iteration is ONE C call: fwd/bwd -> st3r_grad_allreduce (RCCL, no-op for one rank) -> Adam
             return ops.train_step(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999,
                                   1e-8, it + 1, losses[it:it + 1], want_stats=stats)
@@ -447,7 +463,10 @@ def main():
                 "gaussians": N, "views": args.views, "width": W, "height": H, "views_per_gpu": C_local,
                 "parallelism": (f"gaussians+views sharded x{world} (2 all-to-all of splat records / iteration)"
                                 if mode == "gaussian-sharded"
-                                else f"view-dp{world} (st3r_grad_allreduce of the [23N] gradients inside st3r_gs_train_step)"),
+                                else f"view-dp{world} (st3r_grad_allreduce of the [23N] gradients inside st3r_gs_train_step)"
+                                if native_comm else
+                                f"view-dp{world} (torch.distributed all_reduce of the [23N] gradients between "
+                                f"st3r_gs_train_fwd_bwd and st3r_adam_step)"),
                 "n_visible_pairs": V, "n_isects_reference_algorithm": I, "n_isects_kept_after_exact_culling": I_kept,
                 "sort_key_bits": {"reference_single_key": keybits, "level1": key1_bits, "level2": key2_bits},
                 "mean_tiles_per_visible_gaussian": (I_kept / V) if V else 0.0,

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     constexpr int IPT = Traits<K>::IPT;
     constexpr int TILE = THREADS * IPT;
     __shared__ K sbuf[TILE];
+    __shared__ int32_t svals[TILE];   // values regroup together with the keys: one trip through LDS, one store phase
     __shared__ uint32_t whist[WAVES][RADIX];
     __shared__ uint32_t lbase[RADIX];
     __shared__ long long gofs[RADIX];
@@ -130,11 +131,19 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     const int wbase = w * 64 * IPT + lane;
 
     K key[IPT];
+    int32_t val[IPT];
     uint32_t rank[IPT];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const int li = wbase + i * 64;
         key[i] = li < tcount ? kin[tbase + li] : K(0);
+    }
+    if (vin) {   // in flight while the keys are ranked
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int li = wbase + i * 64;
+            val[i] = li < tcount ? vin[tbase + li] : 0;
+        }
     }
     const u64 lt = (1ull << lane) - 1ull;
     uint32_t* wh = whist[w];
@@ -208,36 +217,20 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
         if (wbase + i * 64 < tcount) {
             const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
             const uint32_t pos = lbase[d] + wh[d] + rank[i];
-            rank[i] = pos;
             sbuf[pos] = key[i];
+            if (vin) svals[pos] = val[i];
         }
     }
     __syncthreads();
-    uint32_t dig[IPT];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const int p = i * THREADS + tid;
-        dig[i] = 0;
         if (p < tcount) {
             const K k = sbuf[p];
             const uint32_t d = (uint32_t)(k >> shift) & dmask;
-            dig[i] = d;
-            kout[gofs[d] + p] = k;
-        }
-    }
-    if (vin) {
-        __syncthreads();
-        int32_t* sv = reinterpret_cast<int32_t*>(sbuf);
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-            const int li = wbase + i * 64;
-            if (li < tcount) sv[rank[i]] = vin[tbase + li];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-            const int p = i * THREADS + tid;
-            if (p < tcount) vout[gofs[dig[i]] + p] = sv[p];
+            const long long o = gofs[d] + p;
+            kout[o] = k;
+            if (vin) vout[o] = svals[p];
         }
     }
 }
