@@ -36,7 +36,10 @@ typedef unsigned long long u64;
 constexpr u64 FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, VALUE_MASK = (1ull << 62) - 1;
 
 template <typename K> struct Traits;
-template <> struct Traits<uint32_t> { static constexpr int IPT = 16; };
+#ifndef RS_IPT32
+#define RS_IPT32 16
+#endif
+template <> struct Traits<uint32_t> { static constexpr int IPT = RS_IPT32; };
 template <> struct Traits<uint64_t> { static constexpr int IPT = 8; };
 
 __device__ __forceinline__ int wave_incl_scan_u32(uint32_t v, int lane) {
@@ -46,6 +49,16 @@ __device__ __forceinline__ int wave_incl_scan_u32(uint32_t v, int lane) {
         if (lane >= off) v += t;
     }
     return v;
+}
+
+// value of lane q of this lane's quad (DPP quad_perm: one VALU move, no LDS)
+__device__ __forceinline__ uint32_t quad_lane_u32(uint32_t v, int q) {
+    switch (q) {
+        case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true);
+        case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, true);
+        case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, true);
+        default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, true);
+    }
 }
 
 template <typename K>
@@ -116,6 +129,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     __shared__ int32_t svals[TILE];   // values regroup together with the keys: one trip through LDS, one store phase
     __shared__ uint32_t whist[WAVES][RADIX];
     __shared__ uint32_t lbase[RADIX];
+    __shared__ uint32_t tcnt[RADIX];
+    __shared__ u64 gexc[RADIX];
     __shared__ long long gofs[RADIX];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_tile;
@@ -165,9 +180,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     }
     __syncthreads();
 
-    // per digit: exclusive scan over the waves (in place), tile count, chained scan over the tiles
+    // per digit: exclusive scan over the waves (in place), tile count -> published as this tile's aggregate
     uint32_t cnt = 0;
-    u64 excl = 0;
     if (tid < RADIX) {
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) {
@@ -175,27 +189,10 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
             whist[ww][tid] = cnt;
             cnt += c;
         }
-        u64* st = status + (size_t)tile * RADIX + tid;
-        if (tile == 0) {
-            __hip_atomic_store(st, FLAG_INC | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(st, FLAG_AGG | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int64_t t = (int64_t)tile - 1; t >= 0; --t) {
-                const u64* pt = status + (size_t)t * RADIX + tid;
-                u64 v = __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while ((v >> 62) == 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    v = __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // a predecessor always holds an earlier ticket, i.e. it is running: this bound (seconds) can only
-                    // trip on a broken device or a protocol bug, and then it must be loud rather than a hang
-                    if (++spins > (1u << 26)) __builtin_trap();
-                }
-                excl += v & VALUE_MASK;
-                if ((v >> 62) == 2) break;
-            }
-            __hip_atomic_store(st, FLAG_INC | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tile != 0)
+            __hip_atomic_store(status + (size_t)tile * RADIX + tid, FLAG_AGG | (u64)cnt, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        tcnt[tid] = cnt;
     }
     // tile-local exclusive scan of the digit counts
     const uint32_t inc = wave_incl_scan_u32(cnt, lane);
@@ -205,10 +202,50 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
         uint32_t base = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) base += i < w ? wsum[i] : 0u;
-        const uint32_t lb = base + inc - cnt;
-        lbase[tid] = lb;
-        gofs[tid] = (long long)((u64)hist_base[tid] + excl) - (long long)lb;
+        lbase[tid] = base + inc - cnt;
     }
+    // chained scan over the tiles, LB lanes per digit: lane j of a digit's group reads the status word of the
+    // (j+1)-th predecessor, then the next LB ...; the group adds aggregates up to the nearest inclusive prefix.
+    // Every thread of the workgroup takes part (RADIX * LB == THREADS), so one trip of a few hundred ns covers LB
+    // predecessors instead of one.
+    {
+        constexpr int LB = THREADS / RADIX;
+        static_assert(LB == 4, "the look-back group is a DPP quad");
+        const int d = tid / LB, j = tid % LB;
+        u64 excl = 0;
+        if (tile != 0) {
+            bool done = false;
+            for (int64_t t0 = (int64_t)tile - 1; !done; t0 -= LB) {
+                const int64_t t = t0 - j;
+                u64 v = FLAG_INC;   // before the first tile: an inclusive prefix of zero
+                if (t >= 0) {
+                    const u64* pt = status + (size_t)t * RADIX + d;
+                    v = __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned spins = 0;
+                    while ((v >> 62) == 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // a predecessor always holds an earlier ticket, i.e. it is running: this bound (seconds) can
+                        // only trip on a broken device or a protocol bug, and then it must be loud rather than a hang
+                        if (++spins > (1u << 26)) __builtin_trap();
+                    }
+                }
+                const uint32_t val = (uint32_t)(v & VALUE_MASK), isinc = (uint32_t)(v >> 62) == 2u;
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {   // nearest predecessor first
+                    const uint32_t vq = quad_lane_u32(val, q), iq = quad_lane_u32(isinc, q);
+                    if (!done) { excl += vq; done = iq != 0; }
+                }
+            }
+        }
+        if (j == 0) {
+            __hip_atomic_store(status + (size_t)tile * RADIX + d, FLAG_INC | (excl + tcnt[d]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            gexc[d] = excl;
+        }
+    }
+    __syncthreads();
+    if (tid < RADIX) gofs[tid] = (long long)((u64)hist_base[tid] + gexc[tid]) - (long long)lbase[tid];
     __syncthreads();
 
     // regroup by digit in LDS, then leave in runs that are contiguous in the destination
