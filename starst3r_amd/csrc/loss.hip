@@ -173,11 +173,16 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
 // columns one row behind them -- the two stages overlap instead of alternating, each thread carries one 11-row
 // register ring, one barrier per image row.  Saves the 9-float-per-pixel round trip through HBM (1.2 of the 2.6 GB
 // the two-kernel version moves per iteration at 8 x 1080p).
-#define FT1 256                       // forward threads (4 waves)
-#define FT2 (FT1 + LW * 3)            // + backward threads (3 waves) = 448
+#ifndef FLW
+#define FLW 64                        // output columns of a fused strip
+#endif
 #define HALO2 (2 * HALO)
-#define SEG2 ((LW + 2 * HALO2) * 3)   // floats per staged row segment of an image (252)
-#define DCOLS (LW + 2 * HALO)         // columns of D a workgroup computes (74)
+#define DCOLS (FLW + 2 * HALO)        // columns of D a workgroup computes (74)
+#define FT1 ((DCOLS * 3 + 63) / 64 * 64)   // forward threads, whole waves (256)
+#define FBW ((FLW * 3 + 63) / 64 * 64)     // backward threads, whole waves (192)
+#define FT2 (FT1 + FBW)
+#define SEG2 ((FLW + 2 * HALO2) * 3)  // floats per staged row segment of an image (252)
+#define NPF2 ((SEG2 + FT1 - 1) / FT1) // staged elements per forward thread and row
 
 __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const float* __restrict__ render,
                                                     const float* __restrict__ gt, Win win, float k_l1, float k_ss,
@@ -185,9 +190,9 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
     __shared__ float sx[2][SEG2];
     __shared__ float sy[2][SEG2];
     __shared__ float sd[2][DCOLS * 9];
-    __shared__ float red[8];
+    __shared__ float red[2 * (FT1 / 64)];
     const int cam = blockIdx.z;
-    const int j0 = blockIdx.x * LW, i0 = blockIdx.y * LH;
+    const int j0 = blockIdx.x * FLW, i0 = blockIdx.y * LH;
     const float* xr = render + (int64_t)cam * H * W * 3;
     const float* yr = gt + (int64_t)cam * H * W * 3;
     const int rows_out = min(LH, H - i0);
@@ -201,26 +206,34 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
         const bool active = t < DCOLS * 3;
         const int jd = j0 - HALO + col;
         const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
-        float pfx = 0.f, pfy = 0.f;   // SEG2 <= FT1: one element per thread and row
+        float pfx[NPF2], pfy[NPF2];
         auto prefetch = [&](int r) {
             const int i = i0 - HALO2 + r;
-            const int jj = j0 - HALO2 + t / 3;
-            float vx = 0.f, vy = 0.f;
-            if (r < nrows && i >= 0 && i < H && t < SEG2 && jj >= 0 && jj < W) {
-                const int64_t q = ((int64_t)i * W + j0 - HALO2) * 3 + t;
-                vx = xr[q]; vy = yr[q];
+#pragma unroll
+            for (int n = 0; n < NPF2; ++n) {
+                const int e = t + n * FT1;
+                const int jj = j0 - HALO2 + e / 3;
+                float vx = 0.f, vy = 0.f;
+                if (r < nrows && i >= 0 && i < H && e < SEG2 && jj >= 0 && jj < W) {
+                    const int64_t q = ((int64_t)i * W + j0 - HALO2) * 3 + e;
+                    vx = xr[q]; vy = yr[q];
+                }
+                pfx[n] = vx; pfy[n] = vy;
             }
-            pfx = vx; pfy = vy;
         };
         auto commit = [&](int b) {
-            if (t < SEG2) { sx[b][t] = pfx; sy[b][t] = pfy; }
+#pragma unroll
+            for (int n = 0; n < NPF2; ++n) {
+                const int e = t + n * FT1;
+                if (e < SEG2) { sx[b][e] = pfx[n]; sy[b][e] = pfy[n]; }
+            }
         };
         float ring[KS][5];
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int m = 0; m < 5; ++m) ring[s][m] = 0.f;
-        const bool own_col = (col >= HALO) && (col < HALO + LW) && (jd < W);
+        const bool own_col = (col >= HALO) && (col < HALO + FLW) && (jd < W);
         prefetch(0);
         commit(0);
         prefetch(1);
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
         // ================= backward waves: output column j0 + col, one row behind the forward waves =================
         const int t = threadIdx.x - FT1;
         const int col = t / 3, ch = t - col * 3;
-        const int j = j0 + col;
+        const int j = t < FLW * 3 ? j0 + col : W;   // threads past the strip (whole-wave padding) only keep the barriers
         float ring[KS][3];
 #pragma unroll
         for (int s = 0; s < KS; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                             xn = xr[qn]; yn = yr[qn];
                         }
                     }
-                    if (rp >= 2 * HALO) {
+                    if (rp >= 2 * HALO && j < W) {
                         const float* pd = &sd[rp & 1][col * 9 + ch * 3];
                         float h0 = 0, h1 = 0, h2 = 0;
 #pragma unroll
@@ -344,11 +357,15 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
     // sums of the forward waves (the others hold zeros)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_down(l1, off); ssim_acc += __shfl_down(ssim_acc, off); }
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < FT1) { red[threadIdx.x >> 6] = l1; red[4 + (threadIdx.x >> 6)] = ssim_acc; }
+    constexpr int FW = FT1 / 64;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < FT1) { red[threadIdx.x >> 6] = l1; red[FW + (threadIdx.x >> 6)] = ssim_acc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * cam + 0], (double)((red[0] + red[1]) + (red[2] + red[3])));
-        atomicAdd(&sums[2 * cam + 1], (double)((red[4] + red[5]) + (red[6] + red[7])));
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < FW; ++i) { a += red[i]; b += red[FW + i]; }
+        atomicAdd(&sums[2 * cam + 0], (double)a);
+        atomicAdd(&sums[2 * cam + 1], (double)b);
     }
 }
 
@@ -359,10 +376,14 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
     // A strip of LH output rows streams LH + 20 input rows: tall strips waste less, but the launch needs a few
     // workgroups per CU (two are resident) -- as few row strips as still give ~1280 workgroups, at least 32 rows each
     // (8 x 1080p: 6 strips of 180 rows; measured 0.57 ms against 0.62 ms with 64-row strips)
-    const int per_band = ceil_div(W, LW) * C;
-    const int bands = std::max(1, std::min(ceil_div(1280, per_band), ceil_div(H, 32)));
+#ifndef SSIM_TARGET_WGS
+#define SSIM_TARGET_WGS 1280
+#endif
+    const int strip = v_render ? FLW : LW;
+    const int per_band = ceil_div(W, strip) * C;
+    const int bands = std::max(1, std::min(ceil_div(SSIM_TARGET_WGS, per_band), ceil_div(H, 32)));
     const int LH = ceil_div(H, bands);
-    dim3 grid(ceil_div(W, LW), ceil_div(H, LH), C);
+    dim3 grid(ceil_div(W, strip), ceil_div(H, LH), C);
     if (!v_render) {   // loss value only
         hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(LT), 0, s, LH, H, W, render, gt, win, sums, (float*)nullptr);
         LAUNCH_CHECK();
