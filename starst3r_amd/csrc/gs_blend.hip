@@ -363,16 +363,21 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
     const float2 mean = *reinterpret_cast<const float2*>(&sA[t]);
     const float dy = mean.y - qyf_lane;
     const float2* src = pr + r * PAIR_STRIDE + part * CHUNK;
-    float So = 0.f, Sx = 0.f, Sxx = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
+    // The lane's pixels are i = 0 .. CHUNK-1 to the right of its first one: with d0 = dx of the first pixel,
+    // sum g dx = d0 W0 - W1 and sum g dx^2 = d0 (d0 W0 - 2 W1) + W2 for the index moments W_k = sum i^k g_i -- 12 VALU
+    // instead of 21 for CHUNK = 4 (k_blend_bwd 2.27 -> 2.17 ms); the offsets are at most CHUNK-1 pixels, so the
+    // cancellation costs a few ulps.
+    float W0 = 0.f, W1 = 0.f, W2 = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
 #pragma unroll
     for (int i = 0; i < CHUNK; ++i) {
         const float2 v = src[i];
-        const float dx = mean.x - (qxf_lane + (float)i);
-        const float sdx = v.x * dx;
-        So += v.x; Sx += sdx;
-        Sxx = fmaf(sdx, dx, Sxx);
+        W0 += v.x;
+        if (i == 1) { W1 = v.x; W2 = v.x; }
+        if (i > 1) { W1 = fmaf((float)i, v.x, W1); W2 = fmaf((float)(i * i), v.x, W2); }
         Sr = fmaf(v.y, pvr[i], Sr); Sg = fmaf(v.y, pvg[i], Sg); Sb = fmaf(v.y, pvb[i], Sb);
     }
+    const float d0 = mean.x - qxf_lane;
+    const float So = W0, Sx = fmaf(d0, W0, -W1), Sxx = fmaf(d0, Sx - W1, W2);
     const float Sy = So * dy, Sxy = Sx * dy, Syy = Sy * dy;  // dy is the same for the lane's pixels
     float k0, k1, k2;
     reduce9(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);            // lane bits 5, 4
