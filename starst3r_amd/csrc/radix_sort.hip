@@ -6,7 +6,7 @@
 //   k_rs_hist        one pass over the keys: 256-bin histograms of ALL digits at once (LDS atomics; a wave whose
 //                    lanes agree on a digit -- the rule for the high digits of depth / tile keys -- adds once);
 //   k_rs_scan_hist   exclusive scan of each histogram = global base of every bin;
-//   k_rs_pass        one launch per 8-bit digit.  A workgroup (16 waves) owns a tile of 16384 (32-bit keys) or 8192
+//   k_rs_pass        one launch per 8-bit digit.  A workgroup (16 waves; 8 for small inputs) owns a tile of 16384 (32-bit keys) or 8192
 //                    (64-bit keys) consecutive items.  Ranking is wave-local and stable: wave w holds items
 //                    [w*64*IPT, (w+1)*64*IPT) of the tile as IPT rows of 64 consecutive items; per row the lanes
 //                    find their equals with 8 ballots (match-any), rank = running wave count of the digit (LDS) +
@@ -23,11 +23,17 @@ namespace {
 
 constexpr int RB = 8;
 constexpr int RADIX = 1 << RB;
+// Two tile shapes.  Large inputs: 1024 threads x 16 (32-bit keys) / 8 (64-bit keys) items, one workgroup per CU -- the
+// per-tile costs (256 status words, the chained scan) dominate, smaller tiles measured 12-25 % slower (tools/abl3.sh).
+// Small inputs (fewer than one large tile per CU: a rank's share of a view-sharded job): 512 threads x 8 / 4 items, so that
+// the tiles still cover the chip.
 #ifndef RS_THREADS
-#define RS_THREADS 1024   // 512 measured 4 % slower per pass on MI355X (tools/abl3.sh)
+#define RS_THREADS 1024
 #endif
-constexpr int THREADS = RS_THREADS;
-constexpr int WAVES = THREADS / 64;
+#ifndef RS_SMALL_BELOW
+#define RS_SMALL_BELOW 100   // large tiles needed for the large shape (1 M keys: 0.118 -> 0.098 ms; at 200 tiles the large shape wins)
+#endif
+constexpr int THREADS_L = RS_THREADS, THREADS_S = 512;
 constexpr int HIST_THREADS = 256;
 constexpr int HIST_ITEMS = 16;
 constexpr int MAX_PASSES = 8;
@@ -39,8 +45,8 @@ template <typename K> struct Traits;
 #ifndef RS_IPT32
 #define RS_IPT32 16
 #endif
-template <> struct Traits<uint32_t> { static constexpr int IPT = RS_IPT32; };
-template <> struct Traits<uint64_t> { static constexpr int IPT = 8; };
+template <> struct Traits<uint32_t> { static constexpr int IPT = RS_IPT32, IPT_S = 8; };
+template <> struct Traits<uint64_t> { static constexpr int IPT = 8, IPT_S = 4; };
 
 __device__ __forceinline__ int wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -52,6 +58,11 @@ __device__ __forceinline__ int wave_incl_scan_u32(uint32_t v, int lane) {
 }
 
 // value of lane q of this lane's quad (DPP quad_perm: one VALU move, no LDS)
+// value of lane q of this lane's PAIR (lanes 2k, 2k+1)
+__device__ __forceinline__ uint32_t pair_lane_u32(uint32_t v, int q) {
+    return q == 0 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xA0, 0xf, 0xf, true)
+                  : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xF5, 0xf, 0xf, true);
+}
 __device__ __forceinline__ uint32_t quad_lane_u32(uint32_t v, int q) {
     switch (q) {
         case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true);
@@ -116,15 +127,14 @@ __global__ __launch_bounds__(RADIX) void k_rs_scan_hist(uint32_t* __restrict__ h
     }
 }
 
-template <typename K>
+template <typename K, int THREADS, int IPT>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, const int32_t* __restrict__ vin,
                                                      K* __restrict__ kout, int32_t* __restrict__ vout, int64_t n,
                                                      int shift, int bits, const uint32_t* __restrict__ hist_base,
                                                      u64* status, uint32_t* tile_counter,
                                                      const int32_t* __restrict__ n_dev) {
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));   // count on the device, grid sized for the capacity `n`
-    constexpr int IPT = Traits<K>::IPT;
-    constexpr int TILE = THREADS * IPT;
+    constexpr int TILE = THREADS * IPT, WAVES = THREADS / 64;
     __shared__ K sbuf[TILE];
     __shared__ int32_t svals[TILE];   // values regroup together with the keys: one trip through LDS, one store phase
     __shared__ uint32_t whist[WAVES][RADIX];
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     // predecessors instead of one.
     {
         constexpr int LB = THREADS / RADIX;
-        static_assert(LB == 4, "the look-back group is a DPP quad");
+        static_assert(LB == 4 || LB == 2, "the look-back group is a DPP quad or pair");
         const int d = tid / LB, j = tid % LB;
         u64 excl = 0;
         if (tile != 0) {
@@ -233,7 +243,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
                 const uint32_t val = (uint32_t)(v & VALUE_MASK), isinc = (uint32_t)(v >> 62) == 2u;
 #pragma unroll
                 for (int q = 0; q < LB; ++q) {   // nearest predecessor first
-                    const uint32_t vq = quad_lane_u32(val, q), iq = quad_lane_u32(isinc, q);
+                    const uint32_t vq = LB == 4 ? quad_lane_u32(val, q) : pair_lane_u32(val, q);
+                    const uint32_t iq = LB == 4 ? quad_lane_u32(isinc, q) : pair_lane_u32(isinc, q);
                     if (!done) { excl += vq; done = iq != 0; }
                 }
             }
@@ -281,7 +292,9 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
     if (end_bit > (int)sizeof(K) * 8) end_bit = (int)sizeof(K) * 8;
     if (begin_bit < 0 || begin_bit >= end_bit) { st3r_set_error("radix sort: empty bit range"); return ST3R_ERR_INVALID; }
     const int passes = (end_bit - begin_bit + RB - 1) / RB;
-    constexpr int TILE = THREADS * Traits<K>::IPT;
+    constexpr int TILE_L = THREADS_L * Traits<K>::IPT, TILE_S = THREADS_S * Traits<K>::IPT_S;
+    const bool small = (n + TILE_L - 1) / TILE_L < RS_SMALL_BELOW;   // (with a device count: decided on the capacity)
+    const int64_t TILE = small ? TILE_S : TILE_L;
     const int64_t ntiles = (n + TILE - 1) / TILE;
     const size_t hist_bytes = align256(sizeof(uint32_t) * (size_t)(passes * RADIX + MAX_PASSES));
     const size_t status_bytes = sizeof(u64) * (size_t)passes * (size_t)ntiles * RADIX;
@@ -312,8 +325,14 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
         int32_t* vo = to_out ? vals_out : tv;
         const int shift = begin_bit + RB * ps;
         const int bits = min(RB, end_bit - shift);
-        hipLaunchKernelGGL(k_rs_pass<K>, dim3((unsigned)ntiles), dim3(THREADS), 0, s, kin, vin, ko, vin ? vo : nullptr, n,
-                           shift, bits, hist + ps * RADIX, status + (size_t)ps * ntiles * RADIX, counters + ps, n_dev);
+        if (small)
+            hipLaunchKernelGGL((k_rs_pass<K, THREADS_S, Traits<K>::IPT_S>), dim3((unsigned)ntiles), dim3(THREADS_S), 0, s, kin,
+                               vin, ko, vin ? vo : nullptr, n, shift, bits, hist + ps * RADIX,
+                               status + (size_t)ps * ntiles * RADIX, counters + ps, n_dev);
+        else
+            hipLaunchKernelGGL((k_rs_pass<K, THREADS_L, Traits<K>::IPT>), dim3((unsigned)ntiles), dim3(THREADS_L), 0, s, kin,
+                               vin, ko, vin ? vo : nullptr, n, shift, bits, hist + ps * RADIX,
+                               status + (size_t)ps * ntiles * RADIX, counters + ps, n_dev);
         kin = ko;
         if (vin) vin = vo;
     }

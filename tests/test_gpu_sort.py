@@ -30,7 +30,8 @@ def _keys(rng, n, bits, mode, dtype):
     return k.astype(dtype)
 
 
-SIZES = [0, 1, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16383, 16384, 16385, 32769, 100_003, 1_000_003]
+SIZES = [0, 1, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 16383, 16384, 16385, 32769, 100_003, 1_000_003,
+         1_700_003, 4_200_003]   # the tile shape changes at 100 large tiles (16384 / 8192 items): both shapes are covered
 
 
 @pytest.mark.parametrize("kb,bits", [(4, 32), (4, 17), (4, 16), (4, 3), (8, 49), (8, 36), (8, 64)])
