@@ -374,14 +374,15 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
     static const Win win = make_window();
     HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)C, s));
     // A strip of LH output rows streams LH + 20 input rows: tall strips waste less, but the launch needs a few
-    // workgroups per CU (two are resident) -- as few row strips as still give ~1280 workgroups, at least 32 rows each
-    // (8 x 1080p: 6 strips of 180 rows; measured 0.57 ms against 0.62 ms with 64-row strips)
+    // workgroups per CU -- as few row strips as still give ~1000 workgroups, at least 64 rows each
 #ifndef SSIM_TARGET_WGS
-#define SSIM_TARGET_WGS 1280
+#define SSIM_TARGET_WGS 1020
 #endif
     const int strip = v_render ? FLW : LW;
     const int per_band = ceil_div(W, strip) * C;
-    const int bands = std::max(1, std::min(ceil_div(SSIM_TARGET_WGS, per_band), ceil_div(H, 32)));
+    // (measured, tools/ssim_bands.sh: ~1000 workgroups, strips of at least 64 rows -- 8 views: 5 bands, 1 view: 17)
+    int bands = std::max(1, std::min(ceil_div(SSIM_TARGET_WGS, per_band), std::max(1, H / 64)));
+    if (const char* e = getenv("ST3R_SSIM_BANDS")) bands = std::max(1, atoi(e));   // tuning hook (tools/ssim_bands.sh)
     const int LH = ceil_div(H, bands);
     dim3 grid(ceil_div(W, strip), ceil_div(H, LH), C);
     if (!v_render) {   // loss value only
