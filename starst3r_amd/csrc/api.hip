@@ -202,13 +202,15 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats,
+                        const int32_t* cum, const uint64_t* rects, const uint64_t* rectbase, int tight, int64_t n_pairs,
+                        float* v_splats,
                         bool end_in_offsets);
 int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
                              const float* opacities, const float* sh, int sh_stride, const float* viewmats,
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
                              float scale_fac, float* grads, bool accumulate);
+int st3r_pack_rectbase_impl(hipStream_t s, int64_t n, const uint64_t* rects, const int32_t* cum, uint64_t* rb);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -251,7 +253,7 @@ static int settle_pending_count(st3r_ctx* ctx) {
     }
 
 struct RasterOut {
-    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; uint64_t* rects; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
+    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; uint64_t* rects; uint64_t* rectbase; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
 };
 
 // project -> scan -> emit -> sort -> offsets, all in ctx scratch
@@ -312,6 +314,13 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     // pair-id order scan: slot base of every pair for the backward pass's per-(record, tile) partials
     rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, nullptr);
     if (rc) return rc;
+    uint64_t* rectbase = nullptr;
+    if (tile_w <= 1023 && tile_h <= 1023 && !(ctx->debug_flags & 64)) {   // 10-bit rectangle fields
+        GET(SLOT_RECTBASE, uint64_t, n_pairs, rb);
+        rc = st3r_pack_rectbase_impl(s, n_pairs, rects, cum, rb);
+        if (rc) return rc;
+        rectbase = rb;
+    }
     // depth order scan: write positions of the emit kernel
     int32_t* total_dev = nullptr;
     rc = st3r_isect_scan_perm_impl(ctx, s, n_pairs, tiles, perm, cum_d, &total_dev, rects, rects_d);
@@ -369,7 +378,8 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     rc = st3r_isect_offsets32_impl(s, n_isects, tkeys_b, C, tile_w, tile_h, offsets, n_dev);
     st3r_prof_end(ctx, s, STG_OFFSETS);
     if (rc) return rc;
-    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->rects = rects; o->n_isects = n_isects;
+    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->rects = rects; o->rectbase = rectbase;
+    o->n_isects = n_isects;
     o->tile_w = tile_w; o->tile_h = tile_h;
     return ST3R_OK;
 }
@@ -414,7 +424,8 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, (ctx->debug_flags & 2) ? nullptr : ro.rects, 1, n_pairs, v_splats,
+                             last, v_rgb, nullptr, ro.cum, (ctx->debug_flags & 2) ? nullptr : ro.rects,
+                             (ctx->debug_flags & 2) ? nullptr : ro.rectbase, 1, n_pairs, v_splats,
                              eio);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
@@ -529,7 +540,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, ro.rects, 1, n_pairs, v_records, true);
+                             last, v_rgb, nullptr, ro.cum, ro.rects, ro.rectbase, 1, n_pairs, v_records, true);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     const int Hi = H - 10, Wi = W - 10;

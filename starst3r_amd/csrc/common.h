@@ -67,6 +67,7 @@ enum ArenaSlot {
     SLOT_REG_PART,
     SLOT_RECTS,
     SLOT_RECTS_D,
+    SLOT_RECTBASE,
     SLOT_COUNTS,
     SLOT_COUNT
 };
@@ -97,7 +98,8 @@ struct st3r_ctx {
     int64_t* pinned;  // small pinned host buffer for read-backs
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
     int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test; 1: backward
-                      // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks
+                      // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks;
+                      // 6: backward gathers rectangle and slot base separately
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back
     // still in flight (event), and the capacity the in-flight step was given

@@ -407,7 +407,8 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const uint64_t* __restrict__ cmask, int64_t cmask_words,
                                                    const int32_t* __restrict__ tile_nb,
                                                    const int32_t* __restrict__ cum,
-                                                   const uint64_t* __restrict__ rects, int tight,
+                                                   const uint64_t* __restrict__ rects,
+                                                   const uint64_t* __restrict__ rectbase, int tight,
                                                    float* __restrict__ vtile, int stamp) {
     // staged records, same q-form as the forward's but as three arrays (measured: the forward is faster with one
     // 48-byte record per staged index, this kernel with the split layout)
@@ -478,7 +479,12 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             const int64_t word = mbase + hb;   // HB = 64: one (wave-uniform) mask word per round and wave
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
-            if (my_cb) {
+            if (my_cb && rectbase) {   // fused path: slot base and rectangle in one gathered word
+                const uint64_t r = rectbase[my_id];
+                const int x0 = (int)(r & 0x3FF), y0 = (int)((r >> 10) & 0x3FF), rw = (int)((r >> 20) & 0x3FF);
+                my_u = (int)(r >> 32) + ((g.ty0 >> 4) - y0) * rw + ((g.tx0 >> 4) - x0);
+                my_op = a.z; my_ca = a.w; my_cbb = b.x; my_cc = b.y;
+            } else if (my_cb) {
                 int x0, y0, rw;
                 if (rects) {   // fused path: the packed rectangle the emit kernel used (one 8-byte load instead of
                                // ~100 instructions of tight_tile_rect)
@@ -619,8 +625,8 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
-                        const int32_t* cum, const uint64_t* rects, int tight, int64_t n_pairs, float* v_splats,
-                        bool end_in_offsets) {
+                        const int32_t* cum, const uint64_t* rects, const uint64_t* rectbase, int tight, int64_t n_pairs,
+                        float* v_splats, bool end_in_offsets) {
     if (n_isects == 0) {
         HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
         return ST3R_OK;
@@ -644,11 +650,11 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     if (v_alpha)
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
-                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, stamp);
+                           v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp);
     else
         hipLaunchKernelGGL(k_blend_bwd<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
-                           v_alpha, cmask, words, tile_nb, cum, rects, tight, vtile, stamp);
+                           v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp,
                        (float4*)v_splats);
@@ -666,6 +672,6 @@ ST3R_EXPORT int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width,
     ARG_CHECK(splats && offsets && alpha && last_ids && v_rgb && v_splats && cum_tiles && n_pairs >= 0);
     ARG_CHECK(n_isects >= 0 && n_isects < 2147483647LL && (n_isects == 0 || flatten_ids));
     return st3r_blend_bwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
-                               flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, cum_tiles, nullptr, 0, n_pairs,
+                               flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, cum_tiles, nullptr, nullptr, 0, n_pairs,
                                v_splats, false);
 }

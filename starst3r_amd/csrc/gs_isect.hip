@@ -163,6 +163,26 @@ int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, con
     return st3r_scan_inclusive_i32(ctx, s, tiles, perm, cum, n_pairs, total_dev_out, rects, rects_sorted);
 }
 
+// rectbase[pid] = slot base of the pair (exclusive scan of the tile counts) << 32 | x0 | y0 << 10 | w << 20: the one
+// 8-byte word the blend backward gathers per staged record (instead of the rectangle and the scan entry separately --
+// random 8- and 4-byte reads cost a 64-byte sector each)
+__global__ __launch_bounds__(256) void k_pack_rectbase(int64_t n, const uint64_t* __restrict__ rects,
+                                                       const int32_t* __restrict__ cum, uint64_t* __restrict__ rb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = rects[i];
+    const uint32_t base = i == 0 ? 0u : (uint32_t)cum[i - 1];
+    const uint32_t geo = (uint32_t)(r & 0x3FF) | ((uint32_t)((r >> 16) & 0x3FF) << 10) | ((uint32_t)((r >> 32) & 0x3FF) << 20);
+    rb[i] = ((uint64_t)base << 32) | geo;
+}
+
+int st3r_pack_rectbase_impl(hipStream_t s, int64_t n, const uint64_t* rects, const int32_t* cum, uint64_t* rb) {
+    if (n == 0) return ST3R_OK;
+    hipLaunchKernelGGL(k_pack_rectbase, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, rects, cum, rb);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
                          int64_t* n_isects_host) {
     if (n_pairs == 0) { if (n_isects_host) *n_isects_host = 0; return ST3R_OK; }
