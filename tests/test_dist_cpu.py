@@ -157,6 +157,36 @@ def test_sharded_exchanges_uneven_shards_world2(tmp_path):
     assert [open(f"{out}.{r}").read() for r in range(2)] == ["ok", "ok"]
 
 
+def _gather_rows_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from starst3r_amd import gs
+    ok = True
+    for N in (10, 11):                                   # even and uneven shards
+        counts = sdist.shard_counts(N, world)
+        lo, hi = sdist.shard_gaussians(N, rank, world)
+        for width in (1, 3):
+            truth = torch.arange(N * width, dtype=torch.float32).reshape(N, width) * 0.5
+            full = torch.full((N, width), -1.0)
+            full[lo:hi] = truth[lo:hi]                   # every rank knows only its own rows ...
+            gs._gather_rows(full, full[lo:hi], counts, width)   # ... and passes a VIEW of the output as its input
+            ok &= bool(torch.equal(full, truth))
+    with open(f"{out}.{rank}", "w") as f:
+        f.write("ok" if ok else "bad")
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_rows_are_gathered_even_and_uneven_world2(tmp_path):
+    """gs._gather_rows (the re-assembly of the Gaussian shards before an MCMC refinement step and at the end of
+    run_3dgs_optim on the sharded layout): equal shards through all_gather_into_tensor, uneven ones through the
+    variable-length all-gather; the local rows are a view of the output tensor."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = str(tmp_path / "gr")
+    mp.spawn(_gather_rows_worker, args=(2, port, out), nprocs=2, join=True)
+    assert [open(f"{out}.{r}").read() for r in range(2)] == ["ok", "ok"]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Path A under torch.distributed: the pairs of the complete graph are dealt round-robin to the ranks and the new
 # cache entries all-gathered with variable lengths (starst3r_amd.forward.forward_mast3r, SURVEY 8(e) row A).
