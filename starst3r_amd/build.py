@@ -22,6 +22,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
 PER_FILE = {
     "gs_project.hip": ["-ffp-contract=off"],
     "gs_isect.hip": ["-ffp-contract=off"],
+    # MFMA results straight into VGPRs (gfx950 has one unified register file): the arg-max epilogue would otherwise
+    # start with one v_accvgpr_read per score
+    "recip_nn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }
 # Measured on MI355X: a v_pk_{mul,fma,add}_f32 costs two issue slots and the register pairing it needs costs extra
 # v_mov, so hipcc's packed-fp32 vectorisation slows the VALU-bound loops down (blend forward -12 %, backward -5 %

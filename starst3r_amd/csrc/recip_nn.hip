@@ -54,11 +54,48 @@ __global__ __launch_bounds__(256) void k_nn_argmax(const float* __restrict__ Q, 
             for (int k = 0; k < NN_HALF; ++k) q[t][k] = 0.f;
         }
     }
+    // running winner per query tile: value, the tile it came from and the row's position r in the lane's 16 scores
+    // (the DB row is tile * 32 + (r & 3) + 8 (r >> 2) + 4 h, rebuilt once at the end) -- per score one compare and two
+    // selects with inline constants; the tile is noted once per tile and only the last tile checks rows against m
     float best[2] = {-INFINITY, -INFINITY};
-    int bidx[2] = {0x7fffffff, 0x7fffffff};
+    int btile[2] = {-1, -1}, bcode[2] = {0, 0};
     const int tile0 = seg * tiles_per_seg;
     const int tile1 = min(tile0 + tiles_per_seg, (m + 31) >> 5);
-    for (int tile = tile0; tile < tile1; ++tile) {
+    const int full1 = min(tile1, m >> 5);   // tiles [tile0, full1) lie entirely below m
+    // the lane's 48 bytes of the next tile travel while the 24 MFMAs of the current one run
+    float4 nx = make_float4(0, 0, 0, 0), ny = nx, nz = nx;
+    if (tile0 < full1) {
+        const float4* src = reinterpret_cast<const float4*>(DB + (int64_t)(tile0 * 32 + j) * NN_D + NN_HALF * h);
+        nx = src[0]; ny = src[1]; nz = src[2];
+    }
+    for (int tile = tile0; tile < full1; ++tile) {
+        const float4 x = nx, y = ny, z = nz;
+        if (tile + 1 < full1) {
+            const float4* src = reinterpret_cast<const float4*>(DB + (int64_t)((tile + 1) * 32 + j) * NN_D + NN_HALF * h);
+            nx = src[0]; ny = src[1]; nz = src[2];
+        }
+        const float a[NN_HALF] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, z.x, z.y, z.z, z.w};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NN_HALF; ++k) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], q[t][k], c, 0, 0, 0);
+            const float before = best[t];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = c[r];
+                const bool better = v > best[t];  // strict: the first (smallest) index wins ties (rows increase with r)
+                best[t] = better ? v : best[t];
+                bcode[t] = better ? r : bcode[t];
+            }
+            btile[t] = best[t] > before ? tile : btile[t];
+        }
+    }
+    int bidx[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        bidx[t] = btile[t] < 0 ? 0x7fffffff : btile[t] * 32 + (bcode[t] & 3) + 8 * (bcode[t] >> 2) + 4 * h;
+    for (int tile = full1; tile < tile1; ++tile) {   // the ragged last tile of the DB
         const int row = tile * 32 + j;  // this lane's DB row for the A operand
         float a[NN_HALF];
         if (row < m) {
