@@ -14,13 +14,14 @@ gt, _, st0 = ops.render(ctx, Q, w2c, Ks, campos, w, h)
 gt = gt.clamp(0, 1).contiguous(); del Q
 print("gt render isects", st0, flush=True)
 grads = torch.empty(23 * n, device=DEV); m = torch.zeros_like(grads); vv = torch.zeros_like(grads)
-losses = torch.zeros(700, device=DEV)
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 700
+losses = torch.zeros(STEPS, device=DEV)
 t0=time.time()
-for it in range(700):
+for it in range(STEPS):
     try:
         st = ops.train_step(ctx, P, w2c, Ks, campos, gt, w, h, 0.2, 0.01, 0.01, grads, m, vv, 1e-3, 0.9, 0.999, 1e-8, it + 1, losses[it:it + 1])
     except Exception as e:
         print("FAILED at", it, e, flush=True); break
-    if it % 25 == 0:
+    if it % 25 == 0 or it >= 195:
         torch.cuda.synchronize()
         print(it, st, "scale mean %.4f max %.3f" % (float(P["scales"].abs().mean()), float(P["scales"].abs().max())), "t %.1f" % (time.time()-t0), flush=True)
