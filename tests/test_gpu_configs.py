@@ -105,10 +105,10 @@ def test_cfg4_rank_workload_5M_gaussians_8_views_4k_with_pruning():
     nothing is added), position noise is injected every step, the loss stays finite and decreases, nothing is NaN.
 
     The refinement window is compressed (first refinement at step 50, then every 25 steps, instead of gsplat's
-    500 / 100) because this workload cannot reach step 500 on ANY implementation of the reference's loop: scales are
-    optimised RAW with lr 1e-3, so the 0.002..0.008 Gaussians of the synthetic scene grow by ~4e-5
-    per step and the tile intersections with them -- measured here (tools/diag_cfg4.py): 2.7e8 at step 0, 9.3e8 at
-    step 125, 2.1e9 at step 200, past 2^31 (the int32 limit of one call, gsplat's too) at step 203."""
+    500 / 100) to keep the test short and its memory bounded: scales are optimised RAW with lr 1e-3,
+    so the 0.002..0.008 Gaussians of the synthetic scene grow by ~4e-5 per step and the tile intersections with them --
+    measured here (tools/diag_cfg4.py): 2.7e8 at step 0, 9.3e8 at step 125, 2.1e9 at step 200, past 2^31 at step 203
+    (from where the library walks the views in chunks: profiles/r2_cfg4_view_chunks.log), ~150 GB of scratch by then."""
     from starst3r_amd import gs, ops
     ctx = ops.get_context(DEV)
     n, v, w, h = 5_000_000, 8, 3840, 2160
