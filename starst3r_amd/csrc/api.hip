@@ -167,7 +167,7 @@ ST3R_EXPORT int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* co
 
 // ---- internal stage launchers (other translation units) ----
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
-                         int64_t* n_isects_host);
+                         int64_t* n_isects_host, const uint64_t* pack_rects, uint64_t* pack_out);
 int st3r_isect_emit_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* cum, int tile_size,
                          int tile_w, int tile_h, int64_t* isect_ids, int32_t* flatten_ids);
 int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t* keys_in, int32_t* vals_in,
@@ -210,7 +210,6 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
                              float scale_fac, float* grads, bool accumulate);
-int st3r_pack_rectbase_impl(hipStream_t s, int64_t n, const uint64_t* rects, const int32_t* cum, uint64_t* rb);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -312,15 +311,14 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     int64_t n_isects = 0;
     st3r_prof_begin(ctx, s, STG_SCAN);
     // pair-id order scan: slot base of every pair for the backward pass's per-(record, tile) partials
-    rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, nullptr);
-    if (rc) return rc;
+    // (the same launch leaves slot base | rectangle as one word per pair for the backward's staging)
     uint64_t* rectbase = nullptr;
     if (tile_w <= 1023 && tile_h <= 1023 && !(ctx->debug_flags & 64)) {   // 10-bit rectangle fields
         GET(SLOT_RECTBASE, uint64_t, n_pairs, rb);
-        rc = st3r_pack_rectbase_impl(s, n_pairs, rects, cum, rb);
-        if (rc) return rc;
         rectbase = rb;
     }
+    rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, nullptr, rectbase ? rects : nullptr, rectbase);
+    if (rc) return rc;
     // depth order scan: write positions of the emit kernel
     int32_t* total_dev = nullptr;
     rc = st3r_isect_scan_perm_impl(ctx, s, n_pairs, tiles, perm, cum_d, &total_dev, rects, rects_d);

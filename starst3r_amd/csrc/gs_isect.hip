@@ -101,7 +101,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(int32_t* __rest
 #define SCAN_PAD(i) ((i) + ((i) >> 5))
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, const int32_t* __restrict__ perm,
                                                             int64_t n, const int32_t* __restrict__ block_sums,
-                                                            int32_t* out) {
+                                                            int32_t* out, const uint64_t* __restrict__ pack_rects,
+                                                            uint64_t* __restrict__ pack_out) {
+    // pack_rects / pack_out (optional): also leave, per element, exclusive prefix << 32 | x0 | y0 << 10 | w << 20 of its
+    // packed tile rectangle -- the one word the blend backward gathers per staged record (slot base + rectangle; two
+    // separate random reads cost a 64-byte sector each)
     __shared__ int tile[SCAN_PAD(SCAN_TILE) + 1];
     const int64_t base0 = (int64_t)blockIdx.x * SCAN_TILE;
 #pragma unroll
@@ -132,14 +136,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, c
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         const int e = i * SCAN_THREADS + threadIdx.x;
         const int64_t idx = base0 + e;
-        if (idx < n) out[idx] = tile[SCAN_PAD(e)];
+        if (idx < n) {
+            out[idx] = tile[SCAN_PAD(e)];
+            if (pack_out) {
+                const uint32_t excl = (uint32_t)(e == 0 ? block_sums[blockIdx.x] : tile[SCAN_PAD(e - 1)]);
+                const uint64_t r = pack_rects[idx];
+                const uint32_t geo = (uint32_t)(r & 0x3FF) | ((uint32_t)((r >> 16) & 0x3FF) << 10) |
+                                     ((uint32_t)((r >> 32) & 0x3FF) << 20);
+                pack_out[idx] = ((uint64_t)excl << 32) | geo;
+            }
+        }
     }
 }
 
 // out = inclusive scan(in); the grand total is left in the SLOT_SCAN_TMP buffer at [nblocks]
 int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, const int32_t* perm, int32_t* out,
                             int64_t n, int32_t** total_dev, const uint64_t* rects = nullptr,
-                            uint64_t* rects_sorted = nullptr) {
+                            uint64_t* rects_sorted = nullptr, const uint64_t* pack_rects = nullptr,
+                            uint64_t* pack_out = nullptr) {
     int nblocks = ceil_div(n, SCAN_TILE);
     void* tmp;
     int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, sizeof(int32_t) * (size_t)(nblocks + 4), &tmp);
@@ -149,7 +163,7 @@ int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, con
     hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, perm, n, bs, out, rects, rects_sorted);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_THREADS), 0, s, bs, nblocks, bs + nblocks);
     hipLaunchKernelGGL(k_scan_down, dim3(nblocks), dim3(SCAN_THREADS), 0, s, perm ? out : in,
-                       (const int32_t*)nullptr, n, bs, out);
+                       (const int32_t*)nullptr, n, bs, out, pack_rects, pack_out);
     LAUNCH_CHECK();
     if (total_dev) *total_dev = bs + nblocks;
     return ST3R_OK;
@@ -163,31 +177,12 @@ int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, con
     return st3r_scan_inclusive_i32(ctx, s, tiles, perm, cum, n_pairs, total_dev_out, rects, rects_sorted);
 }
 
-// rectbase[pid] = slot base of the pair (exclusive scan of the tile counts) << 32 | x0 | y0 << 10 | w << 20: the one
-// 8-byte word the blend backward gathers per staged record (instead of the rectangle and the scan entry separately --
-// random 8- and 4-byte reads cost a 64-byte sector each)
-__global__ __launch_bounds__(256) void k_pack_rectbase(int64_t n, const uint64_t* __restrict__ rects,
-                                                       const int32_t* __restrict__ cum, uint64_t* __restrict__ rb) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t r = rects[i];
-    const uint32_t base = i == 0 ? 0u : (uint32_t)cum[i - 1];
-    const uint32_t geo = (uint32_t)(r & 0x3FF) | ((uint32_t)((r >> 16) & 0x3FF) << 10) | ((uint32_t)((r >> 32) & 0x3FF) << 20);
-    rb[i] = ((uint64_t)base << 32) | geo;
-}
-
-int st3r_pack_rectbase_impl(hipStream_t s, int64_t n, const uint64_t* rects, const int32_t* cum, uint64_t* rb) {
-    if (n == 0) return ST3R_OK;
-    hipLaunchKernelGGL(k_pack_rectbase, dim3(ceil_div(n, 256)), dim3(256), 0, s, n, rects, cum, rb);
-    LAUNCH_CHECK();
-    return ST3R_OK;
-}
-
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
-                         int64_t* n_isects_host) {
+                         int64_t* n_isects_host, const uint64_t* pack_rects, uint64_t* pack_out) {
     if (n_pairs == 0) { if (n_isects_host) *n_isects_host = 0; return ST3R_OK; }
     int32_t* total_dev = nullptr;
-    int rc = st3r_scan_inclusive_i32(ctx, s, tiles, nullptr, cum, n_pairs, &total_dev);
+    int rc = st3r_scan_inclusive_i32(ctx, s, tiles, nullptr, cum, n_pairs, &total_dev, nullptr, nullptr, pack_rects,
+                                     pack_out);
     if (rc) return rc;
     if (n_isects_host) {
         int32_t* pin = (int32_t*)ctx->pinned;
@@ -201,7 +196,8 @@ int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const in
 ST3R_EXPORT int st3r_gs_isect_scan(st3r_ctx* ctx, void* stream, int64_t n_pairs, const int32_t* tiles_per_gauss,
                                    int32_t* cum_tiles, int64_t* n_isects_host) {
     ARG_CHECK(ctx && n_pairs >= 0 && tiles_per_gauss && cum_tiles && n_isects_host);
-    return st3r_isect_scan_impl(ctx, (hipStream_t)stream, n_pairs, tiles_per_gauss, cum_tiles, n_isects_host);
+    return st3r_isect_scan_impl(ctx, (hipStream_t)stream, n_pairs, tiles_per_gauss, cum_tiles, n_isects_host, nullptr,
+                                nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_isect_emit(int N, int64_t n_pairs, const float4* __restrict__ splats,
