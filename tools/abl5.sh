@@ -4,7 +4,7 @@ PAT=${1:-k_blend}; shift
 cp starst3r_amd/libst3r_hip.so /tmp/orig.so
 for f in build_variants/v*.so; do
   n=$(basename ${f%.so}); echo "== $(cat ${f%.so}.txt)"; cp $f starst3r_amd/libst3r_hip.so
-  bash tools/ktrace.sh $n > /dev/null 2>&1
+  timeout 600 bash tools/ktrace.sh $n > /dev/null 2>&1
   grep -E "$PAT" gpurun_out/kt_$n.md | cut -c1-120
   tail -1 gpurun_out/kt_$n/bench.log | python -c "
 import sys, json
