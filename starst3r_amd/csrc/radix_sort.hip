@@ -37,6 +37,7 @@ constexpr int THREADS_L = RS_THREADS, THREADS_S = 512;
 constexpr int HIST_THREADS = 256;
 constexpr int HIST_ITEMS = 16;
 constexpr int MAX_PASSES = 8;
+constexpr int HIST_COPIES = 8;   // global histogram copies (workgroup b adds into copy b % 8; 32 copies measured equal)
 
 typedef unsigned long long u64;
 constexpr u64 FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, VALUE_MASK = (1ull << 62) - 1;
@@ -106,16 +107,18 @@ __global__ __launch_bounds__(HIST_THREADS) void k_rs_hist(const K* __restrict__ 
         uint32_t t = 0;
 #pragma unroll
         for (int w = 0; w < HIST_THREADS / 64; ++w) t += sh[w][i];
-        if (t) atomicAdd(&hist[i], t);
+        if (t) atomicAdd(&hist[(blockIdx.x & (HIST_COPIES - 1)) * (MAX_PASSES * RADIX) + i], t);   // copy b % HIST_COPIES: fewer adds meet on an address
     }
 }
 
-// hist[p][d] <- exclusive prefix over d (one workgroup of 256 threads)
+// hist[p][d] <- exclusive prefix over d of the sum of the HIST_COPIES partial histograms (one workgroup of 256 threads)
 __global__ __launch_bounds__(RADIX) void k_rs_scan_hist(uint32_t* __restrict__ hist, int passes) {
     __shared__ uint32_t wsum[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int p = 0; p < passes; ++p) {
-        const uint32_t v = hist[p * RADIX + threadIdx.x];
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < HIST_COPIES; ++c) v += hist[c * (MAX_PASSES * RADIX) + p * RADIX + threadIdx.x];
         const uint32_t inc = wave_incl_scan_u32(v, lane);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
@@ -296,7 +299,7 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
     const bool small = (n + TILE_L - 1) / TILE_L < RS_SMALL_BELOW;   // (with a device count: decided on the capacity)
     const int64_t TILE = small ? TILE_S : TILE_L;
     const int64_t ntiles = (n + TILE - 1) / TILE;
-    const size_t hist_bytes = align256(sizeof(uint32_t) * (size_t)(passes * RADIX + MAX_PASSES));
+    const size_t hist_bytes = align256(sizeof(uint32_t) * (size_t)(HIST_COPIES * MAX_PASSES * RADIX + MAX_PASSES));
     const size_t status_bytes = sizeof(u64) * (size_t)passes * (size_t)ntiles * RADIX;
     const size_t meta_bytes = hist_bytes + align256(status_bytes);
     const bool need_tmp = passes > 1;
@@ -307,7 +310,7 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
     if (rc) return rc;
     char* base = (char*)p;
     uint32_t* hist = (uint32_t*)base;
-    uint32_t* counters = hist + passes * RADIX;
+    uint32_t* counters = hist + HIST_COPIES * MAX_PASSES * RADIX;
     u64* status = (u64*)(base + hist_bytes);
     K* tk = (K*)(base + meta_bytes);
     int32_t* tv = (int32_t*)(base + meta_bytes + tk_bytes);
