@@ -147,6 +147,33 @@ __device__ __forceinline__ int stage_record(const float4* __restrict__ splats, i
 // (a tile of `len` records uses 4*ceil(len/256) <= floor(len/64) + 4 words, hence the 4*lb slack)
 __device__ __forceinline__ int64_t mask_base(int lb, int start) { return (int64_t)(start >> 6) + 4 * (int64_t)lb; }
 
+// Compare into a scalar register pair / select under such a mask, spelled out: hipcc keeps a compare result that must
+// outlive the next compare in a VGPR (v_cndmask 0/1 + v_cmp_ne to get the ballot back: two extra VALU instructions per
+// trip of the forward loop).  "s_nop 1": wait states between a scalar write of the mask and its use by v_cndmask.
+__device__ __forceinline__ uint64_t mask_not_less(float a, float b) {   // lanes with !(a < b)
+    uint64_t m;
+    asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint64_t mask_not_positive(float a) {        // lanes with !(a > 0)
+    uint64_t m;
+    asm("v_cmp_nlt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    return m;
+}
+__device__ __forceinline__ float zero_unless(uint64_t m, float x) {     // m ? x : 0
+    float r;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
+
+// TRAIN (the fused training calls): the per-trip bookkeeping of a saturating pixel -- threshold, alpha, T and index
+// selects -- runs only in trips where some lane of the wave saturates (a wave-uniform branch that is almost never
+// taken), and no "last contributing record" is tracked at all: last_ids receives (index of the record at which the
+// pixel saturated) - 1, or INT_MAX for a pixel that never saturated.  The backward's test `record index <= last_ids`
+// then admits exactly the records in front of the saturation point, and among those the alpha test alone decides, as
+// it did in the forward.  Compare + select cost 1.7 ns each on this chip against 1.1 ns for a multiply or add
+// (tools/probe/valu_cost.hip): the fast path drops six of them per (record, wave).
+template <bool TRAIN>
 __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
                                                    const int32_t* __restrict__ offsets,
@@ -165,7 +192,7 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
     // `thr` is the per-lane alpha threshold: 1/255 while the pixel is live, +inf once it saturated (or outside)
     float thr = g.inside ? 1.f / 255.f : __builtin_inff();
     float T = 1.0f, r = 0.f, gg = 0.f, b = 0.f;
-    int cur = 0;
+    int cur = TRAIN ? 0x7fffffff : 0;
     int nb = 0;
 #ifdef ST3R_STATS
     unsigned long long st_rel = 0, st_any = 0, st_con = 0, st_lanes = 0, st_take = 0;
@@ -202,18 +229,43 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                 const float al0 = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
                 // skipped: sigma < 0, or below the lane's threshold (visibility for a live pixel, +inf for a
                 // saturated one) -- two independent compares and one select
-                const bool ok = !(P > 0.f) && !(al0 < thr);
-                float al = ok ? al0 : 0.f;
+                uint64_t okm = 0;
+                bool ok = false;
+                float al;
+                if (TRAIN) {
+                    okm = mask_not_positive(P) & mask_not_less(al0, thr);
+                    al = zero_unless(okm, al0);
+                } else {
+                    ok = !(P > 0.f) && !(al0 < thr);
+                    al = ok ? al0 : 0.f;
+                }
                 const float nT = T * (1.0f - al);        // == T exactly when al == 0
                 const bool stop = nT <= 1e-4f;           // only a live pixel with al > 0 can get here (T > 1e-4 otherwise)
-                thr = stop ? __builtin_inff() : thr;
-                al = stop ? 0.0f : al;                   // the record that saturates the pixel is not blended
-                const float vis = al * T;
-                T = stop ? T : nT;
+                float vis = al * T;
+                uint64_t tm;
+                if (TRAIN) {
+                    // fast values first (same basic block as the compares: the ballot is their mask), then the fix-up
+                    // of the rare trip in which some pixel of the wave saturates
+                    tm = okm;                                    // ok <=> al > 0 (al0 >= thr > 0)
+                    float Tn = nT;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(stop) != 0, 0)) {
+                        thr = stop ? __builtin_inff() : thr;
+                        vis = stop ? 0.0f : vis;                 // the record that saturates the pixel is not blended
+                        Tn = stop ? T : nT;
+                        cur = stop ? bs + t : cur;
+                        tm = okm & ~__builtin_amdgcn_ballot_w64(stop);
+                    }
+                    T = Tn;
+                } else {
+                    thr = stop ? __builtin_inff() : thr;
+                    al = stop ? 0.0f : al;                   // the record that saturates the pixel is not blended
+                    vis = al * T;
+                    T = stop ? T : nT;
+                    const bool took = al > 0.0f;
+                    cur = took ? bs + t : cur;
+                    tm = __builtin_amdgcn_ballot_w64(took);
+                }
                 r += q.z * vis; gg += q.w * vis; b += cb * vis;
-                const bool took = al > 0.0f;
-                cur = took ? bs + t : cur;
-                const uint64_t tm = __builtin_amdgcn_ballot_w64(took);
                 contributed |= tm ? (1ull << bit) : 0ull;
 #ifdef ST3R_STATS
                 st_rel++; st_con += tm ? 1 : 0; st_take += __popcll(tm); st_any += tm ? 1 : 0; st_lanes += __popcll(tm);
@@ -226,7 +278,7 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
         const int64_t p = ((int64_t)g.cam * H + g.i) * W + g.j;
         out_rgb[3 * p] = r; out_rgb[3 * p + 1] = gg; out_rgb[3 * p + 2] = b;
         out_alpha[p] = 1.0f - T;
-        last_ids[p] = cur;
+        last_ids[p] = TRAIN ? (cur == 0x7fffffff ? cur : cur - 1) : cur;
     }
     if (tile_nb && threadIdx.x == 0) tile_nb[g.lb] = nb;
 #ifdef ST3R_STATS
@@ -264,9 +316,15 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
         int rc = hand_off_buffers(ctx, C, tile_w, tile_h, n_isects, &cmask, &words, &tile_nb);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_blend_fwd, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
-                       offsets, flat, end_in_offsets ? -1 : (int)n_isects, rgb, alpha, last_ids, cmask, words, tile_nb,
-                       ctx->debug_flags & 1);
+    // the fused training calls (their own backward follows) take the TRAIN variant; debug flag 128 keeps them on the
+    // gsplat-style bookkeeping (A/B)
+    if (for_backward && end_in_offsets && !(ctx->debug_flags & 128))
+        hipLaunchKernelGGL(k_blend_fwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
+                           offsets, flat, -1, rgb, alpha, last_ids, cmask, words, tile_nb, ctx->debug_flags & 1);
+    else
+        hipLaunchKernelGGL(k_blend_fwd<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
+                           offsets, flat, end_in_offsets ? -1 : (int)n_isects, rgb, alpha, last_ids, cmask, words, tile_nb,
+                           ctx->debug_flags & 1);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

@@ -30,6 +30,29 @@ __global__ __launch_bounds__(256) void k_pkmul(float* out, float seed) {
     asm volatile("v_mov_b32 %0, v10" : "=v"(a0) :: "v10");
     out[blockIdx.x * 256 + threadIdx.x] = a0;
 }
+KERNEL(k_fmac, "v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %5, %4\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %5, %4\n")
+KERNEL(k_add, "v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(k_sub, "v_sub_f32 %0, %4, %0\n v_sub_f32 %1, %5, %1\n v_sub_f32 %2, %4, %2\n v_sub_f32 %3, %5, %3\n")
+KERNEL(k_max3, "v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %5, %4\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %5, %4\n")
+KERNEL(k_cmpx, "v_cmp_lt_f32_e64 s[20:21], %0, %4\n v_cmp_lt_f32_e64 s[22:23], %1, %5\n v_cmp_lt_f32_e64 s[24:25], %2, %4\n v_cmp_lt_f32_e64 s[26:27], %3, %5\n")
+__global__ __launch_bounds__(256) void k_pkfma(float* out, float seed) {
+    float a0 = seed + threadIdx.x;
+    asm volatile("v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n v_mov_b32 v14, %0\n"
+                 "v_mov_b32 v15, %0\n v_mov_b32 v16, %0\n v_mov_b32 v17, %0\n v_mov_b32 v20, 1.0\n v_mov_b32 v21, 1.0\n"
+                 "v_mov_b32 v22, 0\n v_mov_b32 v23, 0\n"
+                 :: "v"(a0) : "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v20", "v21", "v22", "v23");
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile(REP8("v_pk_fma_f32 v[10:11], v[10:11], v[20:21], v[22:23]\n v_pk_fma_f32 v[12:13], v[12:13], v[20:21], v[22:23]\n"
+                          "v_pk_fma_f32 v[14:15], v[14:15], v[20:21], v[22:23]\n v_pk_fma_f32 v[16:17], v[16:17], v[20:21], v[22:23]\n")
+                     ::: "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17");
+    }
+    asm volatile("v_mov_b32 %0, v10" : "=v"(a0) :: "v10");
+    out[blockIdx.x * 256 + threadIdx.x] = a0;
+}
+KERNEL(k_cnd64, "v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %5, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[22:23]\n v_cndmask_b32_e64 %3, %3, %5, s[22:23]\n")
+// compare + select pairs as compiled code has them (two instructions per chain step: the per-instruction figure is half)
+KERNEL(k_cmpcnd, "v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %5, vcc\n v_cmp_lt_f32 vcc, %1, %5\n v_cndmask_b32 %1, %1, %4, vcc\n")
+KERNEL(k_cmpcnd64, "v_cmp_lt_f32_e64 s[20:21], %0, %4\n v_cndmask_b32_e64 %0, %0, %5, s[20:21]\n v_cmp_lt_f32_e64 s[22:23], %1, %5\n v_cndmask_b32_e64 %1, %1, %4, s[22:23]\n")
 KERNEL(k_exp, "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n")
 KERNEL(k_rcp, "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n")
 KERNEL(k_dpp, "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n")
@@ -65,5 +88,8 @@ int main() {
     run(k_dpp, out, "add_dpp", b); run(k_swap32, out, "swap32", b); run(k_swap16, out, "swap16", b);
     run(k_cmp, out, "v_cmp", b); run(k_cnd, out, "cndmask", b); run(k_mov, out, "v_mov", b); run(k_min, out, "v_min", b);
     run(k_readlane, out, "readfirst", b);
+    run(k_fmac, out, "v_fmac", b); run(k_add, out, "v_add", b); run(k_sub, out, "v_sub", b); run(k_max3, out, "v_max3", b);
+    run(k_cmpx, out, "v_cmp_e64", b); run(k_pkfma, out, "v_pk_fma", b);
+    run(k_cnd64, out, "cndmask_e64", b); run(k_cmpcnd, out, "cmp+cnd vcc", b); run(k_cmpcnd64, out, "cmp+cnd s[]", b);
     return 0;
 }
