@@ -50,6 +50,8 @@
 // (qa,qb,qc) = -log2(e) * (a/2, b, c/2) folded at staging time, so exp(-sigma) = exp2(P) is
 // one v_exp_f32.  Forward and backward use the identical expression, hence identical
 // include/skip decisions.
+#include <type_traits>
+
 #include "common.h"
 #include "tile_rect.h"
 
@@ -475,6 +477,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     __shared__ float sC[HB];    // b
     __shared__ float sAccW[4][HB * ACC_VALS];             // per wave: the sums of the records it met this round
     __shared__ float2 sPair[4][CHUNK * PAIR_STRIDE];      // per wave: (g_o, fac) of CHUNK records x 64 pixels
+    __shared__ uint64_t sClampW;                          // staged records whose opacity can reach the 0.999 clamp
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
     const int nb = tile_nb[g.lb];
     if (nb == 0) return;
@@ -488,6 +491,9 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         if (HAS_VA) va = v_alpha[p];
         bin_final = last_ids[p];
     }
+    // does any pixel of this wave bound the records it includes (saturated, outside the image, or gsplat-style
+    // last_ids from the stand-alone forward)?
+    const bool chk_index = __builtin_amdgcn_ballot_w64(bin_final != 0x7fffffff) != 0;
     // phase-2 view of the quadrant: this lane's CHUNK pixels are those of lanes pbase .. pbase + CHUNK-1; their
     // v_rgb go through the (still unused) chunk buffer into registers once per tile
     float2* pr = sPair[w];
@@ -534,6 +540,10 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
             sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
             sC[t] = c.x;
+            // opacity * exp(-sigma) can only exceed the 0.999 clamp when the opacity does (sigma >= 0 for every included
+            // pixel): rounds whose records all stay below it skip the clamp handling
+            const uint64_t cw = __builtin_amdgcn_ballot_w64(a.z > 0.999f);
+            if (t == 0) sClampW = cw;
             const int64_t word = mbase + hb;   // HB = 64: one (wave-uniform) mask word per round and wave
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
@@ -559,45 +569,63 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             }
         }
         __syncthreads();
-        uint64_t m = m_cur;   // HB = 64: one mask word per round
-        while (m) {
-            // ---- phase 1: lanes are pixels; up to CHUNK records, back to front (unrolled: the chunk row is an
-            // immediate offset, the records' staged indices travel to phase 2 in one scalar, 8 bits each)
-            unsigned tpack = 0;
-            int cnt = 0;
+        // ---- phase 1: lanes are pixels; up to CHUNK records, back to front (unrolled: the chunk row is an immediate
+        // offset, the records' staged indices travel to phase 2 in one scalar, 8 bits each).  Compares and selects cost
+        // 1.7 ns each on this chip against 1.1 ns for an add or multiply (tools/probe/valu_cost.hip), so the two tests
+        // that almost never matter are compiled out of the rounds that do not need them (wave-uniform choice):
+        //   CHK    the record-index bound: only waves holding a saturated (or outside) pixel need it -- every other
+        //          pixel's last_ids is INT_MAX (fused path) and the alpha test alone decides, as in the forward;
+        //   CLAMP  the 0.999 clamp: only rounds that stage a record with opacity > 0.999 (sClampW).
+        // What goes to phase 2 is g' = opacity * g_o (alpha * dL/dalpha instead of vis * dL/dalpha): the flush divides
+        // the one sum that needs it.
+        auto walk = [&](auto chk_tag, auto clamp_tag) {
+            constexpr bool CHK = decltype(chk_tag)::value, CLAMP = decltype(clamp_tag)::value;
+            uint64_t m = m_cur;   // HB = 64: one mask word per round
+            while (m) {
+                unsigned tpack = 0;
+                int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < CHUNK; ++k) {
-                if (m) {
-                    const int t = 63 - __builtin_clzll(m);
-                    m &= ~(1ull << t);
-                    const float4 a = sA[t];
-                    const float4 q = sB[t];
-                    const float cb_ = sC[t];
-                    const float dx = a.x - g.px, dy = a.y - g.py;
-                    const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
-                    const float P = dx * lx + q.y * dy * dy;
-                    const float vis0 = __builtin_amdgcn_exp2f(P);
-                    const float ov0 = a.z * vis0;
-                    const float al0 = fminf(0.999f, ov0);
-                    // same include test as the forward pass (bin_final is -1 outside the image).  Branch-free: a
-                    // lane that does not include this record gets alpha = 0, hence 1/(1-alpha) = 1, fac = 0, g_o = 0.
-                    const bool valid = (bs + t <= bin_final) && !(P > 0.f) && !(al0 < 1.f / 255.f);
-                    const float alpha = valid ? al0 : 0.f;
-                    // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
-                    const float vis_u = (valid && ov0 <= 0.999f) ? vis0 : 0.f;
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    const float cv = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
-                    T *= ra;
-                    const float fac = alpha * T;
-                    float v_al = cv * T - bv * ra;
-                    if (HAS_VA) v_al += T_final * ra * va;
-                    bv += cv * fac;
-                    pr[k * PAIR_STRIDE + lane] = make_float2(vis_u * v_al, fac);
-                    tpack |= (unsigned)t << (8 * k);
-                    cnt = k + 1;
+                for (int k = 0; k < CHUNK; ++k) {
+                    if (m) {
+                        const int t = 63 - __builtin_clzll(m);
+                        m &= ~(1ull << t);
+                        const float4 a = sA[t];
+                        const float4 q = sB[t];
+                        const float cb_ = sC[t];
+                        const float dx = a.x - g.px, dy = a.y - g.py;
+                        const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
+                        const float P = dx * lx + q.y * dy * dy;
+                        const float vis0 = __builtin_amdgcn_exp2f(P);
+                        const float ov0 = a.z * vis0;
+                        const float al0 = CLAMP ? fminf(0.999f, ov0) : ov0;
+                        // same include test as the forward pass.  Branch-free: a lane that does not include this record
+                        // gets alpha = 0, hence 1/(1-alpha) = 1, fac = 0, g' = 0.
+                        uint64_t okm = mask_not_positive(P) & mask_not_less(al0, 1.f / 255.f);
+                        if (CHK) okm &= __builtin_amdgcn_ballot_w64(bs + t <= bin_final);
+                        const float alpha = zero_unless(okm, al0);
+                        // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
+                        float alpha_u = alpha;
+                        if (CLAMP) alpha_u = ov0 <= 0.999f ? alpha : 0.f;
+                        const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
+                        const float cv = q.z * vr + q.w * vg + cb_ * vb;   // colour . v_rgb
+                        T *= ra;
+                        const float fac = alpha * T;
+                        float v_al = cv * T - bv * ra;
+                        if (HAS_VA) v_al += T_final * ra * va;
+                        bv += cv * fac;
+                        pr[k * PAIR_STRIDE + lane] = make_float2(alpha_u * v_al, fac);
+                        tpack |= (unsigned)t << (8 * k);
+                        cnt = k + 1;
+                    }
                 }
+                bwd_phase2(pr, tpack, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
             }
-            bwd_phase2(pr, tpack, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
+        };
+        const bool clamp_round = (uniform_u64(sClampW) & m_cur) != 0;
+        if (chk_index) {
+            if (clamp_round) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{});
+        } else {
+            if (clamp_round) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{});
         }
         __syncthreads();
         // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM
@@ -614,11 +642,12 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             }
             // record constants: v_sigma = -opacity g_o;  v_mean2d = v_sigma (a dx + b dy, b dx + c dy);
             // v_conic = v_sigma (dx^2 / 2, dx dy, dy^2 / 2)
-            const float sx = -my_op * acc[0], sy = -my_op * acc[1];
+            // (the six geometric sums arrive multiplied by the opacity: phase 1 hands over alpha * dL/dalpha)
+            const float sx = -acc[0], sy = -acc[1];
             float2* dst = reinterpret_cast<float2*>(vtile + (int64_t)my_u * VT_STRIDE);
             dst[0] = make_float2(my_ca * sx + my_cbb * sy, my_cbb * sx + my_cc * sy);
-            dst[1] = make_float2(acc[2], -0.5f * my_op * acc[3]);
-            dst[2] = make_float2(-my_op * acc[4], -0.5f * my_op * acc[5]);
+            dst[1] = make_float2(my_op != 0.f ? acc[2] / my_op : 0.f, -0.5f * acc[3]);
+            dst[2] = make_float2(-acc[4], -0.5f * acc[5]);
             dst[3] = make_float2(acc[6], acc[7]);
             dst[4] = make_float2(acc[8], __int_as_float(stamp));
         }
