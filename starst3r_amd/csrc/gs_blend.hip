@@ -216,13 +216,19 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
         __syncthreads();
 #pragma unroll 1
         for (int jj = 0; jj < 4; ++jj) {
-            uint64_t m = uniform_u64(sMask[w][jj]);
+            uint64_t m64 = uniform_u64(sMask[w][jj]);
             uint64_t contributed = 0;
-            if (__builtin_amdgcn_ballot_w64(thr < 1.0f) == 0) m = 0;  // every pixel of this wave is saturated
+            if (__builtin_amdgcn_ballot_w64(thr < 1.0f) == 0) m64 = 0;  // every pixel of this wave is saturated
+            // the word is walked as two 32-bit halves: the scalar unit is shared by the CU's four SIMDs (one issue slot in
+            // four cycles each) and 64-bit mask arithmetic costs it two instructions where 32-bit costs one
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {
+            uint32_t m = hh ? (uint32_t)(m64 >> 32) : (uint32_t)m64;
+            uint32_t cont32 = 0;
             while (m) {
-                const int bit = __builtin_ctzll(m);
+                const int bit = __builtin_ctz(m);
                 m &= m - 1;
-                const int t = jj * 64 + bit;
+                const int t = jj * 64 + hh * 32 + bit;
                 const float4 a = sR[3 * t];
                 const float4 q = sR[3 * t + 1];
                 const float cb = sR[3 * t + 2].x;
@@ -268,10 +274,12 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                     tm = __builtin_amdgcn_ballot_w64(took);
                 }
                 r += q.z * vis; gg += q.w * vis; b += cb * vis;
-                contributed |= tm ? (1ull << bit) : 0ull;
+                cont32 |= tm ? (1u << bit) : 0u;
 #ifdef ST3R_STATS
                 st_rel++; st_con += tm ? 1 : 0; st_take += __popcll(tm); st_any += tm ? 1 : 0; st_lanes += __popcll(tm);
 #endif
+            }
+            contributed |= (uint64_t)cont32 << (32 * hh);
             }
             if (cmask && lane == 0) cmask[(int64_t)w * cmask_words + mbase + nb * 4 + jj] = contributed;
         }
