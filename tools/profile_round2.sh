@@ -3,6 +3,8 @@
 #   1. the driver's bench command, un-profiled                      -> gpurun_out/prof_<tag>/bench.json
 #   2. rocprofv3 --kernel-trace --stats around the SAME command     -> .../trace
 #   3. PMC passes (each in its own run, --kernel-trace only): FETCH_SIZE | WRITE_SIZE | SQ instruction counts | SQ cycles
+# gpurun MERGES gpurun_out/ back into the local copy: delete the local gpurun_out/prof_<tag> before repeating a tag, or
+# tools/make_profile_docs.py averages over the counter files of every earlier run as well.
 set -u
 TAG=${1:-r2}
 ROOT=$(pwd)
