@@ -1,0 +1,129 @@
+// Device helpers shared by the two blend translation units (gs_blend.hip: quadrant formulation, stand-alone entry
+// points; gs_blend_cells.hip: 4x4-cell lists, the fused training path).
+#pragma once
+#include "common.h"
+#include "tile_rect.h"
+
+#define BLK 256
+#define LOG2E 1.4426950408889634f
+
+// Workgroup b runs on XCD b % 8 (each XCD has its own L2).  Tiles are handed out in groups of G consecutive
+// tiles per XCD, the groups round-robin over the XCDs: neighbouring tiles (which share Gaussians) meet in one L2.
+// With C a multiple of 8 a group is a whole camera (one camera per XCD); otherwise a group is one tile row, so
+// that the dense image centre and the sparse borders are spread over all XCDs (a single view cut into 8
+// contiguous bands left the XCDs of the borders idle: blend bwd 0.65 -> see DESIGN.md).
+__device__ __forceinline__ int xcd_remap(int bid, int total, int G) {
+    const int n_full = (total / (8 * G)) * (8 * G);
+    if (bid >= n_full) return bid;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int round = k / G, within = k - round * G;
+    return (round * 8 + xcd) * G + within;
+}
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Stage record `id` into LDS slot t (q-form) and return the 4-bit quadrant relevance.
+// q-form of a record in LDS slot t (see the arithmetic note above); forward and backward stage through this one function
+// LDS record: 3 x float4 = (x y opacity qa | qb qc r g | b - - -); one address register serves the three reads
+__device__ __forceinline__ void stage_qform(const float4& a, const float4& b, const float4& c, int t, float4* sR) {
+    sR[3 * t + 0] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
+    sR[3 * t + 1] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
+    sR[3 * t + 2] = make_float4(c.x, 0.f, 0.f, 0.f);
+}
+
+// word index of the first 64-record chunk of tile lb in the contribution-mask arrays
+// (a tile of `len` records uses 4*ceil(len/256) <= floor(len/64) + 4 words, hence the 4*lb slack)
+__device__ __forceinline__ int64_t mask_base(int lb, int start) { return (int64_t)(start >> 6) + 4 * (int64_t)lb; }
+
+// The exponent of a record at a pixel, P = -log2(e) sigma = dx (qa dx + qb dy) + qc dy^2, with ONE fixed association
+// and contraction: every blend kernel (forward and backward, quadrant and cell formulation) must take identical
+// include / skip decisions, and hipcc contracts the plain expression differently from kernel to kernel (round 3: the
+// quadrant forward computed fma(dx, lx, (qc dy) dy), the backward fma(dy, qc dy, dx lx)).
+__device__ __forceinline__ float blend_power(float dx, float dy, float qa, float qb, float qc) {
+#pragma clang fp contract(off)
+    const float lx = __builtin_fmaf(dx, qa, qb * dy);
+    return __builtin_fmaf(dx, lx, (qc * dy) * dy);
+}
+
+// Compare into a scalar register pair / select under such a mask, spelled out: hipcc keeps a compare result that must
+// outlive the next compare in a VGPR (v_cndmask 0/1 + v_cmp_ne to get the ballot back: two extra VALU instructions per
+// trip of the forward loop).  "s_nop 1": wait states between a scalar write of the mask and its use by v_cndmask.
+__device__ __forceinline__ uint64_t mask_not_less(float a, float b) {   // lanes with !(a < b)
+    uint64_t m;
+    asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint64_t mask_not_positive(float a) {        // lanes with !(a > 0)
+    uint64_t m;
+    asm("v_cmp_nlt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    return m;
+}
+__device__ __forceinline__ float zero_unless(uint64_t m, float x) {     // m ? x : 0
+    float r;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
+
+// (a, b) -> a + b after exchanging halves: lanes 0-31 end up with sum_{l, l+32} a, lanes 32-63 with that of b.
+// Inline asm on purpose: with hipcc 7.2 the second element returned by
+// __builtin_amdgcn_permlane32_swap / permlane16_swap came back equal to the first (measured, see
+// tools/probe/swap_probe.hip); the instruction itself behaves as documented.  "s_nop 1" = the two
+// wait states a VALU-written operand needs before v_permlane*_swap reads it.
+// The swaps of one butterfly level are independent of each other, so they are issued as one asm block
+// behind a single "s_nop 1".
+//
+// reduce9: sums g[0..8] over the 64 lanes.  On return, in every 16-lane row r:
+//   k0 holds the total of g[{0,2,1,3}[r]], k1 that of g[{4,6,5,7}[r]], k2 (row 0 only) that of g[8].
+__device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, float g4, float g5, float g6,
+                                        float g7, float g8, float& k0, float& k1, float& k2) {
+    float z0 = 0.f, z1 = 0.f;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\t"
+        "v_permlane32_swap_b32 %2, %3\n\t"
+        "v_permlane32_swap_b32 %4, %5\n\t"
+        "v_permlane32_swap_b32 %6, %7\n\t"
+        "v_permlane32_swap_b32 %8, %9"
+        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "+v"(z0));
+    float h0 = g0 + g1, h1 = g2 + g3, h2 = g4 + g5, h3 = g6 + g7, h4 = g8 + z0;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5"
+        : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(z1));
+    k0 = h0 + h1; k1 = h2 + h3; k2 = h4 + z1;
+}
+#define ACC_VALS 9      // S_x S_y S_o S_xx S_xy S_yy S_r S_g S_b per staged record and wave
+#define VT_STRIDE 10    // per-(record, tile) slot: 9 partial gradients + the stamp = 5 x 8 B
+#ifndef HB
+#define HB 64           // records staged per backward round (a fraction of a forward batch of 256)
+#endif
+#define HB_WORDS (HB / 64)   // 64-record mask words per round
+static_assert(HB == 64, "the backward walks one mask word per round");
+#ifndef CHUNK
+#define CHUNK 4         // records per transposition chunk (4 or 8); a lane of phase 2 owns CHUNK pixels of one row
+#endif
+#define PAIR_STRIDE 65  // float2 per record row of the chunk buffer (64 pixels + 1: conflict-free both ways)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave complete in order; this only stops the compiler from moving them across
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float row_ror8_add(float v) {
+    float r;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ float row_ror4_add(float v) {
+    float r;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+

@@ -54,28 +54,7 @@
 
 #include "common.h"
 #include "tile_rect.h"
-
-#define BLK 256
-#define LOG2E 1.4426950408889634f
-
-// Workgroup b runs on XCD b % 8 (each XCD has its own L2).  Tiles are handed out in groups of G consecutive
-// tiles per XCD, the groups round-robin over the XCDs: neighbouring tiles (which share Gaussians) meet in one L2.
-// With C a multiple of 8 a group is a whole camera (one camera per XCD); otherwise a group is one tile row, so
-// that the dense image centre and the sparse borders are spread over all XCDs (a single view cut into 8
-// contiguous bands left the XCDs of the borders idle: blend bwd 0.65 -> see DESIGN.md).
-__device__ __forceinline__ int xcd_remap(int bid, int total, int G) {
-    const int n_full = (total / (8 * G)) * (8 * G);
-    if (bid >= n_full) return bid;
-    const int xcd = bid & 7, k = bid >> 3;
-    const int round = k / G, within = k - round * G;
-    return (round * 8 + xcd) * G + within;
-}
-
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
+#include "blend_common.h"
 
 #ifdef ST3R_STATS
 __device__ unsigned long long g_blend_stats[8];
@@ -112,15 +91,6 @@ __device__ __forceinline__ TileGeom tile_geom(int C, int W, int H, int tile_w, i
     return g;
 }
 
-// Stage record `id` into LDS slot t (q-form) and return the 4-bit quadrant relevance.
-// q-form of a record in LDS slot t (see the arithmetic note above); forward and backward stage through this one function
-// LDS record: 3 x float4 = (x y opacity qa | qb qc r g | b - - -); one address register serves the three reads
-__device__ __forceinline__ void stage_qform(const float4& a, const float4& b, const float4& c, int t, float4* sR) {
-    sR[3 * t + 0] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
-    sR[3 * t + 1] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
-    sR[3 * t + 2] = make_float4(c.x, 0.f, 0.f, 0.f);
-}
-
 __device__ __forceinline__ int stage_record(const float4* __restrict__ splats, int64_t id, int t, int tx0, int ty0,
                                             float4* sR) {
     const float4 a = splats[id * 3 + 0];   // x y opacity conic.a
@@ -143,29 +113,6 @@ __device__ __forceinline__ int stage_record(const float4* __restrict__ splats, i
         rel |= ellipse_hits_square(et, dx0, dx0 + 7.0f, dy0, dy0 + 7.0f) ? (1 << q) : 0;
     }
     return rel;
-}
-
-// word index of the first 64-record chunk of tile lb in the contribution-mask arrays
-// (a tile of `len` records uses 4*ceil(len/256) <= floor(len/64) + 4 words, hence the 4*lb slack)
-__device__ __forceinline__ int64_t mask_base(int lb, int start) { return (int64_t)(start >> 6) + 4 * (int64_t)lb; }
-
-// Compare into a scalar register pair / select under such a mask, spelled out: hipcc keeps a compare result that must
-// outlive the next compare in a VGPR (v_cndmask 0/1 + v_cmp_ne to get the ballot back: two extra VALU instructions per
-// trip of the forward loop).  "s_nop 1": wait states between a scalar write of the mask and its use by v_cndmask.
-__device__ __forceinline__ uint64_t mask_not_less(float a, float b) {   // lanes with !(a < b)
-    uint64_t m;
-    asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
-    return m;
-}
-__device__ __forceinline__ uint64_t mask_not_positive(float a) {        // lanes with !(a > 0)
-    uint64_t m;
-    asm("v_cmp_nlt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
-    return m;
-}
-__device__ __forceinline__ float zero_unless(uint64_t m, float x) {     // m ? x : 0
-    float r;
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
-    return r;
 }
 
 // TRAIN (the fused training calls): the per-trip bookkeeping of a saturating pixel -- threshold, alpha, T and index
@@ -233,7 +180,7 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                 const float4 q = sR[3 * t + 1];
                 const float cb = sR[3 * t + 2].x;
                 const float dx = a.x - g.px, dy = a.y - g.py;
-                const float P = dx * (a.w * dx + q.x * dy) + q.y * dy * dy;
+                const float P = blend_power(dx, dy, a.w, q.x, q.y);
                 const float al0 = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
                 // skipped: sigma < 0, or below the lane's threshold (visibility for a live pixel, +inf for a
                 // saturated one) -- two independent compares and one select
@@ -273,7 +220,7 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                     cur = took ? bs + t : cur;
                     tm = __builtin_amdgcn_ballot_w64(took);
                 }
-                r += q.z * vis; gg += q.w * vis; b += cb * vis;
+                r = __builtin_fmaf(q.z, vis, r); gg = __builtin_fmaf(q.w, vis, gg); b = __builtin_fmaf(cb, vis, b);
                 cont32 |= tm ? (1u << bit) : 0u;
 #ifdef ST3R_STATS
                 st_rel++; st_con += tm ? 1 : 0; st_take += __popcll(tm); st_any += tm ? 1 : 0; st_lanes += __popcll(tm);
@@ -317,6 +264,10 @@ static int hand_off_buffers(st3r_ctx* ctx, int C, int tile_w, int tile_h, int64_
     return ST3R_OK;
 }
 
+int st3r_blend_fwd_cells_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
+                              const float* splats, const int32_t* offsets, const int32_t* flat, float* rgb, float* alpha,
+                              int32_t* last_ids, uint64_t* cmask, int64_t cmask_words, int32_t* tile_nb);
+
 int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         float* rgb, float* alpha, int32_t* last_ids, bool for_backward, bool end_in_offsets) {
@@ -328,7 +279,12 @@ int st3r_blend_fwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     }
     // the fused training calls (their own backward follows) take the TRAIN variant; debug flag 128 keeps them on the
     // gsplat-style bookkeeping (A/B)
-    if (for_backward && end_in_offsets && !(ctx->debug_flags & 128))
+    // the fused training calls blend with cell lists (gs_blend_cells.hip; debug flag 128 keeps them on the quadrant
+    // kernel, flag 512 sends st3r_gs_render through the cell kernel as well: A/B and tests)
+    if ((for_backward && end_in_offsets && !(ctx->debug_flags & 128)) || (end_in_offsets && (ctx->debug_flags & 512)))
+        return st3r_blend_fwd_cells_impl(ctx, s, C, W, H, tile_w, tile_h, splats, offsets, flat, rgb, alpha, last_ids, cmask,
+                                         words, tile_nb);
+    if (for_backward && end_in_offsets)
         hipLaunchKernelGGL(k_blend_fwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
                            offsets, flat, -1, rgb, alpha, last_ids, cmask, words, tile_nb, ctx->debug_flags & 1);
     else
@@ -354,65 +310,6 @@ ST3R_EXPORT int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width,
 // ------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------
-// (a, b) -> a + b after exchanging halves: lanes 0-31 end up with sum_{l, l+32} a, lanes 32-63 with that of b.
-// Inline asm on purpose: with hipcc 7.2 the second element returned by
-// __builtin_amdgcn_permlane32_swap / permlane16_swap came back equal to the first (measured, see
-// tools/probe/swap_probe.hip); the instruction itself behaves as documented.  "s_nop 1" = the two
-// wait states a VALU-written operand needs before v_permlane*_swap reads it.
-// The swaps of one butterfly level are independent of each other, so they are issued as one asm block
-// behind a single "s_nop 1".
-//
-// reduce9: sums g[0..8] over the 64 lanes.  On return, in every 16-lane row r:
-//   k0 holds the total of g[{0,2,1,3}[r]], k1 that of g[{4,6,5,7}[r]], k2 (row 0 only) that of g[8].
-__device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, float g4, float g5, float g6,
-                                        float g7, float g8, float& k0, float& k1, float& k2) {
-    float z0 = 0.f, z1 = 0.f;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %1\n\t"
-        "v_permlane32_swap_b32 %2, %3\n\t"
-        "v_permlane32_swap_b32 %4, %5\n\t"
-        "v_permlane32_swap_b32 %6, %7\n\t"
-        "v_permlane32_swap_b32 %8, %9"
-        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "+v"(z0));
-    float h0 = g0 + g1, h1 = g2 + g3, h2 = g4 + g5, h3 = g6 + g7, h4 = g8 + z0;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %0, %1\n\t"
-        "v_permlane16_swap_b32 %2, %3\n\t"
-        "v_permlane16_swap_b32 %4, %5"
-        : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(z1));
-    k0 = h0 + h1; k1 = h2 + h3; k2 = h4 + z1;
-}
-#define ACC_VALS 9      // S_x S_y S_o S_xx S_xy S_yy S_r S_g S_b per staged record and wave
-#define VT_STRIDE 10    // per-(record, tile) slot: 9 partial gradients + the stamp = 5 x 8 B
-#ifndef HB
-#define HB 64           // records staged per backward round (a fraction of a forward batch of 256)
-#endif
-#define HB_WORDS (HB / 64)   // 64-record mask words per round
-static_assert(HB == 64, "the backward walks one mask word per round");
-#ifndef CHUNK
-#define CHUNK 4         // records per transposition chunk (4 or 8); a lane of phase 2 owns CHUNK pixels of one row
-#endif
-#define PAIR_STRIDE 65  // float2 per record row of the chunk buffer (64 pixels + 1: conflict-free both ways)
-
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS operations of one wave complete in order; this only stops the compiler from moving them across
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ float row_ror8_add(float v) {
-    float r;
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    return r;
-}
-__device__ __forceinline__ float row_ror4_add(float v) {
-    float r;
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    return r;
-}
-
 // Phase 2 of the backward pass: the wave's lanes turn from pixels into (record, pixel run) pairs.
 //   lane = r + CHUNK * part: record r of the chunk, pixels part*CHUNK .. part*CHUNK + CHUNK-1 of the wave's 8x8
 //   quadrant (a whole pixel row for CHUNK = 8, half a row for CHUNK = 4)
@@ -601,8 +498,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                         const float4 q = sB[t];
                         const float cb_ = sC[t];
                         const float dx = a.x - g.px, dy = a.y - g.py;
-                        const float lx = a.w * dx + q.x * dy;            // qa dx + qb dy
-                        const float P = dx * lx + q.y * dy * dy;
+                        const float P = blend_power(dx, dy, a.w, q.x, q.y);
                         const float vis0 = __builtin_amdgcn_exp2f(P);
                         const float ov0 = a.z * vis0;
                         const float al0 = CLAMP ? fminf(0.999f, ov0) : ov0;

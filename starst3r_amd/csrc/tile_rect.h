@@ -109,3 +109,46 @@ __device__ __forceinline__ bool ellipse_hits_square(const EllipseTest& e, float 
     }
     return hit;
 }
+
+// ---- exact culling at cell granularity: which of the sixteen 4x4-pixel cells of a tile can the ellipse reach? ----
+// Bit cy * 4 + cx of the result is set when some pixel centre of cell (cx, cy) -- centres tx0 + 4 cx + 0.5 ... + 3.5,
+// rows alike -- may pass the alpha >= 1/255 test; a clear bit means all sixteen pixels fail it (same inflated tau as
+// ellipse_prepare, plus 0.01 px on every extent: the closed forms below round differently from the blend loop's
+// polynomial).  By row strips: for dy in [d0, d1] the ellipse A dx^2 + 2 B dx dy + C dy^2 <= 2 tau spans
+//   dx in [ -(B/A) dy - sqrt(2 tau A - det dy^2) / A ,  -(B/A) dy + sqrt(2 tau A - det dy^2) / A ],   |dy| <= ey,
+// whose upper end is concave in dy with its maximum at dy = -B k and whose lower end is convex with its minimum at
+// dy = +B k, k = sqrt(2 tau / (det C)): the x extent over the strip is attained at those points clamped to the strip.
+__device__ __forceinline__ unsigned cell_mask16(float mx, float my, float opac, float A, float B, float C, int tx0,
+                                                int ty0) {
+    // (a conservative test: contraction is welcome here, unlike in the bit-exact tile rectangles above)
+    const float o255 = 255.0f * opac;
+    if (!(o255 > 1.0f)) return 0u;
+    const float det = A * C - B * B;
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    const float tau2 = 2.0f * (__logf(o255) * (1.0002f + 4e-6f * (A * C) * rdet) + 2e-4f);
+    const float rA = __builtin_amdgcn_rcpf(A);
+    const float t2A = tau2 * A;
+    const float ey = __builtin_amdgcn_sqrtf(t2A * rdet) * 1.0001f + 0.01f;
+    const float dys = B * __builtin_amdgcn_sqrtf(tau2 * rdet * __builtin_amdgcn_rcpf(C));
+    const float bA = B * rA, hA = rA * 1.0001f;
+    const float rx = ((float)tx0 + 0.5f) - mx;   // first pixel-centre column / row of the tile relative to the mean
+    const float ry = ((float)ty0 + 0.5f) - my;
+    const float kh = -0.25f * rx, kl = -0.25f * (rx + 3.0f);
+    unsigned m = 0u;
+#pragma unroll
+    for (int cy = 0; cy < 4; ++cy) {
+        const float e0 = fmaxf(ry + (float)(4 * cy), -ey), e1 = fminf(ry + (float)(4 * cy + 3), ey);
+        // (for e0 > e1 the strip misses the ellipse and the result is discarded below)
+        const float yu = __builtin_amdgcn_fmed3f(-dys, e0, e1), yl = __builtin_amdgcn_fmed3f(dys, e0, e1);
+        const float hu = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-det * yu, yu, t2A), 0.0f)), hA, 0.01f);
+        const float hl = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-det * yl, yl, t2A), 0.0f)), hA, 0.01f);
+        const float xhi = __builtin_fmaf(-bA, yu, hu), xlo = -__builtin_fmaf(bA, yl, hl);
+        // cells with  rx + 4 cx <= xhi  and  rx + 4 cx + 3 >= xlo
+        const float hi = fminf(floorf(__builtin_fmaf(xhi, 0.25f, kh)), 3.0f), lo = fmaxf(ceilf(__builtin_fmaf(xlo, 0.25f, kl)), 0.0f);
+        if (e0 <= e1 && lo <= hi) {
+            const int il = (int)lo, n = (int)hi - il + 1;
+            m |= (((1u << n) - 1u) << il) << (4 * cy);
+        }
+    }
+    return m;
+}

@@ -121,6 +121,14 @@ def test_culling_changes_nothing_at_full_size(S):
     finally:
         ops.set_debug(ctx, 0)
     assert torch.equal(r_all, S["rgb"]) and torch.equal(a_all, S["alpha"])
+    # (c) the cell-list kernel of the training path (flag 512), with its exact cell test and without (513)
+    for flags in (512, 513):
+        ops.set_debug(ctx, flags)
+        try:
+            r_c, a_c, _ = ops.render(ctx, S["P"], S["w2c"], S["Ks"], S["campos"], W, H)
+        finally:
+            ops.set_debug(ctx, 0)
+        assert torch.equal(r_c, S["rgb"]) and torch.equal(a_c, S["alpha"]), flags
     gt = torch.zeros((V, H, W, 3), device=DEV)
     grads = torch.empty(23 * N, device=DEV); loss = torch.zeros(1, device=DEV)
     st = ops.train_fwd_bwd(ctx, S["P"], S["w2c"], S["Ks"], S["campos"], gt, W, H, 0.2, 0.01, 0.01, grads, loss)

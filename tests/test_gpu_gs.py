@@ -319,6 +319,28 @@ def test_fused_train_gradients_equal_stage_path(ctx, name):
     assert abs(float(loss[0]) - expect) <= 1e-5 * abs(expect)
 
 
+@pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
+def test_cell_list_forward_equals_quadrant_forward(ctx, name):
+    """The fused training path blends with 4x4-cell lists (gs_blend_cells.hip: four records per trip, one per 16-lane row,
+    exec-masked tests); st3r_gs_render takes the same kernel under debug flag 512.  Same records per pixel in the same
+    order with the same arithmetic: the images are bit-identical to the quadrant kernel's, with the cell test on (the
+    exact row-strip test must be a superset of the hit cells) and off (flag 1: every record in every list)."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make(name)
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    r0, a0, _ = ops.render(ctx, P, vm, K, campos, W, H)
+    for flags in (512, 513):
+        ops.set_debug(ctx, flags)
+        try:
+            r1, a1, _ = ops.render(ctx, P, vm, K, campos, W, H)
+        finally:
+            ops.set_debug(ctx, 0)
+        assert torch.equal(r1.view(torch.int32), r0.view(torch.int32)), flags
+        assert torch.equal(a1.view(torch.int32), a0.view(torch.int32)), flags
+
+
 def test_train_step_end_to_end(ctx):
     """Fused fwd+bwd+Adam: the first-iteration loss equals the oracle's composite loss and the
     loss goes down over 30 iterations (starster/gs.py:143-161 semantics)."""
