@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-drift", action="store_true",
+                    help="skip the untimed continuation to 200 steps that shows how the step time drifts as training "
+                         "changes the scene (windows.drift; one GPU, only when --steps < 200)")
     ap.add_argument("--multi-gpu", choices=("replicated", "gaussian-sharded"), default="replicated",
                     help="how N > 1 GPUs are used (DESIGN.md section 5): replicated = the north_star partition (default)")
     ap.add_argument("--cpu-sample-div", type=int, default=2,
@@ -90,7 +93,7 @@ def algorithmic_bytes(N, C, V, I_kept, P, Ct, key1_bits, key1_bytes, key2_bits):
 
 def make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device):
     """GT = render of the jittered scene, clipped to [0,1]; produced on device."""
-    from starst3r_amd import synth
+    from st3r_synth import synth
     gt_g = synth.perturb_for_gt(g_np)
     P = {k: torch.tensor(v, device=device) for k, v in gt_g.items()}
     campos = ops.camera_positions(w2c)
@@ -106,7 +109,7 @@ def cpu_baseline(args):
     from oracle import build as ob
     ob.build()
     from oracle import gs_oracle as go
-    from starst3r_amd import synth
+    from st3r_synth import synth
     d = args.cpu_sample_div
     W, H, N = args.width // d, args.height // d, args.gaussians // (d * d)
     g, w2c, Ks = synth.make_scene(N, 1, W, H)
@@ -138,7 +141,8 @@ def align_bench(device, with_cpu=True, views=8):
     """Secondary metric "align sec": wall time of the reference's 500+200-iteration global alignment
     (starster/reconstruct.py:427,440) on a synthetic condensed problem -- HIP path vs the torch-CPU oracle
     (a port of the reference loop, validated against reference-generated goldens) on the host cores."""
-    from starst3r_amd import align, synth_align
+    from starst3r_amd import align
+    from st3r_synth import synth_align
     flat = synth_align.flatten(synth_align.make_problem(n_views=views, n_corr=2000 // (views - 1) + 1, seed=1))
     align.run(flat, niter1=3, niter2=3, device=device)
     torch.cuda.synchronize()
@@ -175,7 +179,8 @@ def align_bench(device, with_cpu=True, views=8):
 def condense_bench(device, with_cpu=True, views=8, W=512, H=384):
     """canonical pointmaps + focals + anchors for `views` images of W x H from the C(C-1)/2 pair
     predictions (the step between matching and alignment), device kernels vs the numpy restatement."""
-    from starst3r_amd import condense, synth_pairs
+    from starst3r_amd import condense
+    from st3r_synth import synth_pairs
     P = synth_pairs.make_pair_predictions(views, W, H, seed=0, n_corr=2000)
     dev_pairs = {}
     for k, ((p1, p2), (score, corr)) in P["pairs"].items():   # resident on the device like freshly inferred pairs
@@ -307,7 +312,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from starst3r_amd import ops, synth
+    from starst3r_amd import ops
+    from st3r_synth import synth
     ctx = ops.get_context(device)
 
     N, W, H = args.gaussians, args.width, args.height
@@ -323,7 +329,9 @@ def main():
     FREEZE = os.environ.get("ST3R_BENCH_FREEZE") == "1"
     mode = args.multi_gpu
     total = args.warmup + args.steps
-    losses = torch.zeros(total, device=device)
+    DRIFT_TO = 200   # SURVEY 8(d) asks for >= 200 steady-state iterations; the driver fixes --steps 20
+    want_drift = world == 1 and not FREEZE and not args.no_drift and args.steps < DRIFT_TO and mode != "gaussian-sharded"
+    losses = torch.zeros(max(total, args.warmup + DRIFT_TO) if want_drift else total, device=device)
     stats = {}
     if mode == "gaussian-sharded":
         from starst3r_amd import dist as sdist
@@ -389,7 +397,8 @@ def main():
     psnr_before = psnr_local()
 
     # Stage timing costs two HIP events per stage and step (~0.15 ms per step for all eleven): the warm-up steps time
-    # every stage to find the dominant one, the timed region times only that one (live, on the launch stream).
+    # every stage to find the dominant one; in the timed region ONE stage is timed per step (two events, live, on the
+    # launch stream): the dominant stage on every other step, the ten others in turn on the steps between.
     ops.set_profiling(ctx, args.warmup > 0)
     ops.stage_ms(ctx)  # reset
     for it in range(args.warmup):
@@ -397,7 +406,9 @@ def main():
     warm_stage = ops.stage_ms(ctx) if args.warmup > 0 else {}
     warm_ms = {k: ms / n for k, (ms, n) in warm_stage.items() if n > 0}
     dom_warm = max(warm_ms, key=warm_ms.get) if warm_ms else None
-    ops.set_profiling(ctx, True, only=dom_warm)
+    others = [k for k in ops.STAGES if k != dom_warm]
+    sched = [dom_warm if (i % 2 == 0 or not others) else others[(i // 2) % len(others)] for i in range(args.steps)]
+    ops.set_profiling(ctx, dom_warm is not None, only=dom_warm)
     ops.stage_ms(ctx)  # reset
     if world > 1:
         dist.barrier()
@@ -408,6 +419,8 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for it in range(args.warmup, total):
+        if dom_warm is not None:
+            ops.set_profiling(ctx, True, only=sched[it - args.warmup])   # (a mask in the ctx: no device work)
         stats = step(it) or stats
         marks[it - args.warmup + 1].record()
     torch.cuda.synchronize()
@@ -420,6 +433,46 @@ def main():
     stage = ops.stage_ms(ctx)
     ops.set_profiling(ctx, False)
     psnr_after = psnr_local()
+    # The reference trains RAW scales: the Gaussians grow and the step gets slower with the step count.
+    # Untimed continuation of the same run to 200 steps: the step time at steps 100-120 and 180-200 next to the timed one.
+    drift = None
+    if want_drift:
+        bounds = [b for b in (100, 120, 180, 200) if b > args.steps]
+        ev = {}
+        for it in range(total, args.warmup + DRIFT_TO):
+            k = it - args.warmup
+            if k in bounds:
+                ev[k] = torch.cuda.Event(enable_timing=True); ev[k].record()
+            step(it)
+        ev[DRIFT_TO] = torch.cuda.Event(enable_timing=True); ev[DRIFT_TO].record()
+        torch.cuda.synchronize()
+        drift = {f"steps_0_{args.steps}": dt / args.steps * 1e3}
+        for a, b in ((100, 120), (180, 200)):
+            if a in ev and b in ev:
+                drift[f"steps_{a}_{b}"] = ev[a].elapsed_time(ev[b]) / (b - a)
+    # per-rank view of the same timed region, and the exchange on its own (N > 1)
+    my_ms = marks[0].elapsed_time(marks[-1]) / args.steps
+    per_rank_ms, exch_ms = [my_ms], None
+    if world > 1:
+        t_all = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(t_all, torch.tensor([my_ms], device=device, dtype=torch.float64))
+        per_rank_ms = [float(x.item()) for x in t_all]
+        if mode != "gaussian-sharded":
+            from starst3r_amd import _lib
+            scratch = torch.zeros(23 * N, device=device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            for r_ in range(reps + 1):
+                if r_ == 1:
+                    dist.barrier(); torch.cuda.synchronize(); e0.record()
+                if native_comm:
+                    _lib.check(_lib.lib().st3r_grad_allreduce(ctx.handle, ops._stream(), ops._p(scratch), scratch.numel()))
+                else:
+                    dist.all_reduce(scratch)
+            e1.record(); torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / reps], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exch_ms = float(t.item())
     if mode == "gaussian-sharded":   # counts of the own Gaussians over all views ~ those of the own views over all Gaussians
         stats["n_visible"] = int(trainer.reg[2].item()); stats["n_isects_ref"] = int(trainer.reg[3].item())
     if world > 1:
@@ -442,8 +495,9 @@ def main():
         key2_bits = max(C_local * tw * th - 1, 1).bit_length()                  # level-2 (camera, tile) key
         ab = algorithmic_bytes(N, C_local, V, I_kept, P_px, C_local * tw * th, key1_bits, key1_bytes, key2_bits)
         ab_ref = algorithmic_bytes_reference(N, V, I, P_px, C_local * tw * th, keybits)
-        per_stage = dict(warm_ms)                      # every stage: warm-up steps
-        per_stage.update({k: ms / n for k, (ms, n) in stage.items() if n > 0})   # timed region (dominant stage only)
+        per_stage = dict(warm_ms)                      # fall-back: warm-up steps
+        timed_samples = {k: n for k, (ms, n) in stage.items() if n > 0}
+        per_stage.update({k: ms / n for k, (ms, n) in stage.items() if n > 0})   # timed region, one stage per step
         dom = dom_warm if dom_warm is not None else max(per_stage, key=per_stage.get)
         dom_ms = per_stage[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -478,7 +532,13 @@ def main():
             # five windows of steps/5 consecutive steps inside the one timed region (HIP events on the launch stream)
             "windows": {"ms_per_step": win_ms, "median_ms_per_step": win_sorted[len(win_sorted) // 2],
                         "median_iters_per_sec": 1e3 / win_sorted[len(win_sorted) // 2],
-                        "spread_rel": (win_sorted[-1] - win_sorted[0]) / win_sorted[len(win_sorted) // 2]},
+                        "spread_rel": (win_sorted[-1] - win_sorted[0]) / win_sorted[len(win_sorted) // 2],
+                        # ms per step of the same run continued (untimed) to 200 steps: raw scales grow under training
+                        "drift_ms_per_step": drift},
+            # every rank's own ms per step over the timed region (HIP events on its launch stream) and, for N > 1, one
+            # exchange of the [23N] gradient buffer on its own (max over ranks): step - exchange ~ what a rank computes
+            "per_rank": {"ms_per_step": per_rank_ms, "exchange_ms_isolated": exch_ms,
+                         "exchange": os.environ.get("ST3R_EXCHANGE", "ranges" if world > 1 else "none")},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -497,7 +557,9 @@ def main():
                     "whole_iter_equiv_GBps": sum(ab_ref.values()) / (ms_per_step * 1e-3) / 1e9},
                 "algorithmic_bytes_by_stage": ab,
                 "stage_ms": per_stage,
-                "stage_ms_source": f"{dom}: HIP events over the timed region; other stages: over the warm-up steps",
+                "stage_ms_samples_in_timed_region": timed_samples,
+                "stage_ms_source": f"HIP events in the timed region, one stage per step ({dom} on every other step, the "
+                                   "others in turn); a stage without a sample there: warm-up steps",
             },
         }
         if not args.no_cpu_baseline and world == 1:

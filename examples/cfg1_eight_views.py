@@ -16,7 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import starst3r_amd as st
-from starst3r_amd.synth_model import SyntheticNetwork
+from st3r_synth.synth_model import SyntheticNetwork
 
 
 def psnr_per_view(sc, W, H):

@@ -80,6 +80,11 @@ int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
  * images must come out bit-identical, which is how the culling is validated at full size.
  * st3r_ctx_peek(which = 8 / 9): rgb [C,H,W,3] / alpha [C,H,W] of the last st3r_gs_train_fwd_bwd call. */
 int st3r_ctx_set_debug(st3r_ctx* ctx, int flags);
+/* Waits for the record count of the last asynchronous training step (st3r_gs_train_fwd_bwd / st3r_gs_train_step with
+ * stats_host == NULL) and reports it like the next training call would: ST3R_ERR_CAPACITY if that step outgrew its
+ * buffers (its Adam update was then skipped on the device: repeat the step).  For the end of a training loop
+ * (starster/gs.py:143-166 returns after the last iteration); a no-op when nothing is in flight. */
+int st3r_ctx_settle(st3r_ctx* ctx);
 int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* counts_out);
 const char* st3r_stage_name(int stage);
 

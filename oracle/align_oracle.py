@@ -3,7 +3,7 @@
 Restates starster/reconstruct.py:116-457 `sparse_scene_optimizer_slam` with the reference's own
 settings (reconstruct.py:61-69: lr1=0.07, niter1=500, lr2=0.014, niter2=200, opt_depth=False,
 matching_conf_thr=5, shared_intrinsics=False) on the flat problem layout of
-starst3r_amd/synth_align.flatten().  Vectorised over views instead of python lists, torch CPU
+st3r_synth/synth_align.flatten().  Vectorised over views instead of python lists, torch CPU
 autograd for the gradients (the HIP path uses hand-derived gradients; this file is what checks them).
 
 PINNED: against golden vectors produced by the reference function itself

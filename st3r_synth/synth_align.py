@@ -165,12 +165,7 @@ def flatten(problem):
     return out
 
 
-class Slice:
-    """One ordered image pair of the reference's `imgs_slices` (reconstruct.py:280-290): the correspondences of the
-    pair sit at anchors[img1][slice1] and anchors[img2][slice2]."""
-
-    def __init__(self, img1, slice1, img2, slice2, confs):
-        self.img1, self.slice1, self.img2, self.slice2, self.confs = img1, slice1, img2, slice2, confs
+from starst3r_amd.condense import Slice  # noqa: E402  (the product's type; re-exported for the generators' users)
 
 
 def to_reference_inputs(P):

@@ -49,7 +49,7 @@ class SyntheticPairwiseModel:
 
 class SyntheticPairModel:
     """The other model protocol of starst3r_amd.reconstruct: `forward_pairs` hands over what Mast3r's forward_mast3r
-    caches per image pair (pointmaps, confidences, correspondences -- starst3r_amd.synth_pairs) and leaves the
+    caches per image pair (pointmaps, confidences, correspondences -- st3r_synth.synth_pairs) and leaves the
     condensation (starst3r_amd.condense) and the alignment to the library."""
     subsample = 8
 

@@ -24,6 +24,7 @@ SIGNATURES = {
     "st3r_ctx_peek": [vp, vp, i32, vp, i64],
     "st3r_ctx_set_profiling": [vp, i32],
     "st3r_ctx_set_debug": [vp, i32],
+    "st3r_ctx_settle": [vp],
     "st3r_ctx_get_stage_ms": [vp, C.POINTER(f64), C.POINTER(i64)],
     "st3r_stage_name": [i32],
     "st3r_gs_project_sh": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32,
@@ -103,4 +104,6 @@ def check(rc):
         msg = msg.decode() if msg else ""
         if rc == -1:
             raise ValueError(f"st3r: invalid argument: {msg}")
-        raise St3rError(f"st3r error {rc}: {msg}")
+        err = St3rError(f"st3r error {rc}: {msg}")
+        err.code = rc
+        raise err

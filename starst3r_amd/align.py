@@ -14,7 +14,7 @@ PARAM_KEYS = ("pps", "log_focals", "quats", "trans", "log_sizes")
 
 
 def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, loss_dust3r_w=0.01, device="cuda:0"):
-    """flat: dict of numpy arrays (starst3r_amd.synth_align.flatten layout).
+    """flat: dict of numpy arrays (st3r_synth.synth_align.flatten layout).
     Returns (result, params): result has intrinsics [C,3,3], cam2w [C,4,4], depthmaps [C,G], pts3d [A,3],
     losses [niter1+niter2] (st3r_align_run stops updating after a NaN loss, like the reference's `break` at
     starster/reconstruct.py:397-398: the remaining entries stay 0); params holds the optimised parameters (and the normalised core_depth) so that a

@@ -13,49 +13,120 @@ struct AdamK {
     float step_size, bc2_sqrt, w1, w2, b2, eps;
 };
 
+// The update covers either a range [i0, i1) of the 23N scalars in buffer order (reduce-scatter exchange: a rank owns
+// one contiguous piece of the gradient buffer) or the 23 scalars of the Gaussians [g0, g1) (range-wise exchange); the
+// whole buffer is the range [0, 23N).  pstage != NULL: the new parameter value is also left in pstage[i] (buffer
+// order), the payload of the parameter all-gather that follows.
+__device__ __forceinline__ float* adam_param(int64_t i, int64_t N, float* means, float* quats, float* scales,
+                                             float* opacities, float* sh, int sh_stride) {
+    if (i < 3 * N) return means + i;
+    if (i < 7 * N) return quats + (i - 3 * N);
+    if (i < 10 * N) return scales + (i - 7 * N);
+    if (i < 11 * N) return opacities + (i - 10 * N);
+    const int64_t j = i - 11 * N;
+    const int64_t g = j / 12;
+    return sh + g * sh_stride + (j - g * 12);
+}
+
 __global__ __launch_bounds__(256) void k_adam(int64_t N, float* __restrict__ means, float* __restrict__ quats,
                                               float* __restrict__ scales, float* __restrict__ opacities,
                                               float* __restrict__ sh, int sh_stride,
                                               const float* __restrict__ grads, float* __restrict__ m,
-                                              float* __restrict__ v, AdamK k) {
-    const int64_t total = 23 * N;
+                                              float* __restrict__ v, AdamK k, const int32_t* __restrict__ count_dev,
+                                              uint32_t count_cap, int64_t i0, int64_t i1, int64_t g0, int64_t g1,
+                                              float* __restrict__ pstage) {
+    // Asynchronous training steps keep the record count on the device; a step whose count outgrew the capacity of its
+    // buffers dropped records, so its gradients are incomplete: the update is skipped HERE, on the device, and the next
+    // call reports ST3R_ERR_CAPACITY -- the caller repeats the iteration with nothing to undo (a count above 2^31 wraps
+    // negative: the unsigned compare catches it).
+    if (count_dev && (uint32_t)count_dev[0] > count_cap) return;
+    const bool by_gaussian = g1 - g0 < N;
+    const int64_t n = g1 - g0;
+    const int64_t total = by_gaussian ? 23 * n : i1 - i0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        float* p;
-        if (i < 3 * N) p = means + i;
-        else if (i < 7 * N) p = quats + (i - 3 * N);
-        else if (i < 10 * N) p = scales + (i - 7 * N);
-        else if (i < 11 * N) p = opacities + (i - 10 * N);
-        else {
-            const int64_t j = i - 11 * N;
-            const int64_t g = j / 12;
-            p = sh + g * sh_stride + (j - g * 12);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        int64_t i;
+        if (by_gaussian) {   // local index -> block (means 3, quats 4, scales 3, opacities 1, sh 12) -> buffer index
+            if (j < 3 * n) i = 3 * g0 + j;
+            else if (j < 7 * n) i = 3 * N + 4 * g0 + (j - 3 * n);
+            else if (j < 10 * n) i = 7 * N + 3 * g0 + (j - 7 * n);
+            else if (j < 11 * n) i = 10 * N + g0 + (j - 10 * n);
+            else i = 11 * N + 12 * g0 + (j - 11 * n);
+        } else {
+            i = i0 + j;
         }
+        float* p = adam_param(i, N, means, quats, scales, opacities, sh, sh_stride);
         const float gi = grads[i];
         const float mi = fmaf(k.w1, gi - m[i], m[i]);
         const float vi = v[i] * k.b2 + (k.w2 * gi) * gi;
         m[i] = mi; v[i] = vi;
         const float denom = sqrtf(vi) / k.bc2_sqrt + k.eps;
-        *p = *p - k.step_size * (mi / denom);
+        const float pn = *p - k.step_size * (mi / denom);
+        *p = pn;
+        if (pstage) pstage[i] = pn;
     }
 }
 
-int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities, float* sh,
-                   int sh_stride, const float* grads, float* m, float* v, double lr, double b1, double b2,
-                   double eps, int step) {
-    if (N == 0) return ST3R_OK;
+// parameters of the scalars OUTSIDE [i0, i1) <- pstage (what the other ranks computed and the all-gather delivered)
+__global__ __launch_bounds__(256) void k_params_from_stage(int64_t N, float* __restrict__ means, float* __restrict__ quats,
+                                                           float* __restrict__ scales, float* __restrict__ opacities,
+                                                           float* __restrict__ sh, int sh_stride,
+                                                           const float* __restrict__ pstage, int64_t i0, int64_t i1,
+                                                           int64_t lim, const int32_t* __restrict__ count_dev,
+                                                           uint32_t count_cap) {
+    if (count_dev && (uint32_t)count_dev[0] > count_cap) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < lim; i += stride) {
+        if (i >= i0 && i < i1) continue;
+        *adam_param(i, N, means, quats, scales, opacities, sh, sh_stride) = pstage[i];
+    }
+}
+
+static AdamK adam_constants(double lr, double b1, double b2, double eps, int step) {
     AdamK k;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     k.step_size = (float)(lr / bc1);
     k.bc2_sqrt = (float)sqrt(bc2);
     k.w1 = (float)(1.0 - b1); k.w2 = (float)(1.0 - b2); k.b2 = (float)b2; k.eps = (float)eps;
-    const int64_t total = 23 * (int64_t)N;
+    return k;
+}
+
+// i0 < 0: the whole buffer.  [g0, g1) a proper sub-range of the Gaussians: that range instead of [i0, i1).
+int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities, float* sh,
+                   int sh_stride, const float* grads, float* m, float* v, double lr, double b1, double b2,
+                   double eps, int step, const int32_t* count_dev, uint32_t count_cap, int64_t i0, int64_t i1,
+                   int64_t g0, int64_t g1, float* pstage) {
+    if (N == 0) return ST3R_OK;
+    if (i0 < 0) { i0 = 0; i1 = 23 * (int64_t)N; }
+    if (g1 < 0) { g0 = 0; g1 = N; }
+    const AdamK k = adam_constants(lr, b1, b2, eps, step);
+    const int64_t total = (g1 - g0 < N) ? 23 * (g1 - g0) : i1 - i0;
+    if (total <= 0) return ST3R_OK;
     int blocks = ceil_div(total, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, (int64_t)N, means, quats, scales, opacities, sh,
-                       sh_stride, grads, m, v, k);
+                       sh_stride, grads, m, v, k, count_dev, count_cap, i0, i1, g0, g1, pstage);
     LAUNCH_CHECK();
     return ST3R_OK;
+}
+
+int st3r_params_from_stage_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities,
+                                float* sh, int sh_stride, const float* pstage, int64_t i0, int64_t i1, int64_t lim,
+                                const int32_t* count_dev, uint32_t count_cap) {
+    if (lim <= 0) return ST3R_OK;
+    int blocks = ceil_div(lim, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_params_from_stage, dim3(blocks), dim3(256), 0, s, (int64_t)N, means, quats, scales, opacities, sh,
+                       sh_stride, pstage, i0, i1, lim, count_dev, count_cap);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+// the device-side guard of an asynchronous step that is still in flight (see k_adam)
+void st3r_adam_guard(st3r_ctx* ctx, const int32_t** count_dev, uint32_t* count_cap) {
+    const bool guard = ctx->count_pending && ctx->slot_ptr[SLOT_COUNTS];
+    *count_dev = guard ? (const int32_t*)ctx->slot_ptr[SLOT_COUNTS] : nullptr;
+    *count_cap = guard ? (uint32_t)ctx->count_cap : 0u;
 }
 
 ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
@@ -64,8 +135,11 @@ ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means,
     ARG_CHECK(ctx && N >= 0 && step >= 1 && sh_stride >= 12);
     ARG_CHECK(means && quats && scales && opacities && sh && grads && m && v);
     st3r_prof_begin(ctx, (hipStream_t)stream, STG_ADAM);
+    // an asynchronous step is in flight and its count not yet settled: guard the update with it (see k_adam)
+    const int32_t* count_dev; uint32_t count_cap;
+    st3r_adam_guard(ctx, &count_dev, &count_cap);
     int rc = st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr,
-                            beta1, beta2, eps, step);
+                            beta1, beta2, eps, step, count_dev, count_cap, -1, -1, 0, -1, nullptr);
     st3r_prof_end(ctx, (hipStream_t)stream, STG_ADAM);
     return rc;
 }

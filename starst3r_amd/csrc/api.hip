@@ -40,6 +40,12 @@ ST3R_EXPORT int st3r_ctx_destroy(st3r_ctx* ctx) {
         if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->count_event) (void)hipEventDestroy(ctx->count_event);
+    if (ctx->comm_stream) {
+        for (int j = 0; j < ST3R_MAX_RANGES; ++j) {
+            (void)hipEventDestroy(ctx->ev_range_bwd[j]); (void)hipEventDestroy(ctx->ev_range_red[j]);
+        }
+        (void)hipStreamDestroy(ctx->comm_stream);
+    }
     if (ctx->prof_ev[0][0][0])
         for (int r = 0; r < PROF_RING; ++r)
             for (int st = 0; st < STG_COUNT; ++st)
@@ -209,7 +215,7 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
                              const float* opacities, const float* sh, int sh_stride, const float* viewmats,
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
-                             float scale_fac, float* grads, bool accumulate);
+                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -234,12 +240,18 @@ static int settle_pending_count(st3r_ctx* ctx) {
     if (n > ctx->count_cap) {
         ctx->isect_hint = 0;   // the next call takes the synchronous path and sizes its buffers exactly
         st3r_set_error("the previous step produced %lld tile intersections, more than the %lld its buffers were sized "
-                       "for from the step before (+25 %%): its gradients were incomplete -- repeat it",
+                       "for from the step before (+25 %%): its gradients were incomplete and st3r_adam_step / "
+                       "st3r_gs_train_step did NOT apply them (the update is guarded on the device) -- repeat that step",
                        (long long)n, (long long)ctx->count_cap);
         return ST3R_ERR_CAPACITY;
     }
     ctx->isect_hint = n;
     return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_ctx_settle(st3r_ctx* ctx) {
+    ARG_CHECK(ctx);
+    return settle_pending_count(ctx);
 }
 
 #define GET(slot, type, count, var)                                                          \
@@ -428,8 +440,23 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
-    rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                                  0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, accumulate);
+    // Range-wise exchange (st3r_gs_train_step, comm.hip): one launch per Gaussian range with an event behind each, so that
+    // a range's gradients can be reduced while the next range is still being computed.  Only for a whole call in one
+    // pass: the later view chunks of a chunked call ADD to every range.
+    ctx->ranges_recorded = 0;
+    if (ctx->n_ranges > 1 && !accumulate && ctx->comm_stream) {
+        const int K = ctx->n_ranges;
+        for (int j = 0; j < K && !rc; ++j) {
+            const int g0 = (int)((int64_t)N * j / K), g1 = (int)((int64_t)N * (j + 1) / K);
+            rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
+                                          H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, false, g0, g1);
+            if (!rc) HIP_TRY(hipEventRecord(ctx->ev_range_bwd[j], s));
+        }
+        if (!rc) ctx->ranges_recorded = K;
+    } else {
+        rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
+                                      0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, accumulate, 0, -1);
+    }
     st3r_prof_end(ctx, s, STG_PROJECT_BWD);
     *ro_out = ro;
     return rc;
@@ -470,10 +497,13 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
             HIP_TRY(hipMemsetAsync(rs, 0, sizeof(double) * 4, s));
             RasterOut ro;
             // exact statistics need the count on the host: a caller that passes stats_host pays the synchronisation;
-            // chunked calls size every chunk exactly (the hint of the steady state belongs to one set of views)
+            // chunked calls size every chunk exactly (the hint of the steady state belongs to one set of views); with a
+            // communicator attached every step is sized exactly too -- a capacity overflow would surface on ONE rank only,
+            // at its next call, while the other ranks are already waiting in the gradient all-reduce
             rc = train_views(ctx, s, N, c1 - c0, means, quats, scales, opacities, sh, sh_stride, viewmats + 16 * c0,
                              Ks + 9 * c0, campos + 3 * c0, gt_images + (int64_t)c0 * H * W * 3, W, H, ssim_fac, opac_fac,
-                             scale_fac, sums + 2 * c0, rs, stats_host == nullptr && chunks == 1, !first, grads, &ro);
+                             scale_fac, sums + 2 * c0, rs, stats_host == nullptr && chunks == 1 && !ctx->comm, !first, grads,
+                             &ro);
             if (!rc) { st_vis += ro.n_visible; st_is += ro.n_isects; st_ref += ro.n_isects_ref; }
             first = false;
         }

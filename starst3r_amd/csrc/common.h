@@ -69,6 +69,7 @@ enum ArenaSlot {
     SLOT_RECTS_D,
     SLOT_RECTBASE,
     SLOT_COUNTS,
+    SLOT_PSTAGE,
     SLOT_COUNT
 };
 
@@ -88,6 +89,7 @@ enum Stage {
     STG_COUNT
 };
 #define PROF_RING 64
+#define ST3R_MAX_RANGES 8
 
 #define ST3R_SPLIT_VIEWS 1000   // internal: more than 2^31 tile intersections, the caller may retry with fewer views
 
@@ -110,6 +112,12 @@ struct st3r_ctx {
     hipEvent_t count_event;
     void* comm;     // ncclComm_t of the view-sharded job (NULL: single replica)
     int comm_owned, comm_rank, comm_size;
+    // range-wise exchange (comm.hip): the projection backward runs once per Gaussian range and leaves an event per
+    // range; the ranges' all-reduces run on comm_stream behind those events, Adam per range behind the all-reduces
+    hipStream_t comm_stream;
+    hipEvent_t ev_range_bwd[ST3R_MAX_RANGES], ev_range_red[ST3R_MAX_RANGES];
+    int n_ranges;            // > 1: train_views splits the projection backward (set by st3r_gs_train_step for one call)
+    int ranges_recorded;     // how many ev_range_bwd the last train_views recorded (0: it ran as one launch)
     int prof_enabled;
     hipEvent_t prof_ev[PROF_RING][STG_COUNT][2];
     unsigned char prof_used[PROF_RING][STG_COUNT];

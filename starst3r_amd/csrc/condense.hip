@@ -178,6 +178,16 @@ ST3R_EXPORT int st3r_focal_weiszfeld_batch(st3r_ctx* ctx, void* stream, int n_vi
     // G workgroups per view: enough to spread an image over many CUs, few enough that the whole grid is resident
     int G = min(FB_MAX_G, max(1, 1024 / n_views));
     G = min(G, max(1, ceil_div((int64_t)H * W, FB_THREADS)));
+    // the per-view counter barrier needs every workgroup of the grid resident at once: bound the grid by what THIS
+    // device can hold (a partitioned GPU or a CU mask leaves fewer CUs than the 256 of a whole MI355X); one workgroup
+    // per view (G = 1) needs no partner and always works
+    {
+        int per_cu = 0, cus = 0;
+        hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_focal_weiszfeld, FB_THREADS, 0);
+        hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int64_t resident = (e1 == hipSuccess && e2 == hipSuccess) ? (int64_t)per_cu * cus / 2 : 0;   // half: other streams
+        if (resident < (int64_t)G * n_views) G = (int)max((int64_t)1, resident / n_views);
+    }
     const size_t part_bytes = sizeof(unsigned long long) * 11 * (size_t)n_views * G;
     const size_t cnt_off = (part_bytes + 255) & ~(size_t)255;
     void* p;

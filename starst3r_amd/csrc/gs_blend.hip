@@ -374,7 +374,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                                                    const int32_t* __restrict__ cum,
                                                    const uint64_t* __restrict__ rects,
                                                    const uint64_t* __restrict__ rectbase, int tight,
-                                                   float* __restrict__ vtile, int stamp) {
+                                                   float* __restrict__ vtile, int stamp, unsigned vt_cap) {
     // staged records, same q-form as the forward's but as three arrays (measured: the forward is faster with one
     // 48-byte record per staged index, this kernel with the split layout)
     __shared__ float4 sA[HB];   // x y opacity qa
@@ -532,8 +532,10 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             if (clamp_round) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{});
         }
         __syncthreads();
-        // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM
-        if (my_cb) {
+        // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM.  Slot indices come from the
+        // scan over the TRUE tile counts; in an asynchronous step that outgrew its capacity they can exceed the slots the
+        // buffer has (that step is discarded anyway): such a record is not written (unsigned: a wrapped index too)
+        if (my_cb && (unsigned)my_u < vt_cap) {
             float acc[ACC_VALS];
 #pragma unroll
             for (int k = 0; k < ACC_VALS; ++k) acc[k] = 0.f;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
 // the HBM side; the next 256 slots are in flight while the current ones are summed); then lane = pair adds the rows
 // of its own slots in slot order.  Measured at SYNTH-1M: 0.26 ms, one thread per pair walking its slots 0.35 ms.
 __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int32_t* __restrict__ cum,
-                                                      const float* __restrict__ vtile, int stamp,
+                                                      const float* __restrict__ vtile, int stamp, unsigned vt_cap,
                                                       float4* __restrict__ v_splats) {
     constexpr int ROW = ACC_VALS;   // odd stride: rows of neighbouring slots fall into different banks
     __shared__ int sCum[257];
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
     float2 q0, q1, q2, q3, q4;
     auto fetch = [&](int u) {
         q0 = q1 = q2 = q3 = q4 = make_float2(0.f, 0.f);   // stamp 0 = never written
-        if (u < s1) {
+        if (u < s1 && (unsigned)u < vt_cap) {   // (vt_cap: see the flush of k_blend_bwd)
             const float2* src = reinterpret_cast<const float2*>(vtile + (int64_t)u * VT_STRIDE);
             q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; q4 = src[4];
         }
@@ -638,16 +640,17 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     }
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
+    const unsigned vt_cap = (unsigned)(ctx->slot_bytes[SLOT_VTILE] / (sizeof(float) * VT_STRIDE));
     if (v_alpha)
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
-                           v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp);
+                           v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp, vt_cap);
     else
         hipLaunchKernelGGL(k_blend_bwd<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
-                           v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp);
+                           v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp, vt_cap);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp,
+    hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp, vt_cap,
                        (float4*)v_splats);
     LAUNCH_CHECK();
     return ST3R_OK;

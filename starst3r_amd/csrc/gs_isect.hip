@@ -454,7 +454,8 @@ __global__ __launch_bounds__(256) void k_isect_emit_rects(int N, int64_t n_pairs
         if (rem < 0) { --q; rem += (int)w; }
         if (rem >= (int)w) { ++q; rem -= (int)w; }
         const uint32_t tx = (geo & 0xFFFF) + (uint32_t)rem, ty = (geo >> 16) + (uint32_t)q;
-        if ((int64_t)base + o < cap) {
+        // (a true total above 2^31 wraps the int32 scan: a negative position must not pass the capacity test)
+        if ((int64_t)base + o >= 0 && (int64_t)base + o < cap) {
             tile_keys[base + o] = s_key0[p] + ty * (uint32_t)tile_w + tx;
             vals[base + o] = s_pid[p];
         }

@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ sh,
     int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     const float* __restrict__ campos, int W, int H, float eps2d, const float4* __restrict__ splats,
-    const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads, int accumulate) {
+    const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads, int accumulate,
+    int g_begin, int g_end) {
     extern __shared__ float cam[];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float* o = cam + c * CAM_STRIDE;
@@ -35,8 +36,8 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
         o[20] = campos[3 * c]; o[21] = campos[3 * c + 1]; o[22] = campos[3 * c + 2];
     }
     __syncthreads();
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
+    const int g = g_begin + blockIdx.x * blockDim.x + threadIdx.x;   // one launch per Gaussian range (see comm.hip)
+    if (g >= g_end) return;
 
     const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
     const float opac = opacities[g];
@@ -244,14 +245,15 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
                              const float* opacities, const float* sh, int sh_stride, const float* viewmats,
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
-                             float scale_fac, float* grads, bool accumulate) {
-    if (N == 0) return ST3R_OK;
+                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end) {
+    if (g_end < 0) g_end = N;
+    if (N == 0 || g_end <= g_begin) return ST3R_OK;
     float reg_o_k = reg_views * opac_fac / (float)N;
     float reg_s_k = reg_views * scale_fac / (3.0f * (float)N);
     size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
-    hipLaunchKernelGGL(k_project_sh_bwd, dim3(ceil_div(N, 256)), dim3(256), shmem, s, N, C, means, quats, scales,
-                       opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d, (const float4*)splats,
-                       (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(k_project_sh_bwd, dim3(ceil_div(g_end - g_begin, 256)), dim3(256), shmem, s, N, C, means, quats,
+                       scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d, (const float4*)splats,
+                       (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin, g_end);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -266,5 +268,5 @@ ST3R_EXPORT int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && v_splats && grads);
     return st3r_project_sh_bwd_impl((hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats,
                                     Ks, campos, width, height, eps2d, splats, v_splats, reg_views, opac_fac, scale_fac,
-                                    grads, false);
+                                    grads, false, 0, -1);
 }

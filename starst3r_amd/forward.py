@@ -85,7 +85,9 @@ def _exchange_pair_results(mine, cache_path, device):
             score, tensors = obj
         else:
             score, tensors = None, obj
-        layout.append((rel, score, [tuple(t.shape) for t in tensors]))
+        # the payload travels as float32 (exact for the float16 / integer tensors a cache entry can hold: |values| < 2^24);
+        # the layout carries each tensor's dtype so that the receiver stores what the sender stored
+        layout.append((rel, score, [(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in tensors]))
         chunks.extend(t.reshape(-1).float() for t in tensors)
     flat = torch.cat(chunks) if chunks else torch.zeros(0)
     backend_dev = device if tdist.get_backend() == "nccl" else "cpu"
@@ -98,11 +100,11 @@ def _exchange_pair_results(mine, cache_path, device):
         buf = buf.cpu(); off = 0
         for rel, score, shapes in lay:
             tensors = []
-            for shp in shapes:
+            for shp, dt in shapes:
                 n = 1
                 for d in shp:
                     n *= d
-                tensors.append(buf[off:off + n].reshape(shp).clone()); off += n
+                tensors.append(buf[off:off + n].reshape(shp).to(getattr(torch, dt)).clone()); off += n
             path = os.path.join(cache_path, rel)
             if not os.path.isfile(path):
                 torch.save(tuple(tensors) if score is None else (score, tuple(tensors)), _mkdir_for(path))
@@ -123,6 +125,7 @@ def forward_mast3r(pairs, model, cache_path, desc_conf="desc_conf", device="cuda
     rank, world = sdist.rank_world()
     if not shard:
         rank, world = 0, 1
+    pairs = list(pairs)
     res_paths, todo = {}, []
     for img1, img2 in pairs:
         n1, n2 = img1["instance"], img2["instance"]
@@ -138,10 +141,24 @@ def forward_mast3r(pairs, model, cache_path, desc_conf="desc_conf", device="cuda
             todo.append((img1, img2, files))
     mine = {}
     if world > 1:
-        # every rank must have taken its inventory of the (possibly shared) cache before anyone adds files to it:
-        # the round-robin deal below is only consistent if all ranks see the same `todo`
+        # Every rank must deal from the SAME list.  Rank-private caches can be in different states (and a shared one
+        # can change while the ranks take their inventory), so the ranks exchange the positions of the pairs they miss
+        # and deal the union: a pair missing anywhere is inferred once, by one rank, and its entries reach every cache
+        # through the exchange below (a rank that already holds a pair keeps its own files).
         import torch.distributed as tdist
-        tdist.barrier()
+        order = {}
+        for img1, img2 in pairs:
+            order.setdefault((img1["instance"], img2["instance"]), len(order))
+        by_key = {(a["instance"], b["instance"]): (a, b) for a, b in pairs}
+        missing = sorted(order[(a["instance"], b["instance"])] for a, b, _ in todo)
+        everyone = [None] * tdist.get_world_size()
+        tdist.all_gather_object(everyone, missing)
+        union = sorted(set(i for lst in everyone for i in lst))
+        keys = {v: k for k, v in order.items()}
+        todo = []
+        for i in union:
+            img1, img2 = by_key[keys[i]]
+            todo.append((img1, img2, _pair_files(cache_path, img1["instance"], img2["instance"], desc_conf, subsample)))
     if model is not None:
         for k in sdist.shard_pairs(len(todo), rank, world):
             img1, img2, files = todo[k]

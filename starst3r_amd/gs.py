@@ -22,6 +22,7 @@ import torch
 
 from . import dist as _dist
 from . import ops
+from . import _lib as _lib_mod
 
 GAUSSIAN_KEYS = ("means", "scales", "quats", "opacities", "sh0", "shN")
 ADAM_BLOCKS = (("means", 3), ("quats", 4), ("scales", 3), ("opacities", 1), ("shN", 12))  # block layout of [23N]
@@ -277,26 +278,61 @@ def run_3dgs_optim(
     gt = _gt_on_device(scene, views)
     losses = torch.zeros(max(iters, 1), device=scene.device)
     fused = world == 1 or getattr(ctx, "native_comm", False)
+    import os
+    if enable_pruning and os.environ.get("ST3R_EXCHANGE") == "rs_ag":
+        # reduce-scatter exchange: a rank maintains the Adam moments of its piece of the buffer only; growing the set
+        # moves the piece boundaries, so the refinement loop stays on an exchange with replicated moments
+        os.environ["ST3R_EXCHANGE"] = "ranges"
     it_range = range(iters)
     if verbose:
         from tqdm import trange
         it_range = trange(iters)
-    for step in it_range:
-        if enable_pruning:
-            scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
+    def one_iteration(step):
         P = {k: g[k].data for k in ("means", "quats", "scales", "opacities", "shN")}  # growth replaces the tensors
-        st.step += 1
         if fused:   # the whole iteration is one C call (gradient all-reduce inside, over the ctx's communicator)
+            # no host round trip in steady state (single rank; with a communicator the library sizes every step exactly)
             ops.train_step(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
                            loss_scale_fac, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step,
-                           losses[step:step + 1], want_stats=False)   # no host round trip in steady state
-        else:       # gradient all-reduce through the host framework's process group (torch.distributed -> RCCL)
+                           losses[step:step + 1], want_stats=False)
+        else:       # gradient all-reduce through the host framework's process group (torch.distributed -> RCCL); every
+                    # step is sized exactly (want_stats): an overflow seen by one rank only would leave the others waiting
             ops.train_fwd_bwd(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
-                              loss_scale_fac, st.grads, losses[step:step + 1], want_stats=False)
+                              loss_scale_fac, st.grads, losses[step:step + 1], want_stats=True)
             _dist.all_reduce_sum(st.grads)
             ops.adam_step(ctx, P, st.grads, st.m, st.v, st.lr, st.betas[0], st.betas[1], st.eps, st.step)
+
+    def capacity_error(e):
+        return getattr(e, "code", 0) == -3 and world == 1
+
+    step = 0
+    for _ in it_range:
+        if enable_pruning:
+            scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
+        st.step += 1
+        try:
+            one_iteration(step)
+        except _lib_mod.St3rError as e:
+            # ST3R_ERR_CAPACITY is reported by the call AFTER the asynchronous step that outgrew its buffers (> 25 % more
+            # tile intersections than the step before it).  That step's records past the capacity were dropped and its
+            # Adam update was skipped on the device (k_adam's guard), so nothing has to be undone: the lost iteration is
+            # repeated -- the context is back on the exactly sized path -- and then this one runs.
+            if not capacity_error(e):
+                raise
+            if step > 0:
+                st.step -= 1
+                one_iteration(step - 1)
+                st.step += 1
+            one_iteration(step)
         if enable_pruning:
             scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
+        step += 1
+    if world == 1 and iters > 0:
+        try:   # the last step's count is still in flight: settle it now so that an overflow cannot go unnoticed
+            ops.settle(ctx)
+        except _lib_mod.St3rError as e:
+            if not capacity_error(e):
+                raise
+            one_iteration(iters - 1)   # its update was skipped on the device: repeat it
     _dist.all_reduce_sum(losses)
     return losses[:iters].cpu().tolist()   # one device->host copy for the whole call (reference: .item() per step)
 

@@ -348,6 +348,12 @@ def peek(ctx, which, count, dtype=torch.int32):
     return out
 
 
+def settle(ctx):
+    """Wait for the record count of the last asynchronous training step; raises St3rError (code -3) if that step outgrew
+    its buffers (its Adam update was skipped on the device)."""
+    _lib.check(_lib.lib().st3r_ctx_settle(ctx.handle))
+
+
 def set_debug(ctx, flags):
     """bit 0: blend forward without the per-quadrant relevance test (tests only)."""
     _lib.check(_lib.lib().st3r_ctx_set_debug(ctx.handle, int(flags)))

@@ -19,11 +19,11 @@ pair list, reciprocal matching, the resumable disk cache (starst3r_amd.forward),
 the per-pair cache of Mast3r's forward_mast3r (see starst3r_amd.condense for the layout; tensors or torch.save
 paths) plus the resized images -- condensation and alignment then run here --, or
       model.condense(imgs, filelist, device, cache_dir) -> dict
-returning the already condensed problem in starst3r_amd.synth_align.flatten() layout plus
+returning the already condensed problem in st3r_synth.synth_align.flatten() layout plus
       "imgs": list of HxWx3 float arrays in [0,1] (the Mast3r-resized GT images),
       "dense": optional per-view dict(pixels [n,2], idxs [n], offsets [n], confs [n], base_focal) -- the dense
                pixels as anchors of the view's core depthmap (dense unprojection).
-starst3r_amd.synth_model.SyntheticPairwiseModel implements it on synthetic scenes (BASELINE configs[0]).
+st3r_synth.synth_model.SyntheticPairwiseModel implements it on synthetic scenes (BASELINE configs[0]).
 """
 __all__ = ("reconstruct_scene", "reconstruct", "run_sparse_ga", "sparse_scene_optimizer_slam",
            "flatten_reference_inputs")
@@ -84,7 +84,7 @@ def flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchor
                              matching_conf_thr=5.0):
     """The set-up block of the reference optimiser (starster/reconstruct.py:148-207, 263-309) restated as array
     plumbing: takes the SAME objects `sparse_scene_optimizer_slam` receives from Mast3r's condense_data and returns
-    the flat layout the C ABI consumes (starst3r_amd.synth_align.flatten documents it).
+    the flat layout the C ABI consumes (st3r_synth.synth_align.flatten documents it).
 
       anchors   {img index: (pixels [n,2], idxs [n], offsets [n])}
       corres    (_, _, imgs_slices) with .img1 .slice1 .img2 .slice2 .confs per ORDERED pair

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from oracle import gs_oracle as go
 from starst3r_amd import dist as sdist
-from starst3r_amd import synth
+from st3r_synth import synth
 
 N, V, W, H = 120, 4, 48, 32
 
@@ -214,14 +214,20 @@ def _pairs_of(n):
     return [(imgs[i], imgs[j]) for i in range(n) for j in range(i + 1, n)]
 
 
-def _forward_worker(rank, world, port, base):
+def _forward_worker(rank, world, port, base, uneven=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     from starst3r_amd import forward
-    from starst3r_amd.synth_model import SyntheticNetwork
+    from st3r_synth.synth_model import SyntheticNetwork
     forward.extract_correspondences = _cpu_extract_correspondences
     net = SyntheticNetwork(n_views=4, width=64, height=48, seed=1)
     cache = os.path.join(base, f"rank{rank}")            # rank-private caches: the exchange has to fill them
+    if uneven and rank == 1:
+        # the caches start in DIFFERENT states: rank 1 already holds the pairs among views 0..2 (the ranks
+        # used to deal from their own lists of missing pairs; now they deal the union of what is missing anywhere)
+        sub = [p for p in _pairs_of(4) if p[0]["idx"] < 3 and p[1]["idx"] < 3]
+        forward.forward_mast3r(sub, net, cache, device="cpu", subsample=8, shard=False)
+        net.calls = 0
     res, _ = forward.forward_mast3r(_pairs_of(4), net, cache, device="cpu", subsample=8)
     assert net.calls == 3, net.calls                     # 6 pairs over 2 ranks
     assert len(res) == 6
@@ -233,12 +239,13 @@ def _forward_worker(rank, world, port, base):
     torch.distributed.destroy_process_group()
 
 
-def test_pair_sharding_fills_every_ranks_cache(tmp_path):
+@pytest.mark.parametrize("uneven", [False, True])
+def test_pair_sharding_fills_every_ranks_cache(tmp_path, uneven):
     from starst3r_amd import forward
-    from starst3r_amd.synth_model import SyntheticNetwork
+    from st3r_synth.synth_model import SyntheticNetwork
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    mp.spawn(_forward_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_forward_worker, args=(2, port, str(tmp_path), uneven), nprocs=2, join=True)
     # single-process reference with the same stand-in matcher
     keep = forward.extract_correspondences
     forward.extract_correspondences = _cpu_extract_correspondences
@@ -312,6 +319,7 @@ def _mock_ops(monkey_ops, g_keys=("means", "quats", "scales", "opacities", "shN"
     monkey_ops.adam_step = adam_step
     monkey_ops.train_step = train_step
     monkey_ops.get_context = lambda device: type("Ctx", (), {"native_comm": False, "device": "cpu"})()
+    monkey_ops.settle = lambda ctx: None     # the stand-in steps are synchronous: nothing is ever in flight
     return calls
 
 

@@ -95,7 +95,7 @@ def _perturbed_params(C, seed):
 def test_analytic_gradient_vs_oracle_autograd(stage):
     """Hand-derived gradient of the HIP path vs torch autograd of the oracle at a generic (non-degenerate)
     parameter point.  After exactly one Adam step from zero moments m = (1 - 0.9) * g, so g = 10 * m."""
-    from starst3r_amd import synth_align
+    from st3r_synth import synth_align
     C = 4
     flat = synth_align.flatten(synth_align.make_problem(n_views=C, n_corr=200, seed=11, bad_pair=True))
     prev = _perturbed_params(C, 5)
@@ -125,7 +125,7 @@ def test_analytic_gradient_vs_oracle_autograd(stage):
 
 def test_warm_start_splices_previous_params():
     """prev_params of a 2-view solve seed the first 2 views of a 3-view problem (reconstruct.py:408-415)."""
-    from starst3r_amd import synth_align
+    from st3r_synth import synth_align
     f2 = synth_align.flatten(synth_align.make_problem(n_views=2, n_corr=200, seed=3))
     _, p2 = run_hip(f2, niter1=50, niter2=0)
     f3 = synth_align.flatten(synth_align.make_problem(n_views=3, n_corr=200, seed=3))
@@ -142,7 +142,7 @@ def test_reference_signature_optimiser_equals_flat_path_and_warm_starts():
     condense_data produces -- runs the same kernels on the same arrays as align.run(flatten(P)), returns the
     reference's tuple, and accepts its own params_ret (lists of per-view tensors) as prev_params."""
     import importlib
-    from starst3r_amd import synth_align as sa
+    from st3r_synth import synth_align as sa
     rc = importlib.import_module("starst3r_amd.reconstruct")
     P = sa.make_problem(n_views=4, n_corr=300, seed=5, bad_pair=True)
     a = sa.to_reference_inputs(P)
@@ -180,7 +180,7 @@ def test_alignment_is_bit_reproducible():
     """No float atomics on path B (per-wave LDS accumulators, per-workgroup partials added in order, fixed-order
     chain sums): two runs of the full 500+200 schedule agree bit for bit -- gauge directions included, where the
     reference's own trajectory is rounding noise -- and so does a 200-view problem that takes the large-LDS path."""
-    from starst3r_amd import synth_align
+    from st3r_synth import synth_align
     z, flat = load("align_c4_badpair")
     a_res, a_par = run_hip(flat, niter1=500, niter2=200)
     b_res, b_par = run_hip(flat, niter1=500, niter2=200)

@@ -11,7 +11,7 @@ from oracle import gs_oracle as go
 
 def test_scene_pipeline_end_to_end():
     import starst3r_amd as st
-    from starst3r_amd.synth_model import SyntheticPairwiseModel
+    from st3r_synth.synth_model import SyntheticPairwiseModel
     model = SyntheticPairwiseModel(width=128, height=96, n_corr=300, seed=2)
     scene = st.Scene(device="cuda:0")
     raw = [torch.zeros(3, 96, 128) for _ in range(2)]
@@ -45,7 +45,7 @@ def test_scene_pipeline_end_to_end():
 
 def test_autograd_through_render_matches_oracle():
     import starst3r_amd as st
-    from starst3r_amd import synth
+    from st3r_synth import synth
     N, V, W, H = 300, 2, 64, 48
     g, w2c, Ks = synth.make_scene(N, V, W, H, seed=9, scale_lo=0.02, scale_hi=0.1)
     scene = st.Scene(device="cuda:0")
@@ -70,7 +70,8 @@ def test_async_steps_equal_synchronous_steps_and_overflow_is_loud():
     inputs; a step that outgrows the capacity derived from the previous count makes the NEXT call fail with
     ST3R_ERR_CAPACITY, after which the context recovers on the synchronous path."""
     import numpy as np
-    from starst3r_amd import _lib, ops, synth
+    from starst3r_amd import _lib, ops
+    from st3r_synth import synth
     ctx = ops.Context("cuda:0")     # a private context: the record-count hint is per context
     N, V, W, H = 20000, 3, 320, 240
     g, w2c, Ks = synth.make_scene(N, V, W, H, seed=5, scale_lo=0.004, scale_hi=0.03)
@@ -118,13 +119,68 @@ def test_async_steps_equal_synchronous_steps_and_overflow_is_loud():
 
 
 @pytest.mark.gpu
+def test_overflowing_async_step_writes_nothing_out_of_bounds_and_skips_its_update():
+    """A FRESH context (its scratch was never sized for the full record count) takes one synchronous step, then an
+    asynchronous step whose capacity the test hook halves: the step's slot indices (scan over the TRUE tile counts) exceed
+    the slots the gradient buffer has -- the blend backward must not write them (out-of-bounds in
+    k_blend_bwd / k_gather_vtile) --, its Adam update is skipped on the device, st3r_ctx_settle reports the overflow, and
+    repeating the step gives exactly the parameters of an undisturbed run."""
+    import numpy as np
+    from starst3r_amd import _lib, ops
+    from st3r_synth import synth
+    N, V, W, H = 20000, 3, 320, 240
+    g, w2c, Ks = synth.make_scene(N, V, W, H, seed=5, scale_lo=0.004, scale_hi=0.03)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda:0")
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    P0 = {k: dev(v) for k, v in g.items()}
+    ref_ctx = ops.Context("cuda:0")
+    rgb, _, _ = ops.render(ref_ctx, P0, vm, K, campos, W, H)
+    gt = torch.clamp(rgb + 0.05 * torch.randn_like(rgb), 0, 1).contiguous()
+
+    def steps(ctx, overflow_at):
+        P = {k: v.clone() for k, v in P0.items()}
+        grads = torch.empty(23 * N, device="cuda:0"); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+        loss = torch.zeros(1, device="cuda:0")
+        it = 1
+        while it <= 3:
+            before = {k: x.clone() for k, x in P.items()} if it == overflow_at else None
+            if it == overflow_at:
+                ops.set_debug(ctx, 8)
+            # (no statistics asked for: the first step of a context still sizes its buffers exactly and leaves the hint the
+            # asynchronous steps after it size theirs from)
+            ops.train_step(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it, loss,
+                           want_stats=False)
+            ops.set_debug(ctx, 0)
+            if it == overflow_at:
+                overflow_at = -1
+                with pytest.raises(_lib.St3rError) as e:
+                    ops.settle(ctx)
+                assert e.value.code == -3 and "NOT apply" in str(e.value)
+                for k in P:   # the update of the overflowing step did not happen
+                    assert torch.equal(P[k], before[k]), k
+                continue      # repeat the same iteration
+            it += 1
+        torch.cuda.synchronize()
+        return P, m, v
+    Pa, ma, va = steps(ref_ctx, -1)
+    ctx = ops.Context("cuda:0")   # fresh arena
+    Pb, mb, vb = steps(ctx, 2)
+    for k in Pa:
+        assert torch.equal(Pa[k], Pb[k]), k
+    assert torch.equal(ma, mb) and torch.equal(va, vb)
+    ctx.close(); ref_ctx.close()
+
+
+@pytest.mark.gpu
 def test_view_chunks_give_the_gradients_of_the_whole_call():
     """A call above 2^31 tile intersections walks its views in chunks (st3r_gs_train_fwd_bwd; here forced by debug
     flag 32 on a small scene): loss, statistics and parameter gradients equal those of the one-pass call -- the loss
     is a sum over views (starster/gs.py:149-152); the float sums of the gradients associate differently, hence a
     tolerance -- and the chunk count sticks to the context."""
     import numpy as np
-    from starst3r_amd import ops, synth
+    from starst3r_amd import ops
+    from st3r_synth import synth
     ctx = ops.Context("cuda:0")
     N, V, W, H = 30000, 5, 320, 240
     g, w2c, Ks = synth.make_scene(N, V, W, H, seed=11, scale_lo=0.004, scale_hi=0.03)

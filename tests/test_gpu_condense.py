@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import condense_oracle as co
-from starst3r_amd import synth_pairs
+from st3r_synth import synth_pairs
 
 pytestmark = pytest.mark.gpu
 
@@ -164,7 +164,7 @@ def test_scene_from_pair_predictions():
     """Scene.add_images with a model that only supplies pair predictions: condensation, alignment, dense seeding and
     a few 3DGS iterations all run in the library; the seeded points lie on the synthetic unit sphere."""
     import starst3r_amd as st
-    from starst3r_amd.synth_model import SyntheticPairModel
+    from st3r_synth.synth_model import SyntheticPairModel
     sc = st.Scene(device="cuda:0")
     sc.add_images(SyntheticPairModel(width=128, height=96, n_corr=600, seed=4), [torch.zeros(3, 96, 128)] * 3)
     n = sum(p.shape[0] for p in sc.dense_pts)
@@ -186,7 +186,7 @@ def test_network_only_model_with_resumable_pair_cache(tmp_path):
     cached pairs (starster/scene.py:117-122, main.py:49-50): only the new pairs are inferred."""
     import os
     import starst3r_amd as st
-    from starst3r_amd.synth_model import SyntheticNetwork
+    from st3r_synth.synth_model import SyntheticNetwork
     net = SyntheticNetwork(n_views=4, width=128, height=96, seed=1)
     views = net.images()
     sc = st.Scene(device="cuda:0", cache_dir=str(tmp_path))

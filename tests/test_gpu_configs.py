@@ -13,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from starst3r_amd import synth
+from st3r_synth import synth
 
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

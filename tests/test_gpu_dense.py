@@ -89,7 +89,7 @@ def test_unproject_and_clean_vs_oracle(seed, C, H, W):
 
 def test_scene_seeding_uses_cleaned_confidences():
     import starst3r_amd as st
-    from starst3r_amd.synth_model import SyntheticPairwiseModel
+    from st3r_synth.synth_model import SyntheticPairwiseModel
     model = SyntheticPairwiseModel(width=128, height=96, n_corr=300, seed=2)
     sc = st.Scene(device=DEV)
     sc.add_images(model, [torch.zeros(3, 96, 128) for _ in range(3)])

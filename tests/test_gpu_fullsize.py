@@ -18,7 +18,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from starst3r_amd import synth
+from st3r_synth import synth
 
 DEV = "cuda:0"
 N, V, W, H = 1_000_000, 8, 1920, 1080

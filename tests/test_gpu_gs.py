@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import gs_oracle as go
-from starst3r_amd import synth
+from st3r_synth import synth
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import gs_oracle as go
 from oracle import gs_torch_ref as tr
-from starst3r_amd import synth
+from st3r_synth import synth
 
 
 def psnr(a, b):

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from starst3r_amd import synth
+from st3r_synth import synth
 
 DEV = torch.device("cuda:0")
 
@@ -149,7 +149,7 @@ def test_scene_run_3dgs_optim_sharded_layout_equals_replicated(monkeypatch):
     """Scene.run_3dgs_optim on the Gaussian-sharded layout (forced with one rank) leaves the same parameters, optimiser
     state and losses as the default single-process path, starting from the same scene state."""
     import starst3r_amd as st
-    from starst3r_amd.synth_model import SyntheticPairwiseModel
+    from st3r_synth.synth_model import SyntheticPairwiseModel
     model = SyntheticPairwiseModel(width=128, height=96, n_corr=300, seed=2)
     sc = st.Scene(device="cuda:0")
     sc.add_images(model, [torch.zeros(3, 96, 128) for _ in range(2)])
@@ -197,7 +197,7 @@ def test_scene_sharded_layout_with_pruning_equals_replicated(monkeypatch):
     gather -> relocate / grow on the full set -> shard again, noise per shard -- the same Gaussian count, losses and
     parameters as the replicated loop."""
     import starst3r_amd as st
-    from starst3r_amd.synth_model import SyntheticPairwiseModel
+    from st3r_synth.synth_model import SyntheticPairwiseModel
     keys = ("means", "quats", "scales", "opacities", "shN")
 
     def run(sharded):

@@ -6,7 +6,7 @@ import importlib
 import numpy as np
 import pytest
 
-from starst3r_amd import synth_align as sa
+from st3r_synth import synth_align as sa
 
 rc = importlib.import_module("starst3r_amd.reconstruct")
 

@@ -5,7 +5,7 @@ import itertools
 import numpy as np
 
 from oracle import condense_oracle as co
-from starst3r_amd import synth_pairs
+from st3r_synth import synth_pairs
 
 
 def _maps_of(P, img):

@@ -13,7 +13,7 @@ import torch
 
 from oracle import gs_oracle as go
 from oracle import gs_torch_ref as tr
-from starst3r_amd import synth
+from st3r_synth import synth
 from kat_scenes import cam_front as _cam_front, sh_const as _sh_const, radius_kat_scene as _radius_kat_scene
 
 

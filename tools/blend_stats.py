@@ -2,7 +2,8 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from starst3r_amd import ops, synth, _lib
+from starst3r_amd import ops, _lib
+from st3r_synth import synth
 ctx = ops.get_context("cuda:0")
 N, V, W, H = 1_000_000, 8, 1920, 1080
 g, w2c, Ks = synth.make_scene(N, V, W, H)

@@ -15,7 +15,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from starst3r_amd import synth  # noqa: E402
+from st3r_synth import synth  # noqa: E402
 
 
 def quat_to_rot(q):

@@ -2,7 +2,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import gs_oracle as go
-from starst3r_amd import ops, synth
+from starst3r_amd import ops
+from st3r_synth import synth
 ctx = ops.get_context("cuda:0")
 N,V,W,H = 400,3,96,64
 g,w2c,Ks = synth.make_scene(N,V,W,H,seed=7,scale_lo=0.01,scale_hi=0.08)

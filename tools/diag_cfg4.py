@@ -1,7 +1,8 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
-from starst3r_amd import ops, synth
+from starst3r_amd import ops
+from st3r_synth import synth
 DEV="cuda:0"
 ctx = ops.get_context(DEV)
 n, v, w, h = 5_000_000, 8, 3840, 2160

@@ -3,7 +3,7 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
 import starst3r_amd as st
-from starst3r_amd.synth_model import SyntheticNetwork
+from st3r_synth.synth_model import SyntheticNetwork
 outs = []
 for rep in range(3):
     net = SyntheticNetwork(n_views=3, width=128, height=96, seed=2)

@@ -107,7 +107,7 @@ def load_reference():
     return m
 
 
-from starst3r_amd.synth_align import Slice, to_reference_inputs  # noqa: E402  (shared with the product's B1 tests)
+from st3r_synth.synth_align import Slice, to_reference_inputs  # noqa: E402  (shared with the product's B1 tests)
 
 
 def _to_f64(x):
@@ -153,7 +153,7 @@ def run_reference(ref, P, niter1, niter2, f64=False):
 
 
 def main():
-    from starst3r_amd import synth_align
+    from st3r_synth import synth_align
     ref = load_reference()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)

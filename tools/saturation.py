@@ -6,7 +6,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
-from starst3r_amd import ops, synth
+from starst3r_amd import ops
+from st3r_synth import synth
 
 N, V, W, H = 1_000_000, 8, 1920, 1080
 g, w2c, Ks = synth.make_scene(N, V, W, H, seed=0)

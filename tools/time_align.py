@@ -1,7 +1,8 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
-from starst3r_amd import align, synth_align
+from starst3r_amd import align
+from st3r_synth import synth_align
 for C in (2, 8, 32):
     flat = synth_align.flatten(synth_align.make_problem(n_views=C, n_corr=2000 // max(C - 1, 1) + 1, seed=1))
     align.run(flat, niter1=5, niter2=5); torch.cuda.synchronize()

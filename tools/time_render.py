@@ -4,7 +4,8 @@ so the whole call is timed: the front end is identical in both)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
-from starst3r_amd import ops, synth
+from starst3r_amd import ops
+from st3r_synth import synth
 
 N, V, W, H = 1_000_000, 8, 1920, 1080
 g, w2c, Ks = synth.make_scene(N, V, W, H)
