@@ -185,11 +185,23 @@ def test_backward_vs_oracle(ctx, name):
     vs = v_splats[pid].cpu().numpy()
     pk = go_grads["packed"]
 
+    dist = {}
+    # measured (round 3): regular scenes median <= 7e-7, p99 <= 4e-5; stress scenes median <= 4e-5, p99 <= 5e-3
+    MED_BOUND, P99_BOUND = (1e-4, 1e-2) if name.startswith("fuzz") else (2e-6, 1e-4)
+
     def close(a, b, name, tol=2e-4):
-        # float atomics are order dependent: tolerance relative to the tensor's max magnitude
+        # the bound: relative to the tensor's max magnitude (the sums group differently in kernel and oracle) ...
         scale = np.abs(b).max() + 1e-20
         err = np.abs(a - b).max() / scale
         assert err < tol, (name, err)
+        # ... which says nothing about small-gradient Gaussians, so the DISTRIBUTION of the element-wise relative error
+        # is pinned as well, over the elements above 1e-4 of the maximum (below that the float32 sums are rounding noise)
+        big = np.abs(b) > 1e-4 * scale
+        if big.sum() >= 50:
+            rel = np.abs(a - b)[big] / np.abs(b)[big]
+            med, p99 = float(np.median(rel)), float(np.percentile(rel, 99))
+            dist[name] = (med, p99)
+            assert med <= MED_BOUND and p99 <= P99_BOUND, (name, med, p99)
     close(vs[:, 0:2], pk["v_means2d"], "v_means2d")
     close(vs[:, 2], pk["v_opacities"], "v_opacities")
     close(vs[:, 3:6], pk["v_conics"], "v_conics")
@@ -201,6 +213,7 @@ def test_backward_vs_oracle(ctx, name):
     # (stress scenes: needle-shaped Gaussians make the covariance chain rule sum terms far larger than the result)
     for k in ("means", "quats", "scales", "opacities", "sh"):
         close(G[k], go_grads[k], k, tol=4e-3 if name.startswith("fuzz") else 1e-3)
+    print(name, "relative gradient error (median, p99):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in dist.items()})
 
 
 def test_backward_is_deterministic(ctx):
