@@ -43,7 +43,11 @@ class Problem:
         self.pps0 = t("pps") / self.imsizes                        # reconstruct.py:170
         self.base_focals = t("base_focals")
         cd = t("core_depth")
-        self.median = cd.median(dim=1).values                      # :176
+        # views of different image sizes: rows padded to the longest, core_len = the true lengths (the reference keeps
+        # per-view lists, reconstruct.py:170-177); the median of a view is taken over its own values
+        clen = [int(x) for x in np.asarray(flat["core_len"]).reshape(-1)] if "core_len" in flat else [cd.shape[1]] * cd.shape[0]
+        self.core_len = clen
+        self.median = torch.stack([cd[v, :clen[v]].median() for v in range(cd.shape[0])])   # :176
         self.core = cd / self.median[:, None]                      # :177
         self.anchor_pix = t("anchor_pix"); self.anchor_idx = t("anchor_idx", torch.int64)
         self.anchor_offset = t("anchor_offset"); self.anchor_img = t("anchor_img", torch.int64)
@@ -187,4 +191,6 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev=None, dtype=torc
                             losses=losses)                                                         # :430-440
     params = {k: v.detach().numpy().copy() for k, v in p.items()}
     params["core_depth"] = pb.core.numpy().copy()
-    return {k: v.numpy() for k, v in res.items()}, params
+    out = {k: v.numpy() for k, v in res.items()}
+    out["core_len"] = np.asarray(pb.core_len, np.int64)      # true lengths of the padded core-depth rows
+    return out, params

@@ -29,9 +29,13 @@ def _look_at_c2w(eye, target=(0, 0, 0), up=(0, 0, 1)):
     return M
 
 
-def make_problem(n_views=2, width=512, height=384, n_corr=2000, seed=0, bad_pair=False, noise=0.01):
+def make_problem(n_views=2, width=512, height=384, n_corr=2000, seed=0, bad_pair=False, noise=0.01, sizes=None):
     """n_corr = correspondences per ordered view pair; bad_pair makes pair (0, C-1) fail the
-    matching-confidence gate so the DUSt3R-regression fallback (reconstruct.py:311-323) is exercised."""
+    matching-confidence gate so the DUSt3R-regression fallback (reconstruct.py:311-323) is exercised.
+    sizes: per-view (width, height) -- e.g. one landscape and one portrait photo: the reference keeps per-view lists
+    (reconstruct.py:170-177, 276) and accepts them; core_depth is then a LIST of arrays of different lengths."""
+    if sizes is not None:
+        return _make_problem_mixed(n_views, sizes, n_corr, seed, bad_pair, noise)
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     C, W, H, S = n_views, width, height, 8
     gw, gh = W // S, H // S
@@ -120,6 +124,101 @@ def make_problem(n_views=2, width=512, height=384, n_corr=2000, seed=0, bad_pair
                 c2w_true=np.stack(c2w).astype(np.float32), K_true=K_true.astype(np.float32))
 
 
+def _make_problem_mixed(n_views, sizes, n_corr, seed, bad_pair, noise):
+    """make_problem with a (width, height) per view: same scene (unit sphere), same focal length for every camera."""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    C, S = n_views, 8
+    assert len(sizes) == C
+    Ws = [int(w) for w, _ in sizes]; Hs = [int(h) for _, h in sizes]
+    f_true = 1.1 * max(max(Ws), max(Hs))
+    c2w = [_look_at_c2w((2.5 * math.cos(0.5 * k), 2.5 * math.sin(0.5 * k), 0.3 * math.sin(1.3 * k))) for k in range(C)]
+    w2c = [np.linalg.inv(m) for m in c2w]
+
+    def depth_of(view, px):
+        W, H = Ws[view], Hs[view]
+        rays = np.stack([(px[:, 0] - W / 2) / f_true, (px[:, 1] - H / 2) / f_true, np.ones(len(px))], -1)
+        R, o = c2w[view][:3, :3], c2w[view][:3, 3]
+        d = rays @ R.T
+        b = d @ o; a = (d * d).sum(-1); cc = o @ o - 1.0
+        disc = b * b - a * cc
+        t = (-b - np.sqrt(np.maximum(disc, 0))) / a
+        t[disc < 0] = np.nan
+        return t
+
+    core_depth = []
+    for v in range(C):
+        gw, gh = Ws[v] // S, Hs[v] // S
+        gy, gx = np.mgrid[0:gh, 0:gw]
+        px = np.stack([gx.reshape(-1) * S + S / 2, gy.reshape(-1) * S + S / 2], -1).astype(np.float64)
+        d = depth_of(v, px)
+        d[np.isnan(d)] = 3.5
+        core_depth.append((d * (1 + noise * rng.standard_normal(d.shape))).astype(np.float32))
+    anchors = [dict(pixels=[], idxs=[], offsets=[]) for _ in range(C)]
+    pairs = []
+    for i in range(C):
+        for j in range(i + 1, C):
+            pts = rng.standard_normal((n_corr * 6, 3)); pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+            keep, proj = [], {}
+            for v in (i, j):
+                W, H = Ws[v], Hs[v]
+                pc = pts @ w2c[v][:3, :3].T + w2c[v][:3, 3]
+                uv = np.stack([f_true * pc[:, 0] / pc[:, 2] + W / 2, f_true * pc[:, 1] / pc[:, 2] + H / 2], -1)
+                facing = (pts * (c2w[v][:3, 3] - pts)).sum(-1) > 0.05
+                inside = (uv[:, 0] > 1) & (uv[:, 0] < W - 2) & (uv[:, 1] > 1) & (uv[:, 1] < H - 2)
+                keep.append(facing & inside & (pc[:, 2] > 0.1)); proj[v] = (uv, pc[:, 2])
+            ok = np.nonzero(keep[0] & keep[1])[0][:n_corr]
+            n = len(ok)
+            if n == 0:
+                continue
+            starts = {}
+            for v in (i, j):
+                gw = Ws[v] // S
+                uv, z = proj[v][0][ok], proj[v][1][ok]
+                uv = uv + 0.3 * rng.standard_normal(uv.shape)
+                idx = (np.floor(uv[:, 1] / S).astype(np.int64) * gw + np.floor(uv[:, 0] / S).astype(np.int64))
+                off = z / core_depth[v][idx]
+                starts[v] = sum(len(a) for a in anchors[v]["idxs"])
+                anchors[v]["pixels"].append(uv.astype(np.float32)); anchors[v]["idxs"].append(idx)
+                anchors[v]["offsets"].append(off.astype(np.float32))
+            confs = rng.uniform(1.0, 12.0, n).astype(np.float32)
+            if bad_pair and (i, j) == (0, C - 1):
+                confs = rng.uniform(1.0, 4.5, n).astype(np.float32)
+            pairs.append((i, j, int(starts[i]), int(starts[j]), n, confs))
+    for v in range(C):
+        a = anchors[v]
+        a["pixels"] = np.concatenate(a["pixels"]).astype(np.float32)
+        a["idxs"] = np.concatenate(a["idxs"]).astype(np.int64)
+        a["offsets"] = np.concatenate(a["offsets"]).astype(np.float32)
+    imsizes = np.array([[Ws[v], Hs[v]] for v in range(C)], np.int64)
+    pps = (np.array([[Ws[v] / 2, Hs[v] / 2] for v in range(C)]) + 3.0 * rng.standard_normal((C, 2))).astype(np.float32)
+    base_focals = (f_true * (1 + 0.05 * rng.standard_normal(C))).astype(np.float32)
+    mst = (0, [(k, k + 1) for k in range(C - 1)])
+    preds_21 = {}
+    for (i, j, ai, aj, n, confs) in pairs:
+        if confs.max() > 5.0:
+            continue
+        for (i1, i2) in ((i, j), (j, i)):
+            a = anchors[i1]
+            z = core_depth[i1][a["idxs"]] * a["offsets"]
+            pc1 = np.stack([(a["pixels"][:, 0] - Ws[i1] / 2) / f_true * z, (a["pixels"][:, 1] - Hs[i1] / 2) / f_true * z, z], -1)
+            pw = pc1 @ c2w[i1][:3, :3].T + c2w[i1][:3, 3]
+            pc2 = pw @ w2c[i2][:3, :3].T + w2c[i2][:3, 3]
+            preds_21[(i2, i1)] = (pc2.astype(np.float32), rng.uniform(1.0, 3.0, len(z)).astype(np.float32))
+    return dict(n_views=C, width=None, height=None, subsample=S, imsizes=imsizes, pps=pps, base_focals=base_focals,
+                core_depth=core_depth, anchors=anchors, pairs=pairs, mst=mst, preds_21=preds_21,
+                c2w_true=np.stack(c2w).astype(np.float32), f_true=np.float32(f_true))
+
+
+def pad_core_depth(core_depth):
+    """list of per-view core-depth vectors (or a [C, G] array) -> ([C, Gmax] float32 padded with 1, lengths int64 [C])."""
+    rows = [np.asarray(d, np.float32).reshape(-1) for d in core_depth]
+    lens = np.array([len(r) for r in rows], np.int64)
+    out = np.ones((len(rows), int(lens.max())), np.float32)
+    for v, r in enumerate(rows):
+        out[v, :len(r)] = r
+    return out, lens
+
+
 def flatten(problem):
     """Problem -> flat dict of numpy arrays (npz friendly, and the layout the C ABI consumes):
       anchor arrays concatenated over views with anchor_off [C+1];
@@ -133,8 +232,9 @@ def flatten(problem):
     anchor_off = np.zeros(C + 1, np.int64)
     for v in range(C):
         anchor_off[v + 1] = anchor_off[v] + len(P["anchors"][v]["idxs"])
+    core, core_len = pad_core_depth(P["core_depth"])   # views of different sizes: rows padded to the longest
     out = dict(n_views=np.int64(C), imsizes=P["imsizes"], pps=P["pps"], base_focals=P["base_focals"],
-               core_depth=P["core_depth"], anchor_off=anchor_off,
+               core_depth=core, core_len=core_len, anchor_off=anchor_off,
                anchor_pix=np.concatenate([P["anchors"][v]["pixels"] for v in range(C)]),
                anchor_idx=np.concatenate([P["anchors"][v]["idxs"] for v in range(C)]),
                anchor_offset=np.concatenate([P["anchors"][v]["offsets"] for v in range(C)]),

@@ -28,7 +28,14 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
     base_focals = f32(flat["base_focals"])
     core_raw = f32(flat["core_depth"])
     G = core_raw.shape[1]
-    median = core_raw.median(dim=1).values.contiguous()                 # reconstruct.py:176
+    # views of different image sizes have core-depth vectors of different lengths (the reference keeps per-view lists,
+    # reconstruct.py:170-177, 276): the rows are padded to the longest, core_len holds the true lengths, the median of a
+    # view is taken over its own values
+    core_len = [int(x) for x in np.asarray(flat["core_len"]).reshape(-1)] if "core_len" in flat else [G] * Cn
+    if all(n == G for n in core_len):
+        median = core_raw.median(dim=1).values.contiguous()             # reconstruct.py:176
+    else:
+        median = torch.stack([core_raw[v, :core_len[v]].median() for v in range(Cn)]).contiguous()
     core = (core_raw / median[:, None]).contiguous()                    # :177
     diags = imsizes.norm(dim=1)
     min_f = (0.25 * diags).contiguous(); max_f = (10 * diags).contiguous()  # :203-205
@@ -61,14 +68,16 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
             P[k][:n] = prev[:n].reshape(P[k][:n].shape)
         if prev_params.get("core_depth") is not None:   # reconstruct.py:414: the old views keep their core depth
             prev = prev_params["core_depth"]
-            if isinstance(prev, (list, tuple)):
-                prev = torch.stack([torch.as_tensor(x).reshape(-1) for x in prev])
-            prev = (prev.detach() if torch.is_tensor(prev) else torch.as_tensor(np.asarray(prev))).to(dev, torch.float32)
-            n = min(prev.shape[0], Cn)
-            if prev.shape[1] != core.shape[1]:
-                raise ValueError(f"warm start: the previous core depth has {prev.shape[1]} values per view, this call "
-                                 f"{core.shape[1]} (image size or subsampling changed between add_images calls)")
-            core[:n] = prev[:n]
+            prev_len = prev_params.get("core_len")
+            rows = list(prev) if isinstance(prev, (list, tuple)) else [prev[v] for v in range(prev.shape[0])]
+            for v in range(min(len(rows), Cn)):                         # spliced view by view: lengths may differ
+                r = torch.as_tensor(rows[v]).detach().reshape(-1).to(dev, torch.float32)
+                if prev_len is not None:
+                    r = r[:int(prev_len[v])]
+                if r.numel() != core_len[v]:
+                    raise ValueError(f"warm start: view {v} had {r.numel()} core depths, this call has {core_len[v]} "
+                                     "(image size or subsampling changed between add_images calls)")
+                core[v, :core_len[v]] = r
     work = torch.zeros(66 * Cn + 8, device=dev)
     cam = torch.empty(Cn, 24, device=dev)
     A = anchor_idx.numel()
@@ -94,4 +103,6 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
                _adam_m=work[:11 * Cn].clone())  # first moments, order pps|log_focals|quats|trans|log_sizes (tests)
     params = dict(P)
     params["core_depth"] = core
+    params["core_len"] = core_len          # true lengths of the padded rows (views of different sizes)
+    res["core_len"] = core_len
     return res, params

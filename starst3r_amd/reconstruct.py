@@ -99,18 +99,20 @@ def flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchor
         return np.ascontiguousarray(x).astype(dt)
 
     C = len(imgs)
-    grid_sizes = sorted({int(np.prod(np.shape(npy(d, np.float32)))) for d in core_depth})
-    if len(grid_sizes) > 1:
-        # the reference (and Mast3r) keep per-view lists and accept mixed aspect ratios; st3r_align_run takes one
-        # [C, G] block -- fail loudly instead of stacking ragged rows
-        raise ValueError(f"views with different subsampled depth-grid sizes {grid_sizes} are not supported by "
-                         "st3r_align_run: resize the images to one size (Scene.add_images does)")
+    # the reference (and Mast3r) keep per-view lists and accept mixed image sizes (reconstruct.py:170-177, 276);
+    # st3r_align_run takes one [C, G] block: the rows are padded to the longest view, `core_len` keeps the true lengths
+    # (an anchor only ever indexes its own view's part)
+    rows = [npy(d, np.float32).reshape(-1) for d in core_depth]
+    core_len = np.array([len(r) for r in rows], np.int64)
+    core_pad = np.ones((C, int(core_len.max())), np.float32)
+    for v, r in enumerate(rows):
+        core_pad[v, :len(r)] = r
     counts = [len(anchors[v][1]) for v in range(C)]
     anchor_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     rng = lambda sl, n: np.arange(n)[sl]
     out = dict(n_views=np.int64(C), imsizes=npy(imsizes, np.int64), pps=npy(torch.stack(list(pps)) if isinstance(pps, (list, tuple)) else pps, np.float32),
                base_focals=npy(torch.stack([torch.as_tensor(f).reshape(()) for f in base_focals]) if isinstance(base_focals, (list, tuple)) else base_focals, np.float32).reshape(-1),
-               core_depth=np.stack([npy(d, np.float32).reshape(-1) for d in core_depth]), anchor_off=anchor_off,
+               core_depth=core_pad, core_len=core_len, anchor_off=anchor_off,
                anchor_pix=np.concatenate([npy(anchors[v][0], np.float32) for v in range(C)]),
                anchor_idx=np.concatenate([npy(anchors[v][1], np.int64) for v in range(C)]),
                anchor_offset=np.concatenate([npy(anchors[v][2], np.float32) for v in range(C)]),
@@ -174,10 +176,12 @@ def sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core
                             loss_dust3r_w=loss_dust3r_w, device=dev)
     off = flat["anchor_off"]
     C = len(imgs)
-    out = dict(intrinsics=res["intrinsics"], cam2w=res["cam2w"], depthmaps=[res["depthmaps"][v] for v in range(C)],
+    clen = flat["core_len"]
+    out = dict(intrinsics=res["intrinsics"], cam2w=res["cam2w"],
+               depthmaps=[res["depthmaps"][v][:int(clen[v])] for v in range(C)],
                pts3d=[res["pts3d"][int(off[v]):int(off[v + 1])] for v in range(C)], losses=res["losses"], _res=res)
-    params_ret = {k: [params[k][v] for v in range(C)] for k in ("pps", "log_focals", "quats", "trans", "log_sizes",
-                                                                   "core_depth")}
+    params_ret = {k: [params[k][v] for v in range(C)] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")}
+    params_ret["core_depth"] = [params["core_depth"][v][:int(clen[v])] for v in range(C)]
     return imgs, out, (out if niter2 else None), params_ret
 
 

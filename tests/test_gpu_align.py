@@ -22,7 +22,7 @@ def run_hip(flat, **kw):
     from starst3r_amd import align
     res, params = align.run(flat, **kw)
     torch.cuda.synchronize()
-    n = lambda t: t.detach().cpu().numpy()
+    n = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
     return {k: n(v) for k, v in res.items()}, {k: n(v) for k, v in params.items()}
 
 
@@ -36,10 +36,12 @@ def compare(a_res, a_par, b_res, b_par, tol, tag):
 def golden(z, tag):
     par = {k: z[f"{tag}__p_{k}"] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")}
     res = {k: z[f"{tag}__{k}"] for k in ("intrinsics", "cam2w", "depthmaps", "pts3d")}
+    if "in__core_len" in z.files:
+        res["core_len"] = z["in__core_len"]      # views of different sizes: padded rows
     return res, par
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
 @pytest.mark.parametrize("iters", [(1, 0), (10, 0)])
 def test_first_steps_vs_reference_golden(name, iters):
     z, flat = load(name)
@@ -48,7 +50,7 @@ def test_first_steps_vs_reference_golden(name, iters):
     compare(res, par, g_res, g_par, 1e-4, f"{name} {iters}")
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
 def test_stage2_first_step_vs_reference_golden(name):
     """500 coarse steps then ONE reprojection step: pins the loss_2d gradient (incl. focals and pps)."""
     z, flat = load(name)
@@ -62,7 +64,7 @@ def test_stage2_first_step_vs_reference_golden(name):
     assert d64 <= F32_DRIFT_BOUND["r500_0"]
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
 def test_full_schedule_vs_reference_golden(name):
     """Full 500+200 schedule against the reference's float32 result AND against its float64 evaluation: the
     reference in float32 itself ends 0.9e-4 .. 1.5e-4 from the float64 run (tests/test_oracle_align.py), so 4e-4 is
@@ -194,3 +196,45 @@ def test_alignment_is_bit_reproducible():
     assert np.isfinite(r1["losses"]).all() and np.isfinite(r1["cam2w"]).all()
     assert np.array_equal(r1["cam2w"].view(np.uint32), r2["cam2w"].view(np.uint32))
     assert np.array_equal(r1["losses"].view(np.uint32), r2["losses"].view(np.uint32))
+
+
+def test_views_of_different_sizes_through_the_reference_signature():
+    """One landscape, one portrait and one smaller photo (the reference keeps per-view lists and accepts them,
+    reconstruct.py:170-177, 276): sparse_scene_optimizer_slam returns per-view depthmaps / core depths of the views' own
+    lengths, equals the flat path, follows the reference golden (tests above), and a warm start splices view by view --
+    a view whose size changed is refused loudly."""
+    import importlib
+    from st3r_synth import synth_align as sa
+    rc = importlib.import_module("starst3r_amd.reconstruct")
+    sizes = [(512, 384), (384, 512), (384, 288)]
+    P = sa.make_problem(n_views=3, n_corr=300, seed=5, sizes=sizes)
+    a = sa.to_reference_inputs(P)
+    lens = [w // 8 * (h // 8) for w, h in sizes]
+    assert [len(d) for d in a["core_depth"]] == lens and len(set(lens)) > 1
+    _, coarse, fine, params = rc.sparse_scene_optimizer_slam(
+        a["imgs"], 8, a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"], a["corres2d"],
+        a["preds_21"], None, a["mst"], lr1=0.07, niter1=30, lr2=0.014, niter2=10, device="cuda", opt_depth=False)
+    res = fine
+    assert [d.numel() for d in res["depthmaps"]] == lens
+    assert [p.numel() for p in params["core_depth"]] == lens
+    z, flat = load("align_c3_mixed_sizes")
+    f_res, f_par = run_hip(flat, niter1=30, niter2=10)
+    n = lambda t: t.detach().cpu().numpy()
+    for v in range(3):
+        np.testing.assert_allclose(n(res["depthmaps"][v]), f_res["depthmaps"][v][:lens[v]], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(n(res["cam2w"]), f_res["cam2w"], rtol=1e-5, atol=1e-6)
+    # warm start with the same sizes: every view keeps parameters and core depth
+    _, _, _, p2 = rc.sparse_scene_optimizer_slam(
+        a["imgs"], 8, a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"], a["corres2d"],
+        a["preds_21"], None, a["mst"], lr1=0.07, niter1=0, lr2=0.014, niter2=0, device="cuda", opt_depth=False,
+        prev_params=params)
+    for v in range(3):
+        assert torch.equal(p2["core_depth"][v].cpu(), params["core_depth"][v].cpu())
+        assert torch.equal(p2["quats"][v].cpu(), params["quats"][v].cpu())
+    # a view that changed its size cannot keep its old core depth
+    bad = dict(params); bad["core_depth"] = [params["core_depth"][1], params["core_depth"][0], params["core_depth"][2][:100]]
+    with pytest.raises(ValueError):
+        rc.sparse_scene_optimizer_slam(
+            a["imgs"], 8, a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"],
+            a["corres2d"], a["preds_21"], None, a["mst"], niter1=0, niter2=0, device="cuda", opt_depth=False,
+            prev_params=bad)

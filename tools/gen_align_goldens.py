@@ -145,9 +145,10 @@ def run_reference(ref, P, niter1, niter2, f64=False):
     out = {}
     for k in ("pps", "log_focals", "quats", "trans", "log_sizes"):
         out["p_" + k] = np.stack([p.detach().numpy().reshape(-1) for p in params[k]])
-    out["p_core_depth"] = np.stack([p.detach().numpy() for p in params["core_depth"]])
+    from st3r_synth.synth_align import pad_core_depth
+    out["p_core_depth"] = pad_core_depth([p.detach().numpy() for p in params["core_depth"]])[0]   # padded if ragged
     out["intrinsics"] = res["intrinsics"].numpy(); out["cam2w"] = res["cam2w"].numpy()
-    out["depthmaps"] = np.stack([d.numpy() for d in res["depthmaps"]])
+    out["depthmaps"] = pad_core_depth([d.numpy() for d in res["depthmaps"]])[0]
     out["pts3d"] = np.concatenate([p.numpy() for p in res["pts3d"]])
     return out
 
@@ -158,7 +159,11 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     configs = [("align_c2", dict(n_views=2, n_corr=400, seed=1)),
-               ("align_c4_badpair", dict(n_views=4, n_corr=250, seed=2, bad_pair=True))]
+               ("align_c4_badpair", dict(n_views=4, n_corr=250, seed=2, bad_pair=True)),
+               # one landscape, one portrait, one smaller landscape photo: core-depth vectors of 3072 / 3072 / 1728 values
+               ("align_c3_mixed_sizes", dict(n_views=3, n_corr=300, seed=5, sizes=[(512, 384), (384, 512), (384, 288)]))]
+    only = sys.argv[1:]
+    configs = [c for c in configs if not only or c[0] in only]
     for name, kw in configs:
         P = synth_align.make_problem(**kw)
         flat = synth_align.flatten(P)
