@@ -522,10 +522,15 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                         cnt = k + 1;
                     }
                 }
+#ifndef BWD_NO_P2
                 bwd_phase2(pr, tpack, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
+#endif
             }
         };
         const bool clamp_round = (uniform_u64(sClampW) & m_cur) != 0;
+#ifdef BWD_NO_WALK
+        if (tight < 0)
+#endif
         if (chk_index) {
             if (clamp_round) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{});
         } else {
@@ -535,7 +540,11 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM.  Slot indices come from the
         // scan over the TRUE tile counts; in an asynchronous step that outgrew its capacity they can exceed the slots the
         // buffer has (that step is discarded anyway): such a record is not written (unsigned: a wrapped index too)
+#ifdef BWD_NO_FLUSH
+        if (my_cb && (unsigned)my_u < vt_cap && tight < 0) {
+#else
         if (my_cb && (unsigned)my_u < vt_cap) {
+#endif
             float acc[ACC_VALS];
 #pragma unroll
             for (int k = 0; k < ACC_VALS; ++k) acc[k] = 0.f;
