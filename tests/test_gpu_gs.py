@@ -295,6 +295,46 @@ def test_empty_and_culled(ctx):
     assert float(rgb.abs().max()) == 0.0 or meta["isect_ids"].size > 0
 
 
+def test_fused_step_on_edge_cases(ctx):
+    """The fused path (cell-list forward, two-level sort, exact culling) on inputs the regular scenes do not reach:
+    (a) nothing visible -- zero records: black image, finite loss, only the regularisers' gradients;
+    (b) an image whose size is no multiple of the 16-pixel tile or of the 4-pixel cell (partial tiles / cells on two
+        borders) with more than one batch of 256 records per tile: fused images bit-identical to the staged path's."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make("small")
+    N, Cn = g["means"].shape[0], w2c.shape[0]
+    far = {k: v.copy() for k, v in g.items()}
+    far["means"] = (far["means"] * 0.01 + np.array([100.0, 0, 0], np.float32)).astype(np.float32)
+    P = {k: dev(v) for k, v in far.items()}
+    vm, K = dev(w2c), dev(Ks)
+    gt = torch.rand((Cn, H, W, 3), device="cuda:0")
+    grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+    st = ops.train_fwd_bwd(ctx, P, vm, K, ops.camera_positions(vm), gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+    torch.cuda.synchronize()
+    assert st["n_isects"] == 0 and np.isfinite(float(loss))
+    assert float(ops.peek(ctx, 8, Cn * H * W * 3, torch.float32).abs().max()) == 0.0
+    G = ops.split_grads(grads, N)
+    assert float(G["means"].abs().max()) == 0.0 and float(G["sh"].abs().max()) == 0.0
+    assert float(G["opacities"].abs().max()) > 0.0          # d/d opacity of the sigmoid regulariser
+    # (b)
+    from st3r_synth import synth
+    W2, H2 = 150, 90
+    g2, w2c2, Ks2 = synth.make_scene(6000, 2, W2, H2, seed=8, scale_lo=0.02, scale_hi=0.12)
+    P2 = {k: dev(v) for k, v in g2.items()}
+    vm2, K2 = dev(w2c2), dev(Ks2)
+    rgb, alpha, info = ops.rasterization(ctx, P2["means"], P2["quats"], P2["scales"], P2["opacities"], P2["shN"], vm2, K2, W2, H2)
+    per_tile = info["isect_ids"].numel() / (2 * ((W2 + 15) // 16) * ((H2 + 15) // 16))
+    assert per_tile > 300                                   # several batches per tile
+    gt2 = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
+    grads2 = torch.empty(23 * 6000, device="cuda:0")
+    ops.train_fwd_bwd(ctx, P2, vm2, K2, ops.camera_positions(vm2), gt2, W2, H2, 0.2, 0.01, 0.01, grads2, loss)
+    torch.cuda.synchronize()
+    for which, full in ((8, rgb), (9, alpha)):
+        got = ops.peek(ctx, which, full.numel(), torch.float32)
+        assert torch.equal(got.view(torch.int32), full.reshape(-1).view(torch.int32))
+    assert bool(torch.isfinite(grads2).all())
+
+
 @pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
 def test_fused_train_gradients_equal_stage_path(ctx, name):
     """The fused train step culls (record, tile) pairs whose alpha >= 1/255 box misses the tile and sorts in
