@@ -172,22 +172,6 @@ __global__ __launch_bounds__(256) void k_replay(const float4* __restrict__ recs,
     if (lane == 0) { atomicAdd(&cyc[0], t1 - t0); atomicAdd(&cyc[1], (unsigned long long)trips); }
 }
 
-// pure streams with half of the wave disabled
-template <int HALF>
-__global__ __launch_bounds__(256) void k_stream(float* out) {
-    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b0 = 1.0001f, b1 = 0.9999f;
-    if (HALF) asm volatile("s_mov_b64 exec, 0xffffffff");
-    for (int i = 0; i < 4000; ++i) {
-        asm volatile("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %5, %4\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %5, %4\n"
-                     "v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %5, %4\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %5, %4\n"
-                     "v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %5, %4\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %5, %4\n"
-                     "v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %5, %4\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %5, %4\n"
-                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));
-    }
-    if (HALF) asm volatile("s_mov_b64 exec, -1");
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3;
-}
-
 template <typename K, typename... A>
 static float time_ms(K k, int blocks, A... args) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -247,7 +231,5 @@ int main() {
         run<6>("6 per-lane gather", recs, out, cyc, masks, blocks);
         run<7>("7 production loop, upper half of exec off", recs, out, cyc, masks, blocks);
     }
-    const float f = time_ms(k_stream<0>, 2048, out), hf = time_ms(k_stream<1>, 2048, out);
-    printf("v_fmac stream: full exec %.3f ms, lower half only %.3f ms\n", f, hf);
     return 0;
 }
