@@ -72,8 +72,8 @@ def _grad_worker(rank, world, port, out, exchange):
     assert sdist.attach_native_comm(ctx) == (rank, world)
     grads = torch.empty(23 * N, device=dev); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
     loss = torch.zeros(1, device=dev)
-    # one whole iteration through the library: fwd/bwd -> exchange -> Adam (lr 0: the parameters stay put, the
-    # exchanged gradients stay readable in `grads` for every variant that leaves them there)
+    # one whole iteration through the library: fwd/bwd -> exchange -> Adam.  The first Adam moment is (1 - beta1) x the
+    # exchanged gradient for every exchange form (under rs_ag `grads` itself only holds the rank's own piece)
     ops.train_step(ctx, P, vm, K, ops.camera_positions(vm), gt[views].contiguous(), W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3,
                    0.9, 0.999, 1e-8, 1, loss)
     torch.distributed.all_reduce(loss)
