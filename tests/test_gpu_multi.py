@@ -21,7 +21,11 @@ import torch
 import torch.multiprocessing as mp
 
 N_GPUS = torch.cuda.device_count() if torch.cuda.is_available() else 0
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(N_GPUS < 2, reason="needs >= 2 visible GPUs (one process per GPU)")]
+# ST3R_TEST_MULTI_FORCE=1 runs the same code with ONE spawned rank on a single-GPU box (plumbing check only: process
+# group, communicator, exchange forms, Scene loop -- every comparison then holds trivially)
+FORCED = os.environ.get("ST3R_TEST_MULTI_FORCE") == "1" and N_GPUS == 1
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(N_GPUS < 2 and not FORCED,
+                                                  reason="needs >= 2 visible GPUs (one process per GPU)")]
 
 N, W, H = 20000, 320, 240
 
@@ -92,7 +96,7 @@ def _grad_worker(rank, world, port, out, exchange):
 @pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag"])
 def test_exchanged_step_equals_single_gpu_step(tmp_path, exchange):
     from starst3r_amd import ops
-    world = min(N_GPUS, 8)
+    world = max(1, min(N_GPUS, 8))
     out = str(tmp_path / "r0.pt")
     mp.spawn(_grad_worker, args=(world, _free_port(), out, exchange), nprocs=world, join=True)
     z = torch.load(out)
@@ -147,7 +151,7 @@ def _scene_worker(rank, world, port, out, iters):
 def test_replicas_stay_identical_over_iterations_with_mcmc_hooks(tmp_path):
     from starst3r_amd import ops
     from starst3r_amd.scene import Scene
-    world, iters = min(N_GPUS, 8), 8
+    world, iters = max(1, min(N_GPUS, 8)), 8
     out = str(tmp_path / "r0.pt")
     mp.spawn(_scene_worker, args=(world, _free_port(), out, iters), nprocs=world, join=True)
     z = torch.load(out)
@@ -187,7 +191,7 @@ def _pairs_worker(rank, world, port, base):
 
 
 def test_pair_sharding_fills_every_cache(tmp_path):
-    world = min(N_GPUS, 8)
+    world = max(1, min(N_GPUS, 8))
     mp.spawn(_pairs_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     outs = [torch.load(tmp_path / f"out{r}.pth") for r in range(world)]
 
