@@ -169,6 +169,20 @@ int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quat
                    float* opacities, float* sh, int sh_stride, const float* grads, float* m, float* v, double lr,
                    double beta1, double beta2, double eps, int step);
 
+/* The same update restricted to the scalars [i0, i1) of the 23N-float gradient / moment buffers (buffer order: means[3N]
+ * quats[4N] scales[3N] opacities[N] sh4[12N]) -- the piece a rank owns after a reduce-scatter of the gradients
+ * (st3r_gs_train_step with ST3R_EXCHANGE=rs_ag does exactly this inside).  param_stage (may be NULL): a 23N-float buffer
+ * in buffer order that receives the new parameter values of the piece, the payload of the parameter all-gather.
+ * st3r_params_from_stage then copies the scalars OUTSIDE [i0, i1) from such a (gathered) buffer into the parameter
+ * tensors, for indices < limit (the tail past limit is each rank's own: see comm.hip). */
+int st3r_adam_step_range(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
+                         float* opacities, float* sh, int sh_stride, const float* grads, float* m, float* v,
+                         double lr, double beta1, double beta2, double eps, int step, int64_t i0, int64_t i1,
+                         float* param_stage);
+int st3r_params_from_stage(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
+                           float* opacities, float* sh, int sh_stride, const float* param_stage, int64_t i0,
+                           int64_t i1, int64_t limit);
+
 /* ------------------------------------------------------------------------------------
  * Fused train step, first half: everything of one iteration of starster/gs.py:143-153
  * (render all C local views -> loss -> backward) using ctx scratch only.

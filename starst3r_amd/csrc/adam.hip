@@ -143,3 +143,26 @@ ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means,
     st3r_prof_end(ctx, (hipStream_t)stream, STG_ADAM);
     return rc;
 }
+
+ST3R_EXPORT int st3r_adam_step_range(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
+                                     float* opacities, float* sh, int sh_stride, const float* grads, float* m, float* v,
+                                     double lr, double beta1, double beta2, double eps, int step, int64_t i0, int64_t i1,
+                                     float* param_stage) {
+    ARG_CHECK(ctx && N >= 0 && step >= 1 && sh_stride >= 12 && i0 >= 0 && i1 >= i0 && i1 <= (int64_t)23 * N);
+    ARG_CHECK(means && quats && scales && opacities && sh && grads && m && v);
+    const int32_t* count_dev; uint32_t count_cap;
+    st3r_adam_guard(ctx, &count_dev, &count_cap);
+    return st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1,
+                          beta2, eps, step, count_dev, count_cap, i0, i1, 0, -1, param_stage);
+}
+
+ST3R_EXPORT int st3r_params_from_stage(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
+                                       float* opacities, float* sh, int sh_stride, const float* param_stage, int64_t i0,
+                                       int64_t i1, int64_t limit) {
+    ARG_CHECK(ctx && N >= 0 && sh_stride >= 12 && i0 >= 0 && i1 >= i0 && limit >= 0 && limit <= (int64_t)23 * N);
+    ARG_CHECK(means && quats && scales && opacities && sh && param_stage);
+    const int32_t* count_dev; uint32_t count_cap;
+    st3r_adam_guard(ctx, &count_dev, &count_cap);
+    return st3r_params_from_stage_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, param_stage,
+                                       i0, i1, limit, count_dev, count_cap);
+}

@@ -223,6 +223,26 @@ def train_fwd_bwd(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fa
     return dict(n_visible=int(stats[0]), n_isects=int(stats[1]), arena_bytes=int(stats[2]), n_isects_ref=int(stats[3]))
 
 
+def adam_step_range(ctx, params, grads, m, v, lr, b1, b2, eps, step, i0, i1, stage=None):
+    """Adam on the scalars [i0, i1) of the 23N-float buffers (the piece a rank owns after a reduce-scatter); `stage`
+    (23N floats, buffer order) receives the new parameter values of the piece."""
+    N = params["means"].shape[0]
+    sh = params["shN"]
+    _lib.check(_lib.lib().st3r_adam_step_range(
+        ctx.handle, _stream(), N, _p(params["means"]), _p(params["quats"]), _p(params["scales"]), _p(params["opacities"]),
+        _p(sh), sh_stride_of(sh), _p(grads), _p(m), _p(v), lr, b1, b2, eps, step, int(i0), int(i1),
+        _p(stage) if stage is not None else None))
+
+
+def params_from_stage(ctx, params, stage, i0, i1, limit):
+    """parameters of the scalars outside [i0, i1) and below `limit` <- stage (buffer order)."""
+    N = params["means"].shape[0]
+    sh = params["shN"]
+    _lib.check(_lib.lib().st3r_params_from_stage(
+        ctx.handle, _stream(), N, _p(params["means"]), _p(params["quats"]), _p(params["scales"]), _p(params["opacities"]),
+        _p(sh), sh_stride_of(sh), _p(stage), int(i0), int(i1), int(limit)))
+
+
 def train_step(ctx, params, viewmats, Ks, campos, gt, W, H, ssim_fac, opac_fac, scale_fac, grads, m, v, lr, b1, b2, eps,
                step, loss_out, want_stats=True):
     """One whole iteration in one C call: fwd/bwd -> gradient all-reduce over the ctx's RCCL communicator (if

@@ -70,3 +70,42 @@ def test_native_comm_single_rank_and_fused_step():
         os.environ.pop("ST3R_EXCHANGE", None)
         sdist.detach_native_comm(ctx)
     assert not ctx.native_comm
+
+
+def test_sharded_adam_pieces_reassemble_the_replicated_update():
+    """The reduce-scatter exchange (ST3R_EXCHANGE=rs_ag) on one GPU with the collectives done by hand: w virtual ranks,
+    each with its own copy of the parameters and moments, run Adam on their piece [r q, (r+1) q) of the (already summed)
+    gradient buffer (st3r_adam_step_range), the pieces of the staging buffers are "all-gathered" with a copy,
+    st3r_params_from_stage fills the rest, everyone updates the < w floats of the tail -- every rank then holds exactly
+    the parameters of the replicated st3r_adam_step, and its piece of the moments."""
+    from starst3r_amd import ops
+    ctx = ops.get_context(DEV)
+    N, w = 1003, 4                       # 23 N = 23069 = 4 x 5767 + 1: a tail of one float
+    torch.manual_seed(5)
+    P0 = dict(means=torch.randn(N, 3, device=DEV), quats=torch.randn(N, 4, device=DEV), scales=torch.randn(N, 3, device=DEV),
+              opacities=torch.randn(N, device=DEV), shN=torch.randn(N, 24, 3, device=DEV))
+    grads = torch.randn(23 * N, device=DEV)
+    m0 = 0.1 * torch.randn(23 * N, device=DEV); v0 = 0.01 * torch.rand(23 * N, device=DEV)
+    ref = {k: t.clone() for k, t in P0.items()}; m_ref, v_ref = m0.clone(), v0.clone()
+    ops.adam_step(ctx, ref, grads, m_ref, v_ref, 1e-3, 0.9, 0.999, 1e-8, 7)
+    total = 23 * N; q = total // w; tail0 = q * w
+    ranks = [dict(P={k: t.clone() for k, t in P0.items()}, m=m0.clone(), v=v0.clone(), stage=torch.zeros(total, device=DEV))
+             for _ in range(w)]
+    for r, R in enumerate(ranks):
+        ops.adam_step_range(ctx, R["P"], grads, R["m"], R["v"], 1e-3, 0.9, 0.999, 1e-8, 7, r * q, (r + 1) * q, R["stage"])
+        ops.adam_step_range(ctx, R["P"], grads, R["m"], R["v"], 1e-3, 0.9, 0.999, 1e-8, 7, tail0, total)
+    gathered = torch.zeros(total, device=DEV)
+    for r, R in enumerate(ranks):
+        gathered[r * q:(r + 1) * q] = R["stage"][r * q:(r + 1) * q]
+    for r, R in enumerate(ranks):
+        ops.params_from_stage(ctx, R["P"], gathered, r * q, (r + 1) * q, tail0)
+    torch.cuda.synchronize()
+    for r, R in enumerate(ranks):
+        for k in ref:
+            if k == "shN":   # rows 4..23 are never touched
+                assert torch.equal(R["P"][k][:, 4:], P0[k][:, 4:])
+            assert torch.equal(R["P"][k], ref[k]), (r, k)
+        assert torch.equal(R["m"][r * q:(r + 1) * q], m_ref[r * q:(r + 1) * q])
+        assert torch.equal(R["v"][tail0:], v_ref[tail0:])
+        other = (r + 1) % w
+        assert torch.equal(R["m"][other * q:(other + 1) * q], m0[other * q:(other + 1) * q])   # not this rank's piece
