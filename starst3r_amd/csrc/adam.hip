@@ -34,13 +34,14 @@ __global__ __launch_bounds__(256) void k_adam(int64_t N, float* __restrict__ mea
                                               const float* __restrict__ grads, float* __restrict__ m,
                                               float* __restrict__ v, AdamK k, const int32_t* __restrict__ count_dev,
                                               uint32_t count_cap, int64_t i0, int64_t i1, int64_t g0, int64_t g1,
-                                              float* __restrict__ pstage) {
+                                              float* __restrict__ pstage, const float* __restrict__ gstage,
+                                              float* __restrict__ grads_out) {
     // Asynchronous training steps keep the record count on the device; a step whose count outgrew the capacity of its
     // buffers dropped records, so its gradients are incomplete: the update is skipped HERE, on the device, and the next
     // call reports ST3R_ERR_CAPACITY -- the caller repeats the iteration with nothing to undo (a count above 2^31 wraps
     // negative: the unsigned compare catches it).
     if (count_dev && (uint32_t)count_dev[0] > count_cap) return;
-    const bool by_gaussian = g1 - g0 < N;
+    const bool by_gaussian = g1 - g0 < N || gstage;
     const int64_t n = g1 - g0;
     const int64_t total = by_gaussian ? 23 * n : i1 - i0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -56,7 +57,11 @@ __global__ __launch_bounds__(256) void k_adam(int64_t N, float* __restrict__ mea
             i = i0 + j;
         }
         float* p = adam_param(i, N, means, quats, scales, opacities, sh, sh_stride);
-        const float gi = grads[i];
+        // gstage (range-wise exchange): the range's gradients sit contiguously at 23 g0 in the range's own block layout,
+        // i.e. at the local index j; they are handed on to the caller's buffer in its layout
+        float gi;
+        if (gstage) { gi = gstage[23 * g0 + j]; grads_out[i] = gi; }
+        else gi = grads[i];
         const float mi = fmaf(k.w1, gi - m[i], m[i]);
         const float vi = v[i] * k.b2 + (k.w2 * gi) * gi;
         m[i] = mi; v[i] = vi;
@@ -95,7 +100,7 @@ static AdamK adam_constants(double lr, double b1, double b2, double eps, int ste
 int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities, float* sh,
                    int sh_stride, const float* grads, float* m, float* v, double lr, double b1, double b2,
                    double eps, int step, const int32_t* count_dev, uint32_t count_cap, int64_t i0, int64_t i1,
-                   int64_t g0, int64_t g1, float* pstage) {
+                   int64_t g0, int64_t g1, float* pstage, const float* gstage, float* grads_out) {
     if (N == 0) return ST3R_OK;
     if (i0 < 0) { i0 = 0; i1 = 23 * (int64_t)N; }
     if (g1 < 0) { g0 = 0; g1 = N; }
@@ -105,7 +110,7 @@ int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scal
     int blocks = ceil_div(total, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, (int64_t)N, means, quats, scales, opacities, sh,
-                       sh_stride, grads, m, v, k, count_dev, count_cap, i0, i1, g0, g1, pstage);
+                       sh_stride, grads, m, v, k, count_dev, count_cap, i0, i1, g0, g1, pstage, gstage, grads_out);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -139,7 +144,7 @@ ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means,
     const int32_t* count_dev; uint32_t count_cap;
     st3r_adam_guard(ctx, &count_dev, &count_cap);
     int rc = st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr,
-                            beta1, beta2, eps, step, count_dev, count_cap, -1, -1, 0, -1, nullptr);
+                            beta1, beta2, eps, step, count_dev, count_cap, -1, -1, 0, -1, nullptr, nullptr, nullptr);
     st3r_prof_end(ctx, (hipStream_t)stream, STG_ADAM);
     return rc;
 }
@@ -153,7 +158,7 @@ ST3R_EXPORT int st3r_adam_step_range(st3r_ctx* ctx, void* stream, int N, float* 
     const int32_t* count_dev; uint32_t count_cap;
     st3r_adam_guard(ctx, &count_dev, &count_cap);
     return st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1,
-                          beta2, eps, step, count_dev, count_cap, i0, i1, 0, -1, param_stage);
+                          beta2, eps, step, count_dev, count_cap, i0, i1, 0, -1, param_stage, nullptr, nullptr);
 }
 
 ST3R_EXPORT int st3r_params_from_stage(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,

@@ -215,7 +215,7 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
                              const float* opacities, const float* sh, int sh_stride, const float* viewmats,
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
-                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end);
+                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end, bool range_major);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render);
 
@@ -445,17 +445,22 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     // pass: the later view chunks of a chunked call ADD to every range.
     ctx->ranges_recorded = 0;
     if (ctx->n_ranges > 1 && !accumulate && ctx->comm_stream) {
+        // the gradients of a range go to the ctx's staging buffer in range-major order (one contiguous piece per range);
+        // Adam reads them from there and leaves them in the caller's buffer in its block layout (comm.hip)
+        GET(SLOT_GSTAGE, float, (int64_t)23 * N, gstage);
         const int K = ctx->n_ranges;
         for (int j = 0; j < K && !rc; ++j) {
             const int g0 = (int)((int64_t)N * j / K), g1 = (int)((int64_t)N * (j + 1) / K);
             rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
-                                          H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, false, g0, g1);
+                                          H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, gstage, false, g0, g1,
+                                          true);
             if (!rc) HIP_TRY(hipEventRecord(ctx->ev_range_bwd[j], s));
         }
         if (!rc) ctx->ranges_recorded = K;
     } else {
         rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                                      0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, accumulate, 0, -1);
+                                      0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, accumulate, 0, -1,
+                                      false);
     }
     st3r_prof_end(ctx, s, STG_PROJECT_BWD);
     *ro_out = ro;

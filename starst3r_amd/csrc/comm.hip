@@ -9,9 +9,12 @@
 //   allreduce  one ncclAllReduce of the 23N floats on the caller's stream after the whole backward, Adam after it
 //              (round 1 / 2).  Nothing overlaps: 92 MB at 1 M Gaussians.
 //   ranges     the projection backward, the last kernel of the backward, runs once per Gaussian range (K = 4) with an
-//              event behind each launch; a range's five gradient segments (block layout) are all-reduced as ONE grouped
-//              RCCL call on a second stream as soon as its event fires, i.e. under the projection backward of the next
-//              range, and Adam of a range starts when its all-reduce is done, i.e. under the all-reduce of the next.
+//              event behind each launch and writes the range's gradients RANGE-MAJOR into a staging buffer of the ctx
+//              (the block layout of the caller's buffer would spread a range over five segments: five small collectives
+//              per range -- fewer, larger collectives is the rule on xGMI); a range is then ONE contiguous all-reduce
+//              of 23 N / K floats (23 MB at 1 M, K = 4) on a second stream as soon as its event fires, i.e. under the
+//              projection backward of the next range; Adam of a range starts when its all-reduce is done, i.e. under
+//              the all-reduce of the next, reads the staged gradients and leaves them in the caller's buffer.
 //              Exposed communication: the last range plus whatever the 0.2 ms of backward / 0.14 ms of Adam cannot cover.
 //   rs_ag      reduce-scatter -> Adam on the rank's 1/w of the buffer (moments m, v are only maintained there: 2 x 92 MB
 //              of optimizer state become 2 x 92/w MB of live state) -> all-gather of the updated parameters through a
@@ -143,7 +146,7 @@ ST3R_EXPORT int st3r_grad_allreduce(st3r_ctx* ctx, void* stream, float* grads, i
 int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities, float* sh,
                    int sh_stride, const float* grads, float* m, float* v, double lr, double b1, double b2,
                    double eps, int step, const int32_t* count_dev, uint32_t count_cap, int64_t i0, int64_t i1,
-                   int64_t g0, int64_t g1, float* pstage);
+                   int64_t g0, int64_t g1, float* pstage, const float* gstage, float* grads_out);
 int st3r_params_from_stage_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities,
                                 float* sh, int sh_stride, const float* pstage, int64_t i0, int64_t i1, int64_t lim,
                                 const int32_t* count_dev, uint32_t count_cap);
@@ -203,18 +206,12 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
         // ---- range-wise: all-reduce of range j behind its backward event, Adam of range j behind its all-reduce
         const int K = ctx->ranges_recorded;
         ncclComm_t comm = (ncclComm_t)ctx->comm;
-        static const int width_of[5] = {3, 4, 3, 1, 12};
-        static const int block_at[5] = {0, 3, 7, 10, 11};   // x N
+        float* gstage = (float*)ctx->slot_ptr[SLOT_GSTAGE];   // range-major: range j = 23 (g1 - g0) floats at 23 g0
         for (int j = 0; j < K; ++j) {
             const int64_t g0 = (int64_t)N * j / K, g1 = (int64_t)N * (j + 1) / K;
             HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_range_bwd[j], 0));
-            RCCL_TRY(api, api->group_start());
-            for (int b = 0; b < 5; ++b) {
-                float* seg = grads + (int64_t)block_at[b] * N + (int64_t)width_of[b] * g0;
-                RCCL_TRY(api, api->all_reduce(seg, seg, (size_t)(width_of[b] * (g1 - g0)), ncclFloat32, ncclSum, comm,
-                                              ctx->comm_stream));
-            }
-            RCCL_TRY(api, api->group_end());
+            RCCL_TRY(api, api->all_reduce(gstage + 23 * g0, gstage + 23 * g0, (size_t)(23 * (g1 - g0)), ncclFloat32, ncclSum,
+                                          comm, ctx->comm_stream));
             HIP_TRY(hipEventRecord(ctx->ev_range_red[j], ctx->comm_stream));
         }
         st3r_prof_begin(ctx, s, STG_ADAM);
@@ -222,7 +219,7 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
             const int64_t g0 = (int64_t)N * j / K, g1 = (int64_t)N * (j + 1) / K;
             HIP_TRY(hipStreamWaitEvent(s, ctx->ev_range_red[j], 0));
             rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
-                                step, count_dev, count_cap, -1, -1, g0, g1, nullptr);
+                                step, count_dev, count_cap, -1, -1, g0, g1, nullptr, gstage, grads);
         }
         st3r_prof_end(ctx, s, STG_ADAM);
         return rc;
@@ -240,10 +237,10 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
         if (total > tail0) RCCL_TRY(api, api->all_reduce(grads + tail0, grads + tail0, (size_t)(total - tail0), ncclFloat32, ncclSum, comm, s));
         st3r_prof_begin(ctx, s, STG_ADAM);
         rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
-                            count_dev, count_cap, r * q, (r + 1) * q, 0, -1, pstage);
+                            count_dev, count_cap, r * q, (r + 1) * q, 0, -1, pstage, nullptr, nullptr);
         if (!rc && total > tail0)   // the remainder: every rank holds its sum and updates it itself
             rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
-                                step, count_dev, count_cap, tail0, total, 0, -1, nullptr);
+                                step, count_dev, count_cap, tail0, total, 0, -1, nullptr, nullptr, nullptr);
         st3r_prof_end(ctx, s, STG_ADAM);
         if (rc) return rc;
         if (q > 0) {

@@ -70,6 +70,7 @@ enum ArenaSlot {
     SLOT_RECTBASE,
     SLOT_COUNTS,
     SLOT_PSTAGE,
+    SLOT_GSTAGE,
     SLOT_COUNT
 };
 

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
     int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     const float* __restrict__ campos, int W, int H, float eps2d, const float4* __restrict__ splats,
     const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads, int accumulate,
-    int g_begin, int g_end) {
+    int g_begin, int g_end, int range_major) {
     extern __shared__ float cam[];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float* o = cam + c * CAM_STRIDE;
@@ -222,30 +222,36 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
     v_scale[1] += reg_s_k * __expf(s1);
     v_scale[2] += reg_s_k * __expf(s2);
 
-    const int64_t Nl = N;
-    float* gm = grads; float* gq = grads + 3 * Nl; float* gs = grads + 7 * Nl;
-    float* go = grads + 10 * Nl; float* gsh = grads + 11 * Nl;
+    // Block layout means[3 Nl] quats[4 Nl] scales[3 Nl] opacities[Nl] sh4[12 Nl] -- over all N Gaussians (the caller's
+    // gradient buffer), or, range_major (the range-wise exchange of comm.hip), over the Gaussians [g_begin, g_end) of this
+    // launch only, stored at 23 * g_begin: every range is then ONE contiguous piece of 23 * (g_end - g_begin) floats,
+    // i.e. one all-reduce per range instead of five.
+    const int64_t Nl = range_major ? g_end - g_begin : N;
+    float* gb = range_major ? grads + (int64_t)23 * g_begin : grads;
+    const int gw = range_major ? g - g_begin : g;   // parameters were read at g, gradients are written at gw
+    float* gm = gb; float* gq = gb + 3 * Nl; float* gs = gb + 7 * Nl;
+    float* go = gb + 10 * Nl; float* gsh = gb + 11 * Nl;
     if (accumulate) {   // a later view chunk of the same training call: its gradients add to the earlier chunks
-        v_mean[0] += gm[3 * g]; v_mean[1] += gm[3 * g + 1]; v_mean[2] += gm[3 * g + 2];
-        vq0 += gq[4 * g]; vq1 += gq[4 * g + 1]; vq2 += gq[4 * g + 2]; vq3 += gq[4 * g + 3];
-        v_scale[0] += gs[3 * g]; v_scale[1] += gs[3 * g + 1]; v_scale[2] += gs[3 * g + 2];
-        v_opac += go[g];
+        v_mean[0] += gm[3 * gw]; v_mean[1] += gm[3 * gw + 1]; v_mean[2] += gm[3 * gw + 2];
+        vq0 += gq[4 * gw]; vq1 += gq[4 * gw + 1]; vq2 += gq[4 * gw + 2]; vq3 += gq[4 * gw + 3];
+        v_scale[0] += gs[3 * gw]; v_scale[1] += gs[3 * gw + 1]; v_scale[2] += gs[3 * gw + 2];
+        v_opac += go[gw];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) v_k[i] += gsh[(int64_t)g * 12 + i];
+        for (int i = 0; i < 12; ++i) v_k[i] += gsh[(int64_t)gw * 12 + i];
     }
-    gm[3 * g] = v_mean[0]; gm[3 * g + 1] = v_mean[1]; gm[3 * g + 2] = v_mean[2];
-    gq[4 * g] = vq0; gq[4 * g + 1] = vq1; gq[4 * g + 2] = vq2; gq[4 * g + 3] = vq3;
-    gs[3 * g] = v_scale[0]; gs[3 * g + 1] = v_scale[1]; gs[3 * g + 2] = v_scale[2];
-    go[g] = v_opac;
+    gm[3 * gw] = v_mean[0]; gm[3 * gw + 1] = v_mean[1]; gm[3 * gw + 2] = v_mean[2];
+    gq[4 * gw] = vq0; gq[4 * gw + 1] = vq1; gq[4 * gw + 2] = vq2; gq[4 * gw + 3] = vq3;
+    gs[3 * gw] = v_scale[0]; gs[3 * gw + 1] = v_scale[1]; gs[3 * gw + 2] = v_scale[2];
+    go[gw] = v_opac;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) gsh[(int64_t)g * 12 + i] = v_k[i];
+    for (int i = 0; i < 12; ++i) gsh[(int64_t)gw * 12 + i] = v_k[i];
 }
 
 int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
                              const float* opacities, const float* sh, int sh_stride, const float* viewmats,
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
-                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end) {
+                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end, bool range_major) {
     if (g_end < 0) g_end = N;
     if (N == 0 || g_end <= g_begin) return ST3R_OK;
     float reg_o_k = reg_views * opac_fac / (float)N;
@@ -253,7 +259,8 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
     size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
     hipLaunchKernelGGL(k_project_sh_bwd, dim3(ceil_div(g_end - g_begin, 256)), dim3(256), shmem, s, N, C, means, quats,
                        scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d, (const float4*)splats,
-                       (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin, g_end);
+                       (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin, g_end,
+                       range_major ? 1 : 0);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -268,5 +275,5 @@ ST3R_EXPORT int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && v_splats && grads);
     return st3r_project_sh_bwd_impl((hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats,
                                     Ks, campos, width, height, eps2d, splats, v_splats, reg_views, opac_fac, scale_fac,
-                                    grads, false, 0, -1);
+                                    grads, false, 0, -1, false);
 }
