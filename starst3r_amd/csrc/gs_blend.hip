@@ -322,12 +322,17 @@ ST3R_EXPORT int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width,
 __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsigned tpack, int cnt, int lane, const float4* sA, float* accw, float qxf_lane, float qyf_lane,
                                            const float (&pvr)[CHUNK], const float (&pvg)[CHUNK],
                                            const float (&pvb)[CHUNK]) {
+#ifdef BWD_SWAP_LAYOUT   // rounds 1-2: lane = record + CHUNK * part, the 16 parts of a record meet through lane swaps
     const int r = lane & (CHUNK - 1), part = lane / CHUNK;
+#else                    // round 3: lane = part + 16 * record: a record's 16 parts are one DPP row (reduce9_rows)
+    static_assert(CHUNK == 4, "one DPP row per record of the chunk");
+    const int r = lane >> 4, part = lane & 15;
+#endif
     wave_lds_sync();
     const int t = (tpack >> (8 * r)) & 0xFF;  // rows >= cnt read index 0 (valid); their sums are dropped below
     const float2 mean = *reinterpret_cast<const float2*>(&sA[t]);
     const float dy = mean.y - qyf_lane;
-    const float2* src = pr + r * PAIR_STRIDE + part * CHUNK;
+    const float2* src = pr + r * PAIR_STRIDE + PAIR_AT(part * CHUNK);
     // The lane's pixels are i = 0 .. CHUNK-1 to the right of its first one: with d0 = dx of the first pixel,
     // sum g dx = d0 W0 - W1 and sum g dx^2 = d0 (d0 W0 - 2 W1) + W2 for the index moments W_k = sum i^k g_i -- 12 VALU
     // instead of 21 for CHUNK = 4 (k_blend_bwd 2.27 -> 2.17 ms); the offsets are at most CHUNK-1 pixels, so the
@@ -345,6 +350,7 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
     const float So = W0, Sx = fmaf(d0, W0, -W1), Sxx = fmaf(d0, Sx - W1, W2);
     const float Sy = So * dy, Sxy = Sx * dy, Syy = Sy * dy;  // dy is the same for the lane's pixels
     float k0, k1, k2;
+#ifdef BWD_SWAP_LAYOUT
     reduce9(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);            // lane bits 5, 4
     k0 = row_ror8_add(k0); k1 = row_ror8_add(k1); k2 = row_ror8_add(k2);  // lane bit 3
     if (CHUNK == 4) { k0 = row_ror4_add(k0); k1 = row_ror4_add(k1); k2 = row_ror4_add(k2); }  // lane bit 2
@@ -357,6 +363,18 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
         acc[4 + slot0] = k1;
         if (row == 0) acc[8] = k2;
     }
+#else
+    reduce9_rows(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);
+    if (r < cnt && (lane & 3) == 0) {
+        // bank b of the record's row -> slots: k0 -> {0,2,1,3}[b], k1 -> {4,6,5,7}[b], k2 -> 8 (bank 0)
+        const int b = (lane >> 2) & 3;
+        const int slot0 = ((b & 1) << 1) | (b >> 1);
+        float* acc = accw + t * ACC_VALS;
+        acc[slot0] = k0;
+        acc[4 + slot0] = k1;
+        if (b == 0) acc[8] = k2;
+    }
+#endif
     wave_lds_sync();
 }
 
@@ -404,7 +422,11 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     float2* pr = sPair[w];
     float* accw = sAccW[w];
     float pvr[CHUNK], pvg[CHUNK], pvb[CHUNK];
+#ifdef BWD_SWAP_LAYOUT
     const int pbase = (lane / CHUNK) * CHUNK;   // first of this lane's phase-2 pixels (quadrant-local index y*8 + x)
+#else
+    const int pbase = (lane & 15) * CHUNK;      // (phase-2 lane = part + 16 * record: see bwd_phase2)
+#endif
     {
         float* px = reinterpret_cast<float*>(pr);
         px[lane] = vr; px[64 + lane] = vg; px[128 + lane] = vb;
@@ -517,7 +539,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                         float v_al = cv * T - bv * ra;
                         if (HAS_VA) v_al += T_final * ra * va;
                         bv += cv * fac;
-                        pr[k * PAIR_STRIDE + lane] = make_float2(alpha_u * v_al, fac);
+                        pr[k * PAIR_STRIDE + PAIR_AT(lane)] = make_float2(alpha_u * v_al, fac);
                         tpack |= (unsigned)t << (8 * k);
                         cnt = k + 1;
                     }
