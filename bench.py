@@ -356,7 +356,7 @@ def main():
         m = torch.zeros_like(grads); v = torch.zeros_like(grads)
 
         native_comm = True
-        if world > 1:
+        if dist is not None:   # one process per GPU (under torch.distributed.run also with a single rank: same code path)
             from starst3r_amd import dist as sdist
             try:
                 sdist.attach_native_comm(ctx)      # torch.distributed only ships the 128-byte RCCL id
@@ -453,7 +453,7 @@ def main():
     # per-rank view of the same timed region, and the exchange on its own (N > 1)
     my_ms = marks[0].elapsed_time(marks[-1]) / args.steps
     per_rank_ms, exch_ms = [my_ms], None
-    if world > 1:
+    if dist is not None:
         t_all = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(t_all, torch.tensor([my_ms], device=device, dtype=torch.float64))
         per_rank_ms = [float(x.item()) for x in t_all]
@@ -473,6 +473,29 @@ def main():
             t = torch.tensor([e0.elapsed_time(e1) / reps], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             exch_ms = float(t.item())
+    # the whole step under each exchange form of st3r_gs_train_step (after the timed region: a few extra steps each;
+    # rs_ag leaves the Adam moments sharded, which no longer matters here)
+    forms_ms = None
+    if dist is not None and mode != "gaussian-sharded" and native_comm and not FREEZE:
+        forms_ms = {}
+        keep = os.environ.get("ST3R_EXCHANGE")
+        it_x = total - 1
+        for form in ("allreduce", "ranges", "rs_ag"):
+            os.environ["ST3R_EXCHANGE"] = form
+            step(it_x)                                   # warm-up of the form (streams, staging buffers)
+            dist.barrier(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                step(it_x)
+            e1.record(); torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / 5], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            forms_ms[form] = float(t.item())
+        if keep is None:
+            os.environ.pop("ST3R_EXCHANGE", None)
+        else:
+            os.environ["ST3R_EXCHANGE"] = keep
     if mode == "gaussian-sharded":   # counts of the own Gaussians over all views ~ those of the own views over all Gaussians
         stats["n_visible"] = int(trainer.reg[2].item()); stats["n_isects_ref"] = int(trainer.reg[3].item())
     if world > 1:
@@ -538,7 +561,8 @@ def main():
             # every rank's own ms per step over the timed region (HIP events on its launch stream) and, for N > 1, one
             # exchange of the [23N] gradient buffer on its own (max over ranks): step - exchange ~ what a rank computes
             "per_rank": {"ms_per_step": per_rank_ms, "exchange_ms_isolated": exch_ms,
-                         "exchange": os.environ.get("ST3R_EXCHANGE", "ranges" if world > 1 else "none")},
+                         "exchange_forms_ms_per_step": forms_ms,
+                         "exchange": os.environ.get("ST3R_EXCHANGE", "allreduce" if dist is not None else "none")},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -4,8 +4,7 @@
 // The reference is single-process (starster/gs.py:143-164 loops over all views on one device); sharding the
 // views over one process per GPU is valid because the loss is a plain sum over views (gs.py:149-152).
 //
-// The exchange itself comes in three forms (ST3R_EXCHANGE = allreduce | ranges | rs_ag; default: ranges when more than
-// one rank is attached).  All three leave every replica with the same parameters; what differs is what overlaps:
+// The exchange itself comes in three forms (ST3R_EXCHANGE = allreduce | ranges | rs_ag; default: allreduce).  All three leave every replica with the same parameters; what differs is what overlaps:
 //   allreduce  one ncclAllReduce of the 23N floats on the caller's stream after the whole backward, Adam after it
 //              (round 1 / 2).  Nothing overlaps: 92 MB at 1 M Gaussians.
 //   ranges     the projection backward, the last kernel of the backward, runs once per Gaussian range (K = 4) with an
@@ -160,7 +159,11 @@ static int exchange_mode(const st3r_ctx* ctx) {
     if (e && !strcmp(e, "allreduce")) return EXCH_ALLREDUCE;
     if (e && !strcmp(e, "ranges")) return EXCH_RANGES;
     if (e && !strcmp(e, "rs_ag")) return EXCH_RS_AG;
-    return ctx->comm && ctx->comm_size > 1 ? EXCH_RANGES : EXCH_ALLREDUCE;
+    // Default: the plain all-reduce.  The exchange follows the LAST kernels of the iteration, so the range-wise form can
+    // hide at most the projection backward and Adam (0.05 + 0.14 ms at one view per GPU) behind four collectives'
+    // latencies, and rs_ag keeps the moments on the own piece only; neither has been measured on more than one GPU --
+    // bench.py --gpus N times all three (per_rank.exchange_forms_ms_per_step).
+    return EXCH_ALLREDUCE;
 }
 
 static int ensure_comm_stream(st3r_ctx* ctx) {
