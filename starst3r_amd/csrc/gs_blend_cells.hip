@@ -19,7 +19,8 @@
 //               with the offset of an all-zero sentinel record up to the longest list of the wave that walks them.
 // A trip then costs one ds_read_u16 (row-uniform address) more than before and no scalar work beyond the loop
 // counter; the trip count of a wave is the longest of its four lists (tools/cell_stats.py: 0.745 of the quadrant
-// trips at SYNTH-1M, 0.65 if the four lists were always equally long).
+// trips at SYNTH-1M, 0.65 if the four lists were always equally long), re-evaluated every 32 list positions over the
+// rows that still hold a live pixel (0.684).
 // The alpha / saturation tests are exec-masked instead of select-based (lanes that fail skip the updates; a trip
 // that no lane passes skips the body: -10 % in the replay probe).
 //
@@ -46,10 +47,11 @@
 //   entries                      the row first fills its whole list with the sentinel offset (two 16-byte stores per
 //                                lane), then every lane writes the LDS byte offsets of its hit records at its positions
 //                                (a loop over the set bits of the piece: as many trips as the fullest piece of the wave).
-// Returns the wave's trip count: the longest of its four lists, rounded up to a multiple of four.
+// Returns the lengths of the wave's four lists packed in one word (a byte each would not hold 256: 9 bits x 4 do not fit
+// either, so two words): lens.x = l0 | l1 << 16, lens.y = l2 | l3 << 16.
 // (Round 3, first version: one thread per record scattered into sixteen lists after a packed-counter prefix scan over
 // the workgroup -- ~280 instructions per wave and batch and a second barrier; this form costs ~110.)
-__device__ __forceinline__ int build_wave_lists(const uint16_t* sCm, uint16_t* myList, int cell, int lane) {
+__device__ __forceinline__ uint2 build_wave_lists(const uint16_t* sCm, uint16_t* myList, int cell, int lane) {
     const int idx = lane & 15;
     const uint4 d0 = *reinterpret_cast<const uint4*>(sCm + 16 * idx);
     const uint4 d1 = *reinterpret_cast<const uint4*>(sCm + 16 * idx + 8);
@@ -83,7 +85,7 @@ __device__ __forceinline__ int build_wave_lists(const uint16_t* sCm, uint16_t* m
         *dst++ = (uint16_t)(off + (unsigned)bpos * SLOT);
     }
     wave_lds_sync();
-    return (max(max(l0, l1), max(l2, l3)) + 3) & ~3;
+    return make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
 }
 
 struct CellPx {
@@ -214,17 +216,28 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
         // ---- trips: every row walks its own list; the wave runs until its longest list is done
         if (__builtin_amdgcn_ballot_w64(s.thr < 1.0f) != 0) {
 #ifdef CELLS_NO_LISTS
-            const int n4 = 0;
+            const uint2 lens = make_uint2(0u, 0u);
 #else
-            const int n4 = build_wave_lists(sCm, lp, g.cell, lane);
+            const uint2 lens = build_wave_lists(sCm, lp, g.cell, lane);
 #endif
+            const int l0 = lens.x & 0xFFFF, l1 = lens.x >> 16, l2 = lens.y & 0xFFFF, l3 = lens.y >> 16;
             // Windows of 32 list positions; inside a window four trips per iteration: the four list entries arrive as one
             // 8-byte read issued an iteration ahead, the record reads run two trips ahead of the bodies.
             uint2 e = *reinterpret_cast<const uint2*>(lp);
+            for (int k0 = 0;; k0 += 32) {
+                // the trips still needed: the longest list among the rows that still have a live pixel (checked once per
+                // window: a wave whose pixels have all saturated stops here instead of at the end of the batch --
+                // tools/cell_stats.py: 0.745 -> 0.68 of the quadrant trips at SYNTH-1M)
+                const uint64_t live = __builtin_amdgcn_ballot_w64(s.thr < 1.0f);
+                int need = (live & 0xFFFFull) ? l0 : 0;
+                need = max(need, (live & 0xFFFF0000ull) ? l1 : 0);
+                need = max(need, (live & 0xFFFF00000000ull) ? l2 : 0);
+                need = max(need, (live & 0xFFFF000000000000ull) ? l3 : 0);
+                const int n4 = (need + 3) & ~3;
 #ifdef CELLS_NO_TRIPS
-            for (int k0 = 0; k0 < (n4 & no_cull); k0 += 32) {   // ablation: staging and list building only
+                if (k0 >= (n4 & no_cull)) break;   // ablation: staging and list building only
 #else
-            for (int k0 = 0; k0 < n4; k0 += 32) {
+                if (k0 >= n4) break;
 #endif
                 unsigned cbits = 0;
                 const int kend = min(k0 + 32, n4);
