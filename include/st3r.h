@@ -250,6 +250,26 @@ int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, con
                    float dust_weight, float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
                    float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out);
 
+/* The same optimisation with the non-default options of sparse_scene_optimizer_slam that only change constants of the
+ * loop (starster/reconstruct.py:118-122; st3r_align_run = the reference's own configuration :61-69):
+ *   lr_host    HOST array of niter1 + niter2 learning rates, one per iteration = the caller's
+ *              schedule(iter / niter, lr_base, 0) (reconstruct.py:384-386), or NULL for cosine_schedule;
+ *   gamma1/2/d exponents of the robust losses gamma_loss(g) of loss_3d (loss1), loss_2d (loss2) and loss_dust3r
+ *              (lossd): rho(d) = (d + off)^g - off^g with off = (1/g)^(1/(g-1)); g = 1 is the plain distance;
+ *   opt_pp     0: the principal points stay fixed in the second stage (reconstruct.py:436).
+ * opt_depth, shared_intrinsics, exp_depth, lora_depth and per-image `init` freezes are not implemented. */
+int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
+                        const float* base_focals, const float* median, const float* core, const float* min_focals,
+                        const float* max_focals, const float* anchor_pix, const int32_t* anchor_idx,
+                        const float* anchor_off, const int32_t* anchor_img, int n_corr, const int32_t* corr_a1,
+                        const int32_t* corr_a2, const float* corr_w, int n_c2d, const float* c2d_pix,
+                        const int32_t* c2d_a2, const int32_t* c2d_img1, const float* c2d_w, int n_dust,
+                        const int32_t* dust_a1, const float* dust_tgt, const int32_t* dust_img2, const float* dust_w,
+                        int root, int n_edges, const int32_t* edges, float lr1, int niter1, float lr2, int niter2,
+                        float dust_weight, float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
+                        float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out,
+                        const float* lr_host, float gamma1, float gamma2, float gammad, int opt_pp);
+
 /* ------------------------------------------------------------------------------------
  * Path A -- matching.  The nearest-neighbour query of Mast3r's fast_reciprocal_NNs with
  * dist='dot' (reached from starster/reconstruct.py:97):

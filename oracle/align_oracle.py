@@ -115,14 +115,14 @@ def make_pts3d(pb, K, cam2w, depth):
     return (cam2w[img, :3, :3] @ pc.unsqueeze(-1)).squeeze(-1) + cam2w[img, :3, 3]
 
 
-def loss_3d(pb, pts):                                   # reconstruct.py:325-353
+def loss_3d(pb, pts, gamma=1.1):                        # reconstruct.py:325-353 (pix_loss = loss1, :118)
     if pb.corr_a1.numel() == 0:
         return torch.zeros((), dtype=pb.dtype)
     d = torch.linalg.norm(pts[pb.corr_a1] - pts[pb.corr_a2], dim=-1)
-    return (pb.corr_conf @ gamma_rho(d, 1.1)) / pb.corr_conf.sum()
+    return (pb.corr_conf @ gamma_rho(d, gamma)) / pb.corr_conf.sum()
 
 
-def loss_2d(pb, K, w2cam, pts):                         # reconstruct.py:355-369 (+ reproj2d, App. A.5)
+def loss_2d(pb, K, w2cam, pts, gamma=0.4):              # reconstruct.py:355-369 (+ reproj2d, App. A.5; loss2, :119)
     if pb.c2d_a2.numel() == 0:
         return torch.zeros((), dtype=pb.dtype)
     P = K @ w2cam[:, :3]
@@ -131,24 +131,30 @@ def loss_2d(pb, K, w2cam, pts):                         # reconstruct.py:355-369
     r = (Pi[:, :, :3] @ p.unsqueeze(-1)).squeeze(-1) + Pi[:, :, 3]
     uv = (r[:, :2] / r[:, 2:3].clip(min=1e-3)).clip(min=-1000, max=2000)
     d = torch.linalg.norm(pb.c2d_pix - uv, dim=-1)
-    return (pb.c2d_conf @ gamma_rho(d, 0.4)) / pb.c2d_conf.sum()
+    return (pb.c2d_conf @ gamma_rho(d, gamma)) / pb.c2d_conf.sum()
 
 
-def loss_dust3r(pb, cam2w, pts):                        # reconstruct.py:311-323
+def loss_dust3r(pb, cam2w, pts, gamma=1.1):             # reconstruct.py:311-323 (lossd, :120)
     if pb.dust_a1.numel() == 0:
         return torch.zeros((), dtype=pb.dtype)
     T = cam2w[pb.dust_img2]
     tgt = (T[:, :3, :3] @ pb.dust_tgt.unsqueeze(-1)).squeeze(-1) + T[:, :3, 3]
     d = torch.linalg.norm(pts[pb.dust_a1] - tgt, dim=-1)
-    return (pb.dust_conf @ gamma_rho(d, 1.1)) / pb.dust_conf.sum()
+    return (pb.dust_conf @ gamma_rho(d, gamma)) / pb.dust_conf.sum()
 
 
 def cosine_schedule(alpha, lr_base, lr_end=0.0):
     return lr_end + (lr_base - lr_end) * (1 + np.cos(alpha * np.pi)) / 2
 
 
-def optimize_loop(pb, p, trainable, stage, lr_base, niter, loss_dust3r_w=0.01, losses=None):
+def linear_schedule(alpha, lr_base, lr_end=0.0):        # the other schedule the reference's helpers offer (App. A.5)
+    return (1 - alpha) * lr_base + alpha * lr_end
+
+
+def optimize_loop(pb, p, trainable, stage, lr_base, niter, loss_dust3r_w=0.01, losses=None, schedule=cosine_schedule,
+                  gamma=None, gammad=1.1):
     """reconstruct.py:371-406"""
+    gamma = (1.1 if stage == 1 else 0.4) if gamma is None else gamma
     for k, v in p.items():
         v.requires_grad_(k in trainable)
     opt = torch.optim.Adam([p[k] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")], lr=1,
@@ -158,12 +164,12 @@ def optimize_loop(pb, p, trainable, stage, lr_base, niter, loss_dust3r_w=0.01, l
         pts = make_pts3d(pb, K, cam2w, depth)
         if niter == 0:
             break
-        lr = cosine_schedule(it / niter, lr_base, 0)
+        lr = schedule(it / niter, lr_base, 0)
         for g in opt.param_groups:
             g["lr"] = lr
         opt.zero_grad()
-        main = loss_3d(pb, pts) if stage == 1 else loss_2d(pb, K, w2cam, pts)
-        loss = main + loss_dust3r_w * loss_dust3r(pb, cam2w, pts)
+        main = loss_3d(pb, pts, gamma) if stage == 1 else loss_2d(pb, K, w2cam, pts, gamma)
+        loss = main + loss_dust3r_w * loss_dust3r(pb, cam2w, pts, gammad)
         loss.backward()
         opt.step()
         with torch.no_grad():
@@ -176,7 +182,8 @@ def optimize_loop(pb, p, trainable, stage, lr_base, niter, loss_dust3r_w=0.01, l
     return dict(intrinsics=K.detach(), cam2w=cam2w.detach(), depthmaps=depth.detach(), pts3d=pts.detach())
 
 
-def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev=None, dtype=torch.float32, losses=None):
+def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev=None, dtype=torch.float32, losses=None,
+        schedule=cosine_schedule, gamma1=1.1, gamma2=0.4, gammad=1.1, opt_pp=True):
     """-> (result dict, params dict) like the reference's (res_fine or res_coarse, params_ret)."""
     pb = Problem(flat, dtype)
     if prev is not None and prev.get("core_depth") is not None:        # :414 -- the old views keep their core depth
@@ -185,10 +192,11 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev=None, dtype=torc
             n = min(pc.shape[0], pb.core.shape[0])
             pb.core = pb.core.clone(); pb.core[:n] = pc[:n]
     p = init_params(pb, prev)
-    res = optimize_loop(pb, p, {"quats", "trans", "log_sizes"}, 1, lr1, niter1, losses=losses)      # :418-427
+    kw = dict(losses=losses, schedule=schedule, gammad=gammad)
+    res = optimize_loop(pb, p, {"quats", "trans", "log_sizes"}, 1, lr1, niter1, gamma=gamma1, **kw)   # :418-427
     if niter2:
-        res = optimize_loop(pb, p, {"quats", "trans", "log_sizes", "pps", "log_focals"}, 2, lr2, niter2,
-                            losses=losses)                                                         # :430-440
+        train2 = {"quats", "trans", "log_sizes", "log_focals"} | ({"pps"} if opt_pp else set())     # :435-437
+        res = optimize_loop(pb, p, train2, 2, lr2, niter2, gamma=gamma2, **kw)                      # :430-440
     params = {k: v.detach().numpy().copy() for k, v in p.items()}
     params["core_depth"] = pb.core.numpy().copy()
     out = {k: v.numpy() for k, v in res.items()}

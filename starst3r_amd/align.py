@@ -13,12 +13,16 @@ from . import _lib, ops
 PARAM_KEYS = ("pps", "log_focals", "quats", "trans", "log_sizes")
 
 
-def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, loss_dust3r_w=0.01, device="cuda:0"):
+def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, loss_dust3r_w=0.01, device="cuda:0",
+        schedule=None, gamma1=1.1, gamma2=0.4, gammad=1.1, opt_pp=True):
     """flat: dict of numpy arrays (st3r_synth.synth_align.flatten layout).
     Returns (result, params): result has intrinsics [C,3,3], cam2w [C,4,4], depthmaps [C,G], pts3d [A,3],
     losses [niter1+niter2] (st3r_align_run stops updating after a NaN loss, like the reference's `break` at
     starster/reconstruct.py:397-398: the remaining entries stay 0); params holds the optimised parameters (and the normalised core_depth) so that a
-    later call can warm start from them (reconstruct.py:408-415)."""
+    later call can warm start from them (reconstruct.py:408-415).
+    schedule: callable (alpha, lr_base, lr_end) -> lr like the reference's `schedule` argument (reconstruct.py:122,
+    385), evaluated here once per iteration (None: cosine_schedule inside the library); gamma1 / gamma2 / gammad: the
+    exponents of loss1 / loss2 / lossd = gamma_loss(g) (:118-120); opt_pp (:121, 436)."""
     ctx = ops.get_context(device)
     dev = ctx.device
     f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev).contiguous()
@@ -84,7 +88,11 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
     pts = torch.empty(A, 3, device=dev)
     losses = torch.zeros(max(niter1 + niter2, 1), device=dev)
     p = ops._p
-    _lib.check(_lib.lib().st3r_align_run(
+    lr_host = None
+    if schedule is not None:   # reconstruct.py:384-385: alpha = iter / niter, lr = schedule(alpha, lr_base, lr_end = 0)
+        lrs = [float(schedule(it / n, lr, 0)) for lr, n in ((lr1, niter1), (lr2, niter2)) for it in range(n)]
+        lr_host = np.ascontiguousarray(np.asarray(lrs + [0.0], np.float32))
+    _lib.check(_lib.lib().st3r_align_run_opts(
         ctx.handle, ops._stream(), Cn, G, A, p(imsizes), p(base_focals), p(median), p(core), p(min_f), p(max_f),
         p(anchor_pix), p(anchor_idx, torch.int32), p(anchor_off), p(anchor_img, torch.int32),
         corr_a1.numel(), p(corr_a1, torch.int32), p(corr_a2, torch.int32), p(corr_w),
@@ -92,7 +100,8 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
         dust_a1.numel(), p(dust_a1, torch.int32), p(dust_tgt), p(dust_img2, torch.int32), p(dust_w),
         int(flat["mst_root"]), edges.shape[0], p(edges, torch.int32), lr1, niter1, lr2, niter2, loss_dust3r_w,
         p(P["pps"]), p(P["log_focals"]), p(P["quats"]), p(P["trans"]), p(P["log_sizes"]),
-        p(work), work.numel(), p(cam), p(pts), p(losses)))
+        p(work), work.numel(), p(cam), p(pts), p(losses),
+        lr_host.ctypes.data if lr_host is not None else None, float(gamma1), float(gamma2), float(gammad), int(bool(opt_pp))))
     K = torch.zeros(Cn, 3, 3, device=dev)
     K[:, 0, 0] = K[:, 1, 1] = cam[:, 12]; K[:, 0, 2] = cam[:, 13]; K[:, 1, 2] = cam[:, 14]; K[:, 2, 2] = 1
     cam2w = torch.zeros(Cn, 4, 4, device=dev)

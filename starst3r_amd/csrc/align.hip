@@ -42,6 +42,9 @@ struct AlignProblem {
     int root; int n_edges; const int32_t* edges;  // [n_edges,2] in chain order
     const float* min_focals; const float* max_focals;
     const float4* anchor_pack;  // [A,2] packed once per run: (u, v, core value, offset) | (img as int bits, 0, 0, 0)
+    // robust losses gamma_loss(gamma) of the three row kinds (reconstruct.py:118-120: loss1, loss2, lossd) and their
+    // offsets (1/gamma)^(1/(gamma-1)); gamma = 1 is the plain L1 distance (offset 0)
+    float gamma1, off1, gamma2, off2, gammad, offd;
 };
 
 struct AlignState {
@@ -55,6 +58,7 @@ struct AlignState {
 
 __device__ __forceinline__ float rho_prime(float d, float gamma, float off, float* rho) {
     // gamma_loss(gamma): rho(d) = (d + off)^gamma - off^gamma, off = (1/gamma)^(1/(gamma-1))
+    if (gamma == 1.0f) { *rho = d; return 1.0f; }
     const float b = d + off;
     const float pw = __powf(b, gamma - 1.0f);
     *rho = pw * b - __powf(off, gamma);
@@ -196,8 +200,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 const float ex = p1.pw[0] - p2.pw[0], ey = p1.pw[1] - p2.pw[1], ez = p1.pw[2] - p2.pw[2];
                 const float d = sqrtf(ex * ex + ey * ey + ez * ez);
                 float rho;
-                const float o11 = __powf(1.0f / 1.1f, 10.0f);
-                const float rp = rho_prime(d, 1.1f, o11, &rho);
+                const float rp = rho_prime(d, P.gamma1, P.off1, &rho);
                 const float w = P.corr_w[row];
                 lsum = w * rho;
                 if (d > 1e-20f) {
@@ -225,8 +228,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 const float du = P.c2d_pix[2 * row] - u, dv = P.c2d_pix[2 * row + 1] - v;
                 const float d = sqrtf(du * du + dv * dv);
                 float rho;
-                const float o04 = __powf(2.5f, -1.0f / 0.6f);  // (1/0.4)^(1/(0.4-1))
-                const float rp = rho_prime(d, 0.4f, o04, &rho);
+                const float rp = rho_prime(d, P.gamma2, P.off2, &rho);
                 const float w = P.c2d_w[row];
                 lsum = w * rho;
                 if (d > 1e-20f) {
@@ -267,8 +269,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
             const float ex = p1.pw[0] - gx, ey = p1.pw[1] - gy, ez = p1.pw[2] - gz;
             const float d = sqrtf(ex * ex + ey * ey + ez * ez);
             float rho;
-            const float o11 = __powf(1.0f / 1.1f, 10.0f);
-            const float rp = rho_prime(d, 1.1f, o11, &rho);
+            const float rp = rho_prime(d, P.gammad, P.offd, &rho);
             const float w = dust_w * P.dust_w[r];
             lsum = w * rho;
             if (d > 1e-20f) {
@@ -338,6 +339,7 @@ struct UpdateArgs {
     int step;          // 1-based Adam step within the stage
     int loss_index;    // where to store the loss of the step just evaluated
     int reset_moments; // first step of a stage: fresh optimiser (reconstruct.py:374)
+    int opt_pp;        // stage 2 also moves the principal points (reconstruct.py:436)
 };
 
 // The chain walks are sequential over the MST edges, but the 12 (forward) / 24 (reverse) numbers of one edge are
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
             const float step_size = (float)((double)U.lr / bc1), bc2_sqrt = (float)sqrt(bc2);
             const float w1 = (float)(1.0 - 0.9), b2 = 0.9f, eps = 1e-8f;
             for (int k = 0; k < 11; ++k) {
-                const bool trainable = (k >= 3) || (U.stage == 2);
+                const bool trainable = (k >= 3) || (U.stage == 2 && (k == 2 || U.opt_pp));
                 if (!trainable) continue;
                 const float gk = grad[k];
                 float mk = S.m[moff[k]], vk = S.v[moff[k]];
@@ -603,7 +605,11 @@ __global__ void k_align_points(AlignProblem P, AlignState S, int n_anchors, floa
     pts[3 * a] = r.pw[0]; pts[3 * a + 1] = r.pw[1]; pts[3 * a + 2] = r.pw[2];
 }
 
-ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
+static float gamma_offset(float gamma) {
+    return gamma == 1.0f ? 0.0f : (float)pow(1.0 / (double)gamma, 1.0 / ((double)gamma - 1.0));
+}
+
+ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
                                const float* base_focals, const float* median, const float* core,
                                const float* min_focals, const float* max_focals, const float* anchor_pix,
                                const int32_t* anchor_idx, const float* anchor_off, const int32_t* anchor_img,
@@ -613,8 +619,10 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
                                const int32_t* dust_img2, const float* dust_w, int root, int n_edges,
                                const int32_t* edges, float lr1, int niter1, float lr2, int niter2, float dust_weight,
                                float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
-                               float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out) {
+                               float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out,
+                               const float* lr_host, float gamma1, float gamma2, float gammad, int opt_pp) {
     ARG_CHECK(ctx && C > 0 && C <= MAXC && G > 0 && n_anchors >= 0 && niter1 >= 0 && niter2 >= 0);
+    ARG_CHECK(gamma1 > 0.f && gamma2 > 0.f && gammad > 0.f);
     ARG_CHECK(imsizes && base_focals && median && core && min_focals && max_focals && pps && log_focals && quats &&
               trans && log_sizes && work && cam_out && edges);
     ARG_CHECK(n_edges == C - 1 && root >= 0 && root < C);
@@ -628,6 +636,8 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
     P.n_c2d = n_c2d; P.c2d_pix = c2d_pix; P.c2d_a2 = c2d_a2; P.c2d_img1 = c2d_img1; P.c2d_w = c2d_w;
     P.n_dust = n_dust; P.dust_a1 = dust_a1; P.dust_tgt = dust_tgt; P.dust_img2 = dust_img2; P.dust_w = dust_w;
     P.root = root; P.n_edges = n_edges; P.edges = edges; P.min_focals = min_focals; P.max_focals = max_focals;
+    P.gamma1 = gamma1; P.off1 = gamma_offset(gamma1); P.gamma2 = gamma2; P.off2 = gamma_offset(gamma2);
+    P.gammad = gammad; P.offd = gamma_offset(gammad);
     AlignState S;
     S.pps = pps; S.log_focals = log_focals; S.quats = quats; S.trans = trans; S.log_sizes = log_sizes;
     S.m = work; S.v = work + 11 * C; S.cam = work + 22 * C; S.acc = S.cam + (int64_t)C * CAM_STRIDE;
@@ -655,7 +665,7 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
             hipLaunchKernelGGL(k_align_pack_anchors, dim3(ceil_div(n_anchors, 256)), dim3(256), 0, s, n_anchors, anchor_pix,
                                anchor_idx, anchor_off, anchor_img, core, G, (float4*)pk);
     }
-    UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0};
+    UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0, 1};
     hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U0);
     // The reference returns K / cam2w / depthmaps / pts3d as computed at the START of the last iteration,
     // i.e. one optimiser step behind the returned parameters (optimize_loop builds them before
@@ -682,11 +692,31 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
             if (n_part > 32) hipLaunchKernelGGL(k_align_reduce, dim3(ceil_div(nacc, 256)), dim3(256), 0, s, S, nacc, n_part);
             UpdateArgs U;
             U.n_part = n_part > 32 ? -1 : n_part; U.do_backward = 1; U.stage = stage;
-            U.lr = (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
-            U.step = it + 1; U.loss_index = li++; U.reset_moments = (it == 0);
+            U.lr = lr_host ? lr_host[li]   // the caller's schedule(alpha, lr_base, lr_end), evaluated per iteration
+                           : (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
+            U.step = it + 1; U.loss_index = li++; U.reset_moments = (it == 0); U.opt_pp = opt_pp;
             hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U);
         }
     }
     LAUNCH_CHECK();
     return ST3R_OK;
+}
+
+// The reference's own configuration (reconstruct.py:118-122 defaults): gamma losses 1.1 / 0.4 / 1.1, cosine schedule, opt_pp.
+ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
+                               const float* base_focals, const float* median, const float* core,
+                               const float* min_focals, const float* max_focals, const float* anchor_pix,
+                               const int32_t* anchor_idx, const float* anchor_off, const int32_t* anchor_img,
+                               int n_corr, const int32_t* corr_a1, const int32_t* corr_a2, const float* corr_w,
+                               int n_c2d, const float* c2d_pix, const int32_t* c2d_a2, const int32_t* c2d_img1,
+                               const float* c2d_w, int n_dust, const int32_t* dust_a1, const float* dust_tgt,
+                               const int32_t* dust_img2, const float* dust_w, int root, int n_edges,
+                               const int32_t* edges, float lr1, int niter1, float lr2, int niter2, float dust_weight,
+                               float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
+                               float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out) {
+    return st3r_align_run_opts(ctx, stream, C, G, n_anchors, imsizes, base_focals, median, core, min_focals, max_focals,
+                               anchor_pix, anchor_idx, anchor_off, anchor_img, n_corr, corr_a1, corr_a2, corr_w, n_c2d,
+                               c2d_pix, c2d_a2, c2d_img1, c2d_w, n_dust, dust_a1, dust_tgt, dust_img2, dust_w, root,
+                               n_edges, edges, lr1, niter1, lr2, niter2, dust_weight, pps, log_focals, quats, trans,
+                               log_sizes, work, work_floats, cam_out, pts_out, losses_out, nullptr, 1.1f, 0.4f, 1.1f, 1);
 }

@@ -28,6 +28,7 @@ st3r_synth.synth_model.SyntheticPairwiseModel implements it on synthetic scenes 
 __all__ = ("reconstruct_scene", "reconstruct", "run_sparse_ga", "sparse_scene_optimizer_slam",
            "flatten_reference_inputs")
 
+import math
 import tempfile
 
 import numpy as np
@@ -151,6 +152,56 @@ def flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchor
     return out
 
 
+def l1_loss(x, y):
+    """Euclidean distance of two point sets (the `l1_loss` Mast3r's gamma_loss builds on)."""
+    return torch.linalg.norm(x - y, dim=-1)
+
+
+def gamma_loss(gamma):
+    """The robust loss the reference passes as loss1 / loss2 / lossd (starster/reconstruct.py:118-120):
+    rho(x, y) = (|x - y| + off)^gamma - off^gamma, off = (1/gamma)^(1/(gamma-1)); gamma = 1 is `l1_loss`.  The returned
+    callable carries `.gamma`, which is all the library needs (the loss itself is evaluated inside k_align_resid)."""
+    if gamma == 1:
+        return l1_loss
+    off = (1 / gamma) ** (1 / (gamma - 1))
+
+    def loss_func(x, y):
+        return (l1_loss(x, y) + off) ** gamma - off ** gamma
+    loss_func.gamma = float(gamma)
+    return loss_func
+
+
+def cosine_schedule(alpha, lr_base, lr_end=0.0):
+    return lr_end + (lr_base - lr_end) * (1 + math.cos(alpha * math.pi)) / 2
+
+
+def linear_schedule(alpha, lr_base, lr_end=0.0):
+    return (1 - alpha) * lr_base + alpha * lr_end
+
+
+def _gamma_of(loss, default):
+    """Exponent of a gamma_loss object: ours (`.gamma`), Mast3r's closure (free variables gamma / mul / offset / clip), or
+    l1_loss (gamma = 1).  Anything else cannot be evaluated by the kernels."""
+    if loss is None:
+        return default
+    g = getattr(loss, "gamma", None)
+    if g is None and getattr(loss, "__name__", "") == "l1_loss":
+        g = 1.0
+    if g is None and getattr(loss, "__closure__", None):
+        fv = dict(zip(loss.__code__.co_freevars, (c.cell_contents for c in loss.__closure__)))
+        if "gamma" in fv:
+            g = float(fv["gamma"])
+            off = fv.get("offset")
+            if fv.get("mul", 1) != 1 or fv.get("clip", float("inf")) != float("inf") or \
+                    (off is not None and abs(off - (1 / g) ** (1 / (g - 1))) > 1e-6 * abs(off)):
+                raise NotImplementedError("gamma_loss with mul / clip / a custom offset is not implemented on the HIP path")
+    if g is None or "meta" in repr(loss):
+        raise NotImplementedError("only gamma_loss(g) / l1_loss objects can be evaluated on the HIP path")
+    if not g > 0:
+        raise ValueError("gamma_loss: gamma must be positive")
+    return float(g)
+
+
 def sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d,
                                 preds_21, canonical_paths, mst, cache_path=None, lr1=0.2, niter1=500, loss1=None,
                                 lr2=0.02, niter2=500, loss2=None, lossd=None, opt_pp=True, opt_depth=True,
@@ -160,20 +211,21 @@ def sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core
     """Same signature and return value as the reference's optimiser (starster/reconstruct.py:116-457):
     `(imgs, res_coarse, res_fine, params_ret)` with `res = dict(intrinsics, cam2w, depthmaps, pts3d)` and
     `params_ret` the dict of per-view parameter lists a later call accepts as `prev_params`.  The optimisation
-    itself is st3r_align_run.  Implemented: the configuration the reference uses (:61-69, :118-126 defaults):
-    gamma losses 1.1 / 0.4 / 1.1, cosine schedule, opt_pp, depth_mode 'add', no shared intrinsics, no depth
-    optimisation; anything else raises.  The stage-1 result is not kept separately (the reference's only caller
-    takes `res_fine or res_coarse`, :113): `res_coarse` is `res_fine` when a second stage ran."""
-    if opt_depth or shared_intrinsics or exp_depth or lora_depth or depth_mode != "add" or not opt_pp or init:
-        raise NotImplementedError("only the reference's own configuration (opt_depth=False, shared_intrinsics=False, "
-                                  "depth_mode='add', opt_pp=True, no init) runs on the HIP path")
-    if loss1 is not None or loss2 is not None or lossd is not None or schedule is not None:
-        raise NotImplementedError("the robust losses (gamma 1.1 / 0.4 / 1.1) and the cosine schedule are built into the kernels")
+    itself is st3r_align_run_opts.  Implemented: the configuration the reference uses (:61-69) and the options that
+    only change constants of the loop -- loss1 / loss2 / lossd = gamma_loss(g) (any g; `gamma_loss` below, Mast3r's own
+    closures, or `l1_loss`), any `schedule(alpha, lr_base, lr_end)` callable, `opt_pp`.  opt_depth, shared_intrinsics,
+    exp_depth, lora_depth, depth_mode != 'add' and `init` raise.  The stage-1 result is not kept separately (the
+    reference's only caller takes `res_fine or res_coarse`, :113): `res_coarse` is `res_fine` when a second stage ran."""
+    if opt_depth or shared_intrinsics or exp_depth or lora_depth or depth_mode != "add" or init:
+        raise NotImplementedError("opt_depth, shared_intrinsics, exp_depth, lora_depth, depth_mode != 'add' and per-image "
+                                  "`init` are not implemented on the HIP path (the reference's own call uses none of them)")
+    g1, g2, gd = _gamma_of(loss1, 1.1), _gamma_of(loss2, 0.4), _gamma_of(lossd, 1.1)
     flat = flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21,
                                     mst, matching_conf_thr)
     dev = "cuda:0" if str(device) == "cuda" else str(device)
     res, params = align.run(flat, lr1=lr1, niter1=niter1, lr2=lr2, niter2=niter2, prev_params=prev_params,
-                            loss_dust3r_w=loss_dust3r_w, device=dev)
+                            loss_dust3r_w=loss_dust3r_w, device=dev, schedule=schedule, gamma1=g1, gamma2=g2, gammad=gd,
+                            opt_pp=bool(opt_pp))
     off = flat["anchor_off"]
     C = len(imgs)
     clen = flat["core_len"]

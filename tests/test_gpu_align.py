@@ -83,6 +83,50 @@ def test_full_schedule_vs_reference_golden(name):
     assert np.all(np.isfinite(L)) and L[499] < L[0] and L[-1] < L[500]
 
 
+def test_non_default_options_vs_reference_golden():
+    """loss1 / loss2 / lossd = gamma_loss(1.5 / 0.6 / 1), linear schedule, principal points frozen -- the options of
+    sparse_scene_optimizer_slam (starster/reconstruct.py:118-122) that st3r_align_run_opts implements, against the
+    reference's own run with them (golden align_c3_opts) and through the reference's signature."""
+    from test_oracle_align import OPTS, OPTS_DRIFT_BOUND
+    z, flat = load("align_c3_opts")
+    res, par = run_hip(flat, niter1=10, niter2=0, **OPTS)
+    compare(res, par, *golden(z, "r10_0"), 1e-4, "opts r10")
+    res, par = run_hip(flat, niter1=500, niter2=200, **OPTS)
+    # (tolerances: this configuration's own float32 floor is 2.7e-4, see tests/test_oracle_align.py)
+    compare(res, par, *golden(z, "r500_200"), 1e-3, "opts r500_200")
+    d64 = drift(gauge_free(res, par, 0), gauge_free(*golden(z, "f64_r500_200"), 0))
+    print("options: HIP-reference64 %.2e" % d64)
+    assert d64 <= OPTS_DRIFT_BOUND
+    np.testing.assert_array_equal(par["pps"], run_hip(flat, niter1=0, niter2=0)[1]["pps"])    # opt_pp = False
+    # the same through sparse_scene_optimizer_slam with loss / schedule OBJECTS: ours and a Mast3r-style closure
+    import importlib
+    rc = importlib.import_module("starst3r_amd.reconstruct")
+    from st3r_synth import synth_align
+
+    def mast3r_style_gamma_loss(gamma, mul=1, offset=None, clip=np.inf):
+        if offset is None:
+            offset = (1 / gamma) ** (1 / (gamma - 1))
+
+        def loss_func(x, y):
+            return (mul * rc.l1_loss(x, y).clip(max=clip) + offset) ** gamma - offset ** gamma
+        return loss_func
+    P = synth_align.make_problem(n_views=3, n_corr=300, seed=7, bad_pair=True)
+    a = synth_align.to_reference_inputs(P)
+    _, coarse, fine, params = rc.sparse_scene_optimizer_slam(
+        a["imgs"], a["subsample"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"],
+        a["corres2d"], a["preds_21"], a["canonical_paths"], a["mst"], lr1=0.07, niter1=500, lr2=0.014, niter2=200,
+        loss1=rc.gamma_loss(1.5), loss2=mast3r_style_gamma_loss(0.6), lossd=rc.gamma_loss(1), schedule=rc.linear_schedule,
+        opt_pp=False, opt_depth=False, device="cuda:0")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(fine["intrinsics"].cpu().numpy(), res["intrinsics"], rtol=1e-6)
+    np.testing.assert_allclose(torch.stack([q.reshape(-1) for q in params["quats"]]).cpu().numpy(), par["quats"], atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        rc.sparse_scene_optimizer_slam(
+            a["imgs"], a["subsample"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"],
+            a["corres2d"], a["preds_21"], a["canonical_paths"], a["mst"], loss1=lambda x, y: (x - y).abs().sum(-1),
+            opt_depth=False, device="cuda:0")
+
+
 def _perturbed_params(C, seed):
     rng = np.random.default_rng(seed)
     q = np.tile(np.array([[0, 0, 0, 1.0]]), (C, 1)) + 0.1 * rng.standard_normal((C, 4))

@@ -84,6 +84,31 @@ def test_full_schedule_matches_reference(name):
     check(z, "r500_200", res, params, 4e-4)
 
 
+OPTS_DRIFT_BOUND = 7e-4
+OPTS = dict(schedule=ao.linear_schedule, gamma1=1.5, gamma2=0.6, gammad=1.0, opt_pp=False)   # = align_c3_opts.npz
+
+
+def test_non_default_options_match_reference():
+    """Golden align_c3_opts: the reference's optimiser run with loss1 / loss2 / lossd = gamma_loss(1.5 / 0.6 / 1),
+    schedule = linear_schedule and opt_pp = False (tools/gen_align_goldens.py; starster/reconstruct.py:118-122)."""
+    z, flat = load("align_c3_opts")
+    res, params = ao.run(flat, niter1=10, niter2=0, **OPTS)
+    check(z, "r10_0", res, params, 2e-5)
+    # this configuration drifts more in float32 than the default one (gamma 1.5: larger gradients; the linear schedule
+    # keeps the rate high for longer): the reference's own float32 run ends 2.7e-4 from its float64 evaluation
+    # (f64_r500_200), so float32 results are held to OPTS_DRIFT_BOUND = 7e-4 from float64 and 1e-3 from each other
+    res, params = ao.run(flat, niter1=500, niter2=0, **OPTS)
+    check(z, "r500_0", res, params, 5e-4)
+    res, params = ao.run(flat, niter1=500, niter2=200, **OPTS)
+    check(z, "r500_200", res, params, 1e-3)
+    g32, g64 = gauge_free(*golden(z, "r500_200"), 0), gauge_free(*golden(z, "f64_r500_200"), 0)
+    d_ref, d_orc = drift(g32, g64), drift(gauge_free(res, params, 0), g64)
+    print("options: reference32-reference64 %.2e  oracle32-reference64 %.2e" % (d_ref, d_orc))
+    assert d_ref <= OPTS_DRIFT_BOUND and d_orc <= OPTS_DRIFT_BOUND
+    # principal points frozen: still the initial values
+    np.testing.assert_array_equal(params["pps"], ao.run(flat, niter1=0, niter2=0)[1]["pps"])
+
+
 def golden(z, tag):
     par = {k: z[f"{tag}__p_{k}"] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")}
     res = {k: z[f"{tag}__{k}"] for k in ("intrinsics", "cam2w", "depthmaps", "pts3d")}

@@ -55,6 +55,10 @@ def cosine_schedule(alpha, lr_base, lr_end=0):
     return lr_end + (lr_base - lr_end) * (1 + np.cos(alpha * np.pi)) / 2
 
 
+def linear_schedule(alpha, lr_base, lr_end=0):
+    return (1 - alpha) * lr_base + alpha * lr_end
+
+
 def adjust_learning_rate_by_lr(optimizer, lr):
     for g in optimizer.param_groups:
         g["lr"] = lr * g["lr_scale"] if "lr_scale" in g else lr
@@ -123,7 +127,7 @@ def _to_f64(x):
     return x
 
 
-def run_reference(ref, P, niter1, niter2, f64=False):
+def run_reference(ref, P, niter1, niter2, f64=False, **extra):
     """f64: the SAME reference function evaluated in float64 (its own `dtype` argument + torch's default dtype): the
     yardstick that tells how far a float32 trajectory -- the reference's included -- drifts from the exact one."""
     a = to_reference_inputs(P)
@@ -138,7 +142,8 @@ def run_reference(ref, P, niter1, niter2, f64=False):
                 a["imgs"], a["subsample"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"],
                 a["corres"], a["corres2d"], a["preds_21"], a["canonical_paths"], a["mst"], cache_path=None,
                 lr1=0.07, niter1=niter1, lr2=0.014, niter2=niter2, device="cpu", opt_depth=False, dtype=dtype,
-                matching_conf_thr=5, shared_intrinsics=False)  # the reference's own settings, reconstruct.py:61-69
+                matching_conf_thr=5, shared_intrinsics=False,  # the reference's own settings, reconstruct.py:61-69
+                **extra)
     finally:
         torch.set_default_dtype(torch.float32)
     res = fine or coarse
@@ -163,6 +168,23 @@ def main():
                # one landscape, one portrait, one smaller landscape photo: core-depth vectors of 3072 / 3072 / 1728 values
                ("align_c3_mixed_sizes", dict(n_views=3, n_corr=300, seed=5, sizes=[(512, 384), (384, 512), (384, 288)]))]
     only = sys.argv[1:]
+    if not only or "align_c3_opts" in only:
+        # non-default optimiser options of the same function (reconstruct.py:118-122): other robust losses, the linear
+        # schedule, principal points frozen
+        P = synth_align.make_problem(n_views=3, n_corr=300, seed=7, bad_pair=True)
+        flat = synth_align.flatten(P)
+        runs = {}
+        opts = dict(loss1=gamma_loss(1.5), loss2=gamma_loss(0.6), lossd=gamma_loss(1), schedule=linear_schedule, opt_pp=False)
+        for (n1, n2) in ((10, 0), (500, 0), (500, 200)):
+            r = run_reference(ref, P, n1, n2, **opts)
+            for k, v in r.items():
+                runs[f"r{n1}_{n2}__{k}"] = v.astype(np.float32) if v.dtype.kind == "f" else v
+            print("align_c3_opts", (n1, n2), "focals", r["intrinsics"][:, 0, 0])
+        r = run_reference(ref, P, 500, 200, f64=True, **opts)
+        for k, v in r.items():
+            runs[f"f64_r500_200__{k}"] = v
+        np.savez_compressed(os.path.join(out_dir, "align_c3_opts.npz"), **{"in__" + k: v for k, v in flat.items()}, **runs)
+        print("wrote align_c3_opts", os.path.getsize(os.path.join(out_dir, "align_c3_opts.npz")) // 1024, "KiB")
     configs = [c for c in configs if not only or c[0] in only]
     for name, kw in configs:
         P = synth_align.make_problem(**kw)
