@@ -473,29 +473,6 @@ def main():
             t = torch.tensor([e0.elapsed_time(e1) / reps], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             exch_ms = float(t.item())
-    # the whole step under each exchange form of st3r_gs_train_step (after the timed region: a few extra steps each;
-    # rs_ag leaves the Adam moments sharded, which no longer matters here)
-    forms_ms = None
-    if dist is not None and mode != "gaussian-sharded" and native_comm and not FREEZE:
-        forms_ms = {}
-        keep = os.environ.get("ST3R_EXCHANGE")
-        it_x = total - 1
-        for form in ("allreduce", "ranges", "rs_ag"):
-            os.environ["ST3R_EXCHANGE"] = form
-            step(it_x)                                   # warm-up of the form (streams, staging buffers)
-            dist.barrier(); torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                step(it_x)
-            e1.record(); torch.cuda.synchronize()
-            t = torch.tensor([e0.elapsed_time(e1) / 5], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            forms_ms[form] = float(t.item())
-        if keep is None:
-            os.environ.pop("ST3R_EXCHANGE", None)
-        else:
-            os.environ["ST3R_EXCHANGE"] = keep
     if mode == "gaussian-sharded":   # counts of the own Gaussians over all views ~ those of the own views over all Gaussians
         stats["n_visible"] = int(trainer.reg[2].item()); stats["n_isects_ref"] = int(trainer.reg[3].item())
     if world > 1:
@@ -561,7 +538,9 @@ def main():
             # every rank's own ms per step over the timed region (HIP events on its launch stream) and, for N > 1, one
             # exchange of the [23N] gradient buffer on its own (max over ranks): step - exchange ~ what a rank computes
             "per_rank": {"ms_per_step": per_rank_ms, "exchange_ms_isolated": exch_ms,
-                         "exchange_forms_ms_per_step": forms_ms,
+                         # (the whole step under the other exchange forms -- ranges, rs_ag -- is timed AFTER this line is
+                         # out and reported on stderr / gpurun_out/exchange_forms_n<N>.json: those forms have never run
+                         # with more than one rank, and a hang there must not cost the measurement)
                          "exchange": os.environ.get("ST3R_EXCHANGE", "allreduce" if dist is not None else "none")},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -599,6 +578,42 @@ def main():
             out["matching"] = matching_bench(device, with_cpu=not args.no_cpu_baseline)
             out["condense"] = condense_bench(device, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
+    # ---- after the line: the whole step under each exchange form of st3r_gs_train_step (a few extra steps each; rs_ag
+    # leaves the Adam moments sharded, which no longer matters here).  Every rank arms a watchdog first: the forms other
+    # than the plain all-reduce have only ever run with one rank, and a hung collective cannot be interrupted in-process.
+    if dist is not None and mode != "gaussian-sharded" and native_comm and not FREEZE:
+        import threading
+        wd = threading.Timer(120.0, lambda: (sys.stderr.write("bench.py: exchange-form timing timed out\n"), os._exit(0)))
+        wd.daemon = True; wd.start()
+        forms_ms = {}
+        keep = os.environ.get("ST3R_EXCHANGE")
+        it_x = total - 1
+        for form in ("allreduce", "ranges", "rs_ag"):
+            os.environ["ST3R_EXCHANGE"] = form
+            step(it_x)                                   # warm-up of the form (streams, staging buffers)
+            dist.barrier(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                step(it_x)
+            e1.record(); torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / 5], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            forms_ms[form] = float(t.item())
+        if keep is None:
+            os.environ.pop("ST3R_EXCHANGE", None)
+        else:
+            os.environ["ST3R_EXCHANGE"] = keep
+        wd.cancel()
+        if rank == 0:
+            rec = {"n_gpus": world, "exchange_forms_ms_per_step": forms_ms}
+            print("exchange forms: " + json.dumps(rec), file=sys.stderr, flush=True)
+            try:
+                os.makedirs("gpurun_out", exist_ok=True)
+                with open(os.path.join("gpurun_out", f"exchange_forms_n{world}.json"), "w") as f:
+                    json.dump(rec, f)
+            except OSError:
+                pass
     if dist is not None:
         dist.destroy_process_group()
 
