@@ -257,9 +257,17 @@ int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, con
  *   gamma1/2/d exponents of the robust losses gamma_loss(g) of loss_3d (loss1), loss_2d (loss2) and loss_dust3r
  *              (lossd): rho(d) = (d + off)^g - off^g with off = (1/g)^(1/(g-1)); g = 1 is the plain distance;
  *   opt_pp     0: the principal points stay fixed in the second stage (reconstruct.py:436).
- * opt_depth, shared_intrinsics, exp_depth, lora_depth and per-image `init` freezes are not implemented. */
+ *   opt_depth  (reconstruct.py:437: the core depths are parameters of the second stage too) is on when depth_csr_off is
+ *              not NULL.  The caller groups the rows of stage 2 -- the n_c2d loss_2d rows, then the n_dust regression
+ *              rows, numbered in that order -- by the core depth (img * G + anchor_idx) of the row's anchor (c2d_a2 /
+ *              dust_a1): depth_csr_off int32 [C*G + 1], depth_csr_rows int32 [n_c2d + n_dust].  A core depth's
+ *              gradient is the sum over its rows in that order (no float atomics).  `core` is then updated IN PLACE;
+ *              depth_work: >= n_c2d + n_dust + 3*C*G floats of scratch whose last C*G floats return the core depths
+ *              the exported results belong to (the reference's results are one optimiser step behind its parameters,
+ *              reconstruct.py:379-380, 405-406): depthmap = A + B * that.
+ * shared_intrinsics, exp_depth, lora_depth and per-image `init` freezes are not implemented. */
 int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
-                        const float* base_focals, const float* median, const float* core, const float* min_focals,
+                        const float* base_focals, const float* median, float* core, const float* min_focals,
                         const float* max_focals, const float* anchor_pix, const int32_t* anchor_idx,
                         const float* anchor_off, const int32_t* anchor_img, int n_corr, const int32_t* corr_a1,
                         const int32_t* corr_a2, const float* corr_w, int n_c2d, const float* c2d_pix,
@@ -268,7 +276,9 @@ int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors
                         int root, int n_edges, const int32_t* edges, float lr1, int niter1, float lr2, int niter2,
                         float dust_weight, float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
                         float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out,
-                        const float* lr_host, float gamma1, float gamma2, float gammad, int opt_pp);
+                        const float* lr_host, float gamma1, float gamma2, float gammad, int opt_pp,
+                        const int32_t* depth_csr_off, const int32_t* depth_csr_rows, float* depth_work,
+                        int64_t depth_work_floats);
 
 /* ------------------------------------------------------------------------------------
  * Path A -- matching.  The nearest-neighbour query of Mast3r's fast_reciprocal_NNs with

@@ -157,8 +157,10 @@ def optimize_loop(pb, p, trainable, stage, lr_base, niter, loss_dust3r_w=0.01, l
     gamma = (1.1 if stage == 1 else 0.4) if gamma is None else gamma
     for k, v in p.items():
         v.requires_grad_(k in trainable)
-    opt = torch.optim.Adam([p[k] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")], lr=1,
-                           weight_decay=0, betas=(0.9, 0.9))
+    core_trainable = "core_depth" in trainable                          # opt_depth (:437)
+    pb.core.requires_grad_(core_trainable)
+    opt = torch.optim.Adam([p[k] for k in ("pps", "log_focals", "quats", "trans", "log_sizes")] +
+                           ([pb.core] if core_trainable else []), lr=1, weight_decay=0, betas=(0.9, 0.9))
     for it in range(niter or 1):
         K, w2cam, cam2w, depth = make_K_cam_depth(pb, p)
         pts = make_pts3d(pb, K, cam2w, depth)
@@ -183,7 +185,7 @@ def optimize_loop(pb, p, trainable, stage, lr_base, niter, loss_dust3r_w=0.01, l
 
 
 def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev=None, dtype=torch.float32, losses=None,
-        schedule=cosine_schedule, gamma1=1.1, gamma2=0.4, gammad=1.1, opt_pp=True):
+        schedule=cosine_schedule, gamma1=1.1, gamma2=0.4, gammad=1.1, opt_pp=True, opt_depth=False):
     """-> (result dict, params dict) like the reference's (res_fine or res_coarse, params_ret)."""
     pb = Problem(flat, dtype)
     if prev is not None and prev.get("core_depth") is not None:        # :414 -- the old views keep their core depth
@@ -196,9 +198,12 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev=None, dtype=torc
     res = optimize_loop(pb, p, {"quats", "trans", "log_sizes"}, 1, lr1, niter1, gamma=gamma1, **kw)   # :418-427
     if niter2:
         train2 = {"quats", "trans", "log_sizes", "log_focals"} | ({"pps"} if opt_pp else set())     # :435-437
+        if opt_depth:
+            pb.core = pb.core.clone()
+            train2.add("core_depth")
         res = optimize_loop(pb, p, train2, 2, lr2, niter2, gamma=gamma2, **kw)                      # :430-440
     params = {k: v.detach().numpy().copy() for k, v in p.items()}
-    params["core_depth"] = pb.core.numpy().copy()
+    params["core_depth"] = pb.core.detach().numpy().copy()
     out = {k: v.numpy() for k, v in res.items()}
     out["core_len"] = np.asarray(pb.core_len, np.int64)      # true lengths of the padded core-depth rows
     return out, params

@@ -49,7 +49,7 @@ SIGNATURES = {
                        vp, vp, vp],
     "st3r_align_run_opts": [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp,
                             vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, f32, i32, f32, i32, f32, vp, vp, vp, vp, vp, vp,
-                            i64, vp, vp, vp, vp, f32, f32, f32, i32],
+                            i64, vp, vp, vp, vp, f32, f32, f32, i32, vp, vp, vp, i64],
     "st3r_nn_dot_argmax": [vp, vp, vp, i32, vp, i32, i32, vp, vp],
     "st3r_mcmc_relocate": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, f32, u64, u32, C.POINTER(i64)],
     "st3r_mcmc_add": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, u64, u32],

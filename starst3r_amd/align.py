@@ -14,7 +14,7 @@ PARAM_KEYS = ("pps", "log_focals", "quats", "trans", "log_sizes")
 
 
 def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, loss_dust3r_w=0.01, device="cuda:0",
-        schedule=None, gamma1=1.1, gamma2=0.4, gammad=1.1, opt_pp=True):
+        schedule=None, gamma1=1.1, gamma2=0.4, gammad=1.1, opt_pp=True, opt_depth=False):
     """flat: dict of numpy arrays (st3r_synth.synth_align.flatten layout).
     Returns (result, params): result has intrinsics [C,3,3], cam2w [C,4,4], depthmaps [C,G], pts3d [A,3],
     losses [niter1+niter2] (st3r_align_run stops updating after a NaN loss, like the reference's `break` at
@@ -22,7 +22,9 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
     later call can warm start from them (reconstruct.py:408-415).
     schedule: callable (alpha, lr_base, lr_end) -> lr like the reference's `schedule` argument (reconstruct.py:122,
     385), evaluated here once per iteration (None: cosine_schedule inside the library); gamma1 / gamma2 / gammad: the
-    exponents of loss1 / loss2 / lossd = gamma_loss(g) (:118-120); opt_pp (:121, 436)."""
+    exponents of loss1 / loss2 / lossd = gamma_loss(g) (:118-120); opt_pp (:121, 436); opt_depth (:121, 437): the
+    (normalised) core depths are parameters of the second stage too -- `params["core_depth"]` then holds the optimised
+    values and the depthmaps of the result use the values of the last iteration's start, like the reference's."""
     ctx = ops.get_context(device)
     dev = ctx.device
     f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev).contiguous()
@@ -92,6 +94,18 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
     if schedule is not None:   # reconstruct.py:384-385: alpha = iter / niter, lr = schedule(alpha, lr_base, lr_end = 0)
         lrs = [float(schedule(it / n, lr, 0)) for lr, n in ((lr1, niter1), (lr2, niter2)) for it in range(n)]
         lr_host = np.ascontiguousarray(np.asarray(lrs + [0.0], np.float32))
+    csr_off = csr_rows = depth_work = None
+    if opt_depth and niter2 > 0:
+        # rows of stage 2 (loss_2d rows, then regression rows) grouped by the core depth their anchor reads; the kernel
+        # adds a core depth's rows in this (stable) order
+        a_img = np.asarray(flat["anchor_img"]).astype(np.int64); a_idx = np.asarray(flat["anchor_idx"]).astype(np.int64)
+        a_row = np.concatenate([np.asarray(flat["c2d_a2"]).astype(np.int64).reshape(-1),
+                                np.asarray(flat["dust_a1"]).astype(np.int64).reshape(-1)])
+        elem = a_img[a_row] * G + a_idx[a_row]
+        order = np.argsort(elem, kind="stable")
+        csr_rows = i32(order if order.size else np.zeros(1, np.int64))
+        csr_off = i32(np.searchsorted(elem[order], np.arange(Cn * G + 1), side="left"))
+        depth_work = torch.zeros(a_row.size + 3 * Cn * G, device=dev)
     _lib.check(_lib.lib().st3r_align_run_opts(
         ctx.handle, ops._stream(), Cn, G, A, p(imsizes), p(base_focals), p(median), p(core), p(min_f), p(max_f),
         p(anchor_pix), p(anchor_idx, torch.int32), p(anchor_off), p(anchor_img, torch.int32),
@@ -101,15 +115,22 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
         int(flat["mst_root"]), edges.shape[0], p(edges, torch.int32), lr1, niter1, lr2, niter2, loss_dust3r_w,
         p(P["pps"]), p(P["log_focals"]), p(P["quats"]), p(P["trans"]), p(P["log_sizes"]),
         p(work), work.numel(), p(cam), p(pts), p(losses),
-        lr_host.ctypes.data if lr_host is not None else None, float(gamma1), float(gamma2), float(gammad), int(bool(opt_pp))))
+        lr_host.ctypes.data if lr_host is not None else None, float(gamma1), float(gamma2), float(gammad), int(bool(opt_pp)),
+        p(csr_off, torch.int32) if csr_off is not None else None, p(csr_rows, torch.int32) if csr_rows is not None else None,
+        p(depth_work) if depth_work is not None else None, depth_work.numel() if depth_work is not None else 0))
     K = torch.zeros(Cn, 3, 3, device=dev)
     K[:, 0, 0] = K[:, 1, 1] = cam[:, 12]; K[:, 0, 2] = cam[:, 13]; K[:, 1, 2] = cam[:, 14]; K[:, 2, 2] = 1
     cam2w = torch.zeros(Cn, 4, 4, device=dev)
     cam2w[:, :3, :3] = cam[:, :9].reshape(Cn, 3, 3); cam2w[:, :3, 3] = cam[:, 9:12]; cam2w[:, 3, 3] = 1
-    depth = cam[:, 15:16] + cam[:, 16:17] * core
+    # (opt_depth: the results belong to the core depths as they were at the start of the last iteration)
+    core_res = depth_work[-Cn * G:].reshape(Cn, G) if depth_work is not None else core
+    depth = cam[:, 15:16] + cam[:, 16:17] * core_res
     res = dict(intrinsics=K, cam2w=cam2w, depthmaps=depth, pts3d=pts, losses=losses[:niter1 + niter2],
                _cam_rows=cam, _core=core, _base_focals=base_focals,
                _adam_m=work[:11 * Cn].clone())  # first moments, order pps|log_focals|quats|trans|log_sizes (tests)
+    if depth_work is not None:   # opt_depth: first moments of the core depths [C, G] (tests)
+        n_rows2 = depth_work.numel() - 3 * Cn * G
+        res["_adam_m_core"] = depth_work[n_rows2:n_rows2 + Cn * G].reshape(Cn, G).clone()
     params = dict(P)
     params["core_depth"] = core
     params["core_len"] = core_len          # true lengths of the padded rows (views of different sizes)

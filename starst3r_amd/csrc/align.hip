@@ -45,6 +45,8 @@ struct AlignProblem {
     // robust losses gamma_loss(gamma) of the three row kinds (reconstruct.py:118-120: loss1, loss2, lossd) and their
     // offsets (1/gamma)^(1/(gamma-1)); gamma = 1 is the plain L1 distance (offset 0)
     float gamma1, off1, gamma2, off2, gammad, offd;
+    // opt_depth (reconstruct.py:437): stage 2 also leaves, per row, dL/d(core depth of the row's anchor); NULL otherwise
+    float* rowgrad;
 };
 
 struct AlignState {
@@ -111,8 +113,8 @@ __device__ __forceinline__ void cam_clear(CamGrad& c) {
 }
 
 // dL/d(pw) of an anchor point -> its camera's 17 numbers
-__device__ __forceinline__ void point_bwd(const AlignProblem& P, const float* __restrict__ cam, int a, const Pt& r,
-                                          const float vp[3], CamGrad& out) {
+__device__ __forceinline__ float point_bwd(const AlignProblem& P, const float* __restrict__ cam, int a, const Pt& r,
+                                           const float vp[3], CamGrad& out) {
     const float* c = cam + r.img * CAM_STRIDE;
     float* g = out.g;
     out.img = r.img;
@@ -137,6 +139,7 @@ __device__ __forceinline__ void point_bwd(const AlignProblem& P, const float* __
     g[16] += vD * r.core;
     vf += vz * r.D * (-(r.off - 1.0f) * bf * (r.inv_f * r.inv_f));
     g[12] += vf;
+    return vD * c[16];   // dL/d(core depth): depth = A + B core
 }
 
 // Rows arrive grouped by image pair, so a wave's 64 rows almost always feed the same camera: 64 lanes adding to the
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
     for (int rr = 0; rr < rpt; ++rr) {   // rpt consecutive groups of 256 rows per workgroup (bounds the number of partials)
     CamGrad ca, cb;
     cam_clear(ca); cam_clear(cb);
-    float lsum = 0.f;
+    float lsum = 0.f, vcore = 0.f;
     if (running) {
         const int n_main = stage == 1 ? P.n_corr : P.n_c2d;
         const int row = (blockIdx.x * rpt + rr) * blockDim.x + threadIdx.x;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                     for (int m = 0; m < 3; ++m) ve[m] = c[m * 3] * vq0 + c[m * 3 + 1] * vq1 + c[m * 3 + 2] * vq2;
 #pragma unroll
                     for (int m = 0; m < 3; ++m) g[9 + m] += -ve[m];
-                    point_bwd(P, scam, a2, p2, ve, cb);
+                    vcore = point_bwd(P, scam, a2, p2, ve, cb);
                 }
             }
         } else if (row - n_main < P.n_dust) {
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
             if (d > 1e-20f) {
                 const float k = w * rp / d;
                 const float v1[3] = {k * ex, k * ey, k * ez};
-                point_bwd(P, scam, a1, p1, v1, ca);
+                vcore = point_bwd(P, scam, a1, p1, v1, ca);
                 float* g = cb.g;
                 cb.img = i2;
                 const float tg[3] = {t0, t1, t2};
@@ -287,6 +290,10 @@ __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState 
                 }
             }
         }
+    }
+    if (P.rowgrad && stage == 2) {   // opt_depth: one number per row, summed per core depth by k_align_depth_update
+        const int row = (blockIdx.x * rpt + rr) * blockDim.x + threadIdx.x;
+        if (row < P.n_c2d + P.n_dust) P.rowgrad[row] = vcore;
     }
     // converged again: wave-level hand-over to the wave's LDS accumulators
     flush_camera(ca, sw);
@@ -597,6 +604,30 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
     for (int k = i; k < C * ACC_STRIDE + 1; k += blockDim.x) S.acc[k] = 0.f;
 }
 
+// opt_depth (reconstruct.py:437): the core depths are parameters of the second stage as well.  One thread per core
+// depth adds the numbers of its rows in the fixed order of the caller's grouping (csr_off / csr_rows: rows of stage 2
+// -- loss_2d rows, then regression rows -- grouped by the core depth their anchor reads), then Adam(0.9, 0.9) like
+// k_align_update.  No float atomics: bit-reproducible.
+__global__ __launch_bounds__(256) void k_align_depth_update(int n_elem, float* __restrict__ core, float* __restrict__ m,
+                                                            float* __restrict__ v, const int32_t* __restrict__ csr_off,
+                                                            const int32_t* __restrict__ csr_rows,
+                                                            const float* __restrict__ rowgrad,
+                                                            const float* __restrict__ flags, float lr, int step,
+                                                            int reset_moments) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elem || flags[1] != 0.f) return;   // (stopped earlier by a NaN loss)
+    float g = 0.f;
+    for (int j = csr_off[e]; j < csr_off[e + 1]; ++j) g += rowgrad[csr_rows[j]];
+    const double bc1 = 1.0 - pow(0.9, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc1);
+    const float w1 = (float)(1.0 - 0.9), b2 = 0.9f, eps = 1e-8f;
+    float mk = reset_moments ? 0.f : m[e], vk = reset_moments ? 0.f : v[e];
+    mk = fmaf(w1, g - mk, mk);
+    vk = vk * b2 + (w1 * g) * g;
+    m[e] = mk; v[e] = vk;
+    core[e] = core[e] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+}
+
 // world points of every anchor from the current camera table (the reference's `pts3d` result, :405-406)
 __global__ void k_align_points(AlignProblem P, AlignState S, int n_anchors, float* __restrict__ pts) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -610,7 +641,7 @@ static float gamma_offset(float gamma) {
 }
 
 ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, int n_anchors, const float* imsizes,
-                               const float* base_focals, const float* median, const float* core,
+                               const float* base_focals, const float* median, float* core,
                                const float* min_focals, const float* max_focals, const float* anchor_pix,
                                const int32_t* anchor_idx, const float* anchor_off, const int32_t* anchor_img,
                                int n_corr, const int32_t* corr_a1, const int32_t* corr_a2, const float* corr_w,
@@ -620,9 +651,14 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
                                const int32_t* edges, float lr1, int niter1, float lr2, int niter2, float dust_weight,
                                float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
                                float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out,
-                               const float* lr_host, float gamma1, float gamma2, float gammad, int opt_pp) {
+                               const float* lr_host, float gamma1, float gamma2, float gammad, int opt_pp,
+                               const int32_t* depth_csr_off, const int32_t* depth_csr_rows, float* depth_work,
+                               int64_t depth_work_floats) {
     ARG_CHECK(ctx && C > 0 && C <= MAXC && G > 0 && n_anchors >= 0 && niter1 >= 0 && niter2 >= 0);
     ARG_CHECK(gamma1 > 0.f && gamma2 > 0.f && gammad > 0.f);
+    const bool opt_depth = depth_csr_off != nullptr;
+    const int64_t n_core = (int64_t)C * G, n_rows2 = (int64_t)n_c2d + n_dust;
+    ARG_CHECK(!opt_depth || (depth_work && depth_work_floats >= n_rows2 + 3 * n_core && (n_rows2 == 0 || depth_csr_rows)));
     ARG_CHECK(imsizes && base_focals && median && core && min_focals && max_focals && pps && log_focals && quats &&
               trans && log_sizes && work && cam_out && edges);
     ARG_CHECK(n_edges == C - 1 && root >= 0 && root < C);
@@ -638,6 +674,12 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
     P.root = root; P.n_edges = n_edges; P.edges = edges; P.min_focals = min_focals; P.max_focals = max_focals;
     P.gamma1 = gamma1; P.off1 = gamma_offset(gamma1); P.gamma2 = gamma2; P.off2 = gamma_offset(gamma2);
     P.gammad = gammad; P.offd = gamma_offset(gammad);
+    // opt_depth scratch: per-row numbers | Adam moments of the core depths | the core depths as they were when the
+    // results were exported (the reference's depthmaps are one step behind its parameters, see export_results)
+    P.rowgrad = opt_depth ? depth_work : nullptr;
+    float* core_m = opt_depth ? depth_work + n_rows2 : nullptr;
+    float* core_v = opt_depth ? core_m + n_core : nullptr;
+    float* core_snapshot = opt_depth ? core_v + n_core : nullptr;
     AlignState S;
     S.pps = pps; S.log_focals = log_focals; S.quats = quats; S.trans = trans; S.log_sizes = log_sizes;
     S.m = work; S.v = work + 11 * C; S.cam = work + 22 * C; S.acc = S.cam + (int64_t)C * CAM_STRIDE;
@@ -673,6 +715,8 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
     // the camera table is exported right before the final update launch.
     auto export_results = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(cam_out, S.cam, sizeof(float) * (size_t)C * CAM_STRIDE, hipMemcpyDeviceToDevice, s));
+        if (opt_depth)
+            HIP_TRY(hipMemcpyAsync(core_snapshot, core, sizeof(float) * (size_t)n_core, hipMemcpyDeviceToDevice, s));
         if (pts_out && n_anchors > 0)
             hipLaunchKernelGGL(k_align_points, dim3(ceil_div(n_anchors, 256)), dim3(256), 0, s, P, S, n_anchors, pts_out);
         return ST3R_OK;
@@ -695,7 +739,15 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
             U.lr = lr_host ? lr_host[li]   // the caller's schedule(alpha, lr_base, lr_end), evaluated per iteration
                            : (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
             U.step = it + 1; U.loss_index = li++; U.reset_moments = (it == 0); U.opt_pp = opt_pp;
+            const bool depth_step = opt_depth && stage == 2 && rows > 0;
+            if (depth_step)   // before k_align_update: both then see the NaN flag of the EARLIER iterations
+                hipLaunchKernelGGL(k_align_depth_update, dim3(ceil_div((int)n_core, 256)), dim3(256), 0, s, (int)n_core, core,
+                                   core_m, core_v, depth_csr_off, depth_csr_rows, P.rowgrad, S.acc + C * ACC_STRIDE, U.lr,
+                                   U.step, U.reset_moments);
             hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U);
+            if (depth_step && n_anchors > 0)   // the anchors' packed core depths follow the parameters
+                hipLaunchKernelGGL(k_align_pack_anchors, dim3(ceil_div(n_anchors, 256)), dim3(256), 0, s, n_anchors,
+                                   anchor_pix, anchor_idx, anchor_off, anchor_img, core, G, (float4*)P.anchor_pack);
         }
     }
     LAUNCH_CHECK();
@@ -714,9 +766,10 @@ ST3R_EXPORT int st3r_align_run(st3r_ctx* ctx, void* stream, int C, int G, int n_
                                const int32_t* edges, float lr1, int niter1, float lr2, int niter2, float dust_weight,
                                float* pps, float* log_focals, float* quats, float* trans, float* log_sizes,
                                float* work, int64_t work_floats, float* cam_out, float* pts_out, float* losses_out) {
-    return st3r_align_run_opts(ctx, stream, C, G, n_anchors, imsizes, base_focals, median, core, min_focals, max_focals,
+    return st3r_align_run_opts(ctx, stream, C, G, n_anchors, imsizes, base_focals, median, (float*)core, min_focals, max_focals,
                                anchor_pix, anchor_idx, anchor_off, anchor_img, n_corr, corr_a1, corr_a2, corr_w, n_c2d,
                                c2d_pix, c2d_a2, c2d_img1, c2d_w, n_dust, dust_a1, dust_tgt, dust_img2, dust_w, root,
                                n_edges, edges, lr1, niter1, lr2, niter2, dust_weight, pps, log_focals, quats, trans,
-                               log_sizes, work, work_floats, cam_out, pts_out, losses_out, nullptr, 1.1f, 0.4f, 1.1f, 1);
+                               log_sizes, work, work_floats, cam_out, pts_out, losses_out, nullptr, 1.1f, 0.4f, 1.1f, 1,
+                               nullptr, nullptr, nullptr, 0);
 }

@@ -213,19 +213,19 @@ def sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core
     `params_ret` the dict of per-view parameter lists a later call accepts as `prev_params`.  The optimisation
     itself is st3r_align_run_opts.  Implemented: the configuration the reference uses (:61-69) and the options that
     only change constants of the loop -- loss1 / loss2 / lossd = gamma_loss(g) (any g; `gamma_loss` below, Mast3r's own
-    closures, or `l1_loss`), any `schedule(alpha, lr_base, lr_end)` callable, `opt_pp`.  opt_depth, shared_intrinsics,
+    closures, or `l1_loss`), any `schedule(alpha, lr_base, lr_end)` callable, `opt_pp`, `opt_depth`.  shared_intrinsics,
     exp_depth, lora_depth, depth_mode != 'add' and `init` raise.  The stage-1 result is not kept separately (the
     reference's only caller takes `res_fine or res_coarse`, :113): `res_coarse` is `res_fine` when a second stage ran."""
-    if opt_depth or shared_intrinsics or exp_depth or lora_depth or depth_mode != "add" or init:
-        raise NotImplementedError("opt_depth, shared_intrinsics, exp_depth, lora_depth, depth_mode != 'add' and per-image "
-                                  "`init` are not implemented on the HIP path (the reference's own call uses none of them)")
+    if shared_intrinsics or exp_depth or lora_depth or depth_mode != "add" or init:
+        raise NotImplementedError("shared_intrinsics, exp_depth, lora_depth, depth_mode != 'add' and per-image `init` are "
+                                  "not implemented on the HIP path (the reference's own call uses none of them)")
     g1, g2, gd = _gamma_of(loss1, 1.1), _gamma_of(loss2, 0.4), _gamma_of(lossd, 1.1)
     flat = flatten_reference_inputs(imgs, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21,
                                     mst, matching_conf_thr)
     dev = "cuda:0" if str(device) == "cuda" else str(device)
     res, params = align.run(flat, lr1=lr1, niter1=niter1, lr2=lr2, niter2=niter2, prev_params=prev_params,
                             loss_dust3r_w=loss_dust3r_w, device=dev, schedule=schedule, gamma1=g1, gamma2=g2, gammad=gd,
-                            opt_pp=bool(opt_pp))
+                            opt_pp=bool(opt_pp), opt_depth=bool(opt_depth))
     off = flat["anchor_off"]
     C = len(imgs)
     clen = flat["core_len"]

@@ -169,6 +169,54 @@ def test_analytic_gradient_vs_oracle_autograd(stage):
         assert np.abs(got - ref).max() <= 2e-3 * scale + 1e-7, (k, got, ref)
 
 
+def test_opt_depth_gradient_and_schedule_vs_reference_golden():
+    """opt_depth=True (starster/reconstruct.py:121, 437): the core depths are parameters of the second stage.
+    * gradient: after one Adam step from zero moments m = 0.1 g -- the core-depth gradient (per-row numbers summed per
+      core depth in a fixed order) against torch autograd of the oracle;
+    * reference golden align_c3_optdepth (the reference run with opt_depth=True): tight after the first step of stage 2;
+      after 10 / 200 steps only as close as float32 allows -- most core depths are barely constrained, Adam turns their
+      rounding-noise gradients into lr-sized steps, and the reference's OWN float32 run ends 1.2e-2 (core depths:
+      2.5e-2) from its float64 evaluation (goldens f64_*; tests/test_oracle_align.py prints both)."""
+    from st3r_synth import synth_align
+    C = 4
+    flat = synth_align.flatten(synth_align.make_problem(n_views=C, n_corr=200, seed=11, bad_pair=True))
+    prev = _perturbed_params(C, 5)
+    res, par = run_hip(flat, niter1=0, niter2=1, prev_params=prev, opt_depth=True)
+    pb = ao.Problem(flat)
+    p = ao.init_params(pb, prev)
+    pb.core = pb.core.clone().requires_grad_(True)
+    K, w2cam, cam2w, depth = ao.make_K_cam_depth(pb, p)
+    pts = ao.make_pts3d(pb, K, cam2w, depth)
+    loss = ao.loss_2d(pb, K, w2cam, pts) + 0.01 * ao.loss_dust3r(pb, cam2w, pts)
+    loss.backward()
+    ref = pb.core.grad.numpy()
+    got = 10.0 * res["_adam_m_core"]
+    assert np.count_nonzero(ref) > 100
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-9
+    assert np.array_equal(got == 0, ref == 0)          # core depths no anchor reads keep a zero gradient (and value)
+    # reference golden
+    z, flat = load("align_c3_optdepth")
+    res, par = run_hip(flat, niter1=500, niter2=1, opt_depth=True)
+    compare(res, par, *golden(z, "r500_1"), 3e-3, "opt_depth r500_1")
+    np.testing.assert_allclose(par["core_depth"], z["r500_1__p_core_depth"], atol=2e-6)   # one step of lr2 * sign(g)
+    res, par = run_hip(flat, niter1=500, niter2=200, opt_depth=True)
+    g64 = golden(z, "f64_r500_200")
+    d_hip = drift(gauge_free(res, par, 0), gauge_free(*g64, 0))
+    d_ref = drift(gauge_free(*golden(z, "r500_200"), 0), gauge_free(*g64, 0))
+    c_hip = float(np.abs(par["core_depth"] - z["f64_r500_200__p_core_depth"]).max())
+    c_ref = float(np.abs(z["r500_200__p_core_depth"] - z["f64_r500_200__p_core_depth"]).max())
+    print("opt_depth: HIP-reference64 %.2e (reference32-reference64 %.2e); core depths %.2e (%.2e)" % (d_hip, d_ref, c_hip, c_ref))
+    assert d_hip <= 2.5 * d_ref and c_hip <= 2.5 * c_ref
+    L = res["losses"]
+    assert np.all(np.isfinite(L)) and L[-1] < L[500]
+    # the depthmaps of the result are one step behind the returned core depths, like the reference's (:379-380, 405-406)
+    cam = res["_cam_rows"]
+    assert not np.allclose(res["depthmaps"], cam[:, 15:16] + cam[:, 16:17] * par["core_depth"], rtol=0, atol=1e-7)
+    # bit-reproducible (no float atomics in the core-depth sums)
+    res2, par2 = run_hip(flat, niter1=500, niter2=200, opt_depth=True)
+    assert np.array_equal(par["core_depth"], par2["core_depth"]) and np.array_equal(par["quats"], par2["quats"])
+
+
 def test_warm_start_splices_previous_params():
     """prev_params of a 2-view solve seed the first 2 views of a 3-view problem (reconstruct.py:408-415)."""
     from st3r_synth import synth_align

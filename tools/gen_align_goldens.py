@@ -141,9 +141,9 @@ def run_reference(ref, P, niter1, niter2, f64=False, **extra):
             imgs, coarse, fine, params = ref.sparse_scene_optimizer_slam(
                 a["imgs"], a["subsample"], a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"],
                 a["corres"], a["corres2d"], a["preds_21"], a["canonical_paths"], a["mst"], cache_path=None,
-                lr1=0.07, niter1=niter1, lr2=0.014, niter2=niter2, device="cpu", opt_depth=False, dtype=dtype,
+                lr1=0.07, niter1=niter1, lr2=0.014, niter2=niter2, device="cpu", dtype=dtype,
                 matching_conf_thr=5, shared_intrinsics=False,  # the reference's own settings, reconstruct.py:61-69
-                **extra)
+                **{"opt_depth": False, **extra})
     finally:
         torch.set_default_dtype(torch.float32)
     res = fine or coarse
@@ -185,6 +185,22 @@ def main():
             runs[f"f64_r500_200__{k}"] = v
         np.savez_compressed(os.path.join(out_dir, "align_c3_opts.npz"), **{"in__" + k: v for k, v in flat.items()}, **runs)
         print("wrote align_c3_opts", os.path.getsize(os.path.join(out_dir, "align_c3_opts.npz")) // 1024, "KiB")
+    if not only or "align_c3_optdepth" in only:
+        # opt_depth=True (the default of the function's signature, reconstruct.py:121; the reference's caller passes False):
+        # the core depths are parameters of the second stage
+        P = synth_align.make_problem(n_views=3, n_corr=300, seed=8, bad_pair=True)
+        flat = synth_align.flatten(P)
+        runs = {}
+        for (n1, n2) in ((500, 1), (500, 10), (500, 200)):
+            r = run_reference(ref, P, n1, n2, opt_depth=True)
+            for k, v in r.items():
+                runs[f"r{n1}_{n2}__{k}"] = v.astype(np.float32) if v.dtype.kind == "f" else v
+            print("align_c3_optdepth", (n1, n2), "focals", r["intrinsics"][:, 0, 0])
+        r = run_reference(ref, P, 500, 200, f64=True, opt_depth=True)
+        for k, v in r.items():
+            runs[f"f64_r500_200__{k}"] = v
+        np.savez_compressed(os.path.join(out_dir, "align_c3_optdepth.npz"), **{"in__" + k: v for k, v in flat.items()}, **runs)
+        print("wrote align_c3_optdepth", os.path.getsize(os.path.join(out_dir, "align_c3_optdepth.npz")) // 1024, "KiB")
     configs = [c for c in configs if not only or c[0] in only]
     for name, kw in configs:
         P = synth_align.make_problem(**kw)
