@@ -43,6 +43,15 @@ def test_unsupported_configurations_are_refused():
     args = (a["imgs"], 8, a["imsizes"], a["pps"], a["base_focals"], a["core_depth"], a["anchors"], a["corres"],
             a["corres2d"], a["preds_21"], None, a["mst"])
     with pytest.raises(NotImplementedError):
-        rc.sparse_scene_optimizer_slam(*args, opt_depth=True)
-    with pytest.raises(NotImplementedError):
         rc.sparse_scene_optimizer_slam(*args, opt_depth=False, shared_intrinsics=True)
+    with pytest.raises(NotImplementedError):
+        rc.sparse_scene_optimizer_slam(*args, exp_depth=True)
+    with pytest.raises(NotImplementedError):
+        rc.sparse_scene_optimizer_slam(*args, depth_mode="mul")
+    with pytest.raises(NotImplementedError):   # a loss the kernels cannot evaluate
+        rc.sparse_scene_optimizer_slam(*args, loss1=lambda x, y: (x - y).abs().sum(-1))
+    # the loss / schedule objects the kernels can take
+    assert rc._gamma_of(rc.gamma_loss(0.5), 1.1) == 0.5 and rc._gamma_of(None, 1.1) == 1.1
+    assert rc._gamma_of(rc.gamma_loss(1), 1.1) == 1.0 and rc._gamma_of(rc.l1_loss, 0.4) == 1.0
+    assert rc.cosine_schedule(0.0, 0.07) == pytest.approx(0.07) and rc.cosine_schedule(1.0, 0.07) == pytest.approx(0.0)
+    assert rc.linear_schedule(0.25, 0.08) == pytest.approx(0.06)
