@@ -56,6 +56,21 @@
 #include "tile_rect.h"
 #include "blend_common.h"
 
+#ifdef BWD_PROFILE
+// Where a round of k_blend_bwd spends its time (tools/bwd_profile.py; -DBWD_PROFILE builds only): shader-clock cycles
+// summed over all waves, wave 0 (staging + flush) and waves 1-3 apart:
+//   [0..3] wave 0: staging incl. the barrier behind it | walk (phases 1 + 2) | wait at the barrier behind the walk | flush
+//   [4..7] waves 1-3: the same four
+//   [8] rounds x waves   [9] record trips   [10] phase-2 passes
+__device__ unsigned long long g_bwd_prof[16];
+ST3R_EXPORT int st3r_debug_bwd_profile(unsigned long long* out_host, int reset) {
+    if (out_host) (void)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_prof), z, sizeof(z)); }
+    return 0;
+}
+#define PROF_T() ((long long)__builtin_readcyclecounter())
+#endif
+
 #ifdef ST3R_STATS
 __device__ unsigned long long g_blend_stats[8];
 ST3R_EXPORT int st3r_debug_blend_stats(unsigned long long* out_host, int reset) {
@@ -445,6 +460,9 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     // wave-uniform pointer (scalar loads); the mask word of a round is fetched one round ahead so that no dependent
     // load sits at the head of a round
     const uint64_t* wmask = cmask + (int64_t)__builtin_amdgcn_readfirstlane(w) * cmask_words + mbase;
+#ifdef BWD_PROFILE
+    long long prof[4] = {0, 0, 0, 0}; long long prof_rounds = 0, prof_trips = 0, prof_p2 = 0;
+#endif
     uint64_t m_next = wmask[(BLK / HB) * nb - 1];
     for (int hb = (BLK / HB) * nb - 1; hb >= 0; --hb) {
         const int bs = g.start + hb * HB;
@@ -452,6 +470,9 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         const uint64_t m_cur = m_next;
         if (hb > 0) m_next = wmask[hb - 1];
         if (bsz <= 0) continue;   // the tail of the last forward batch may be empty (uniform over the workgroup)
+#ifdef BWD_PROFILE
+        const long long pt0 = PROF_T();
+#endif
         __syncthreads();
         // ---- staging: one record per thread (threads 0..HB-1).  A record some wave contributed to also fixes its
         // output slot now, so that the flush below is loads-free:  u = cum_excl[pid] + index of this tile inside the
@@ -496,6 +517,9 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             }
         }
         __syncthreads();
+#ifdef BWD_PROFILE
+        const long long pt1 = PROF_T();
+#endif
         // ---- phase 1: lanes are pixels; up to CHUNK records, back to front (unrolled: the chunk row is an immediate
         // offset, the records' staged indices travel to phase 2 in one scalar, 8 bits each).  Compares and selects cost
         // 1.7 ns each on this chip against 1.1 ns for an add or multiply (tools/probe/valu_cost.hip), so the two tests
@@ -544,6 +568,9 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                         cnt = k + 1;
                     }
                 }
+#ifdef BWD_PROFILE
+                prof_trips += cnt; prof_p2 += 1;
+#endif
 #ifndef BWD_NO_P2
                 bwd_phase2(pr, tpack, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
 #endif
@@ -558,7 +585,13 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         } else {
             if (clamp_round) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{});
         }
+#ifdef BWD_PROFILE
+        const long long pt2 = PROF_T();
+#endif
         __syncthreads();
+#ifdef BWD_PROFILE
+        const long long pt3 = PROF_T();
+#endif
         // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM.  Slot indices come from the
         // scan over the TRUE tile counts; in an asynchronous step that outgrew its capacity they can exceed the slots the
         // buffer has (that step is discarded anyway): such a record is not written (unsigned: a wrapped index too)
@@ -588,7 +621,20 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
             dst[3] = make_float2(acc[6], acc[7]);
             dst[4] = make_float2(acc[8], __int_as_float(stamp));
         }
+#ifdef BWD_PROFILE
+        const long long pt4 = PROF_T();
+        prof[0] += pt1 - pt0; prof[1] += pt2 - pt1; prof[2] += pt3 - pt2; prof[3] += pt4 - pt3; prof_rounds += 1;
+#endif
     }
+#ifdef BWD_PROFILE
+    if (lane == 0) {
+        const int o = w == 0 ? 0 : 4;
+        for (int k = 0; k < 4; ++k) atomicAdd(&g_bwd_prof[o + k], (unsigned long long)prof[k]);
+        atomicAdd(&g_bwd_prof[8], (unsigned long long)prof_rounds);
+        atomicAdd(&g_bwd_prof[9], (unsigned long long)prof_trips);
+        atomicAdd(&g_bwd_prof[10], (unsigned long long)prof_p2);
+    }
+#endif
 }
 
 // v_splats[pid] = sum over the pair's tiles of the slots stamped by this backward call, in slot order (deterministic
