@@ -78,7 +78,9 @@ int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t byt
 int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
 /* test hook. bit 0: the blend forward walks every staged record in every wave (no per-quadrant relevance test):
  * images must come out bit-identical, which is how the culling is validated at full size.
- * st3r_ctx_peek(which = 8 / 9): rgb [C,H,W,3] / alpha [C,H,W] of the last st3r_gs_train_fwd_bwd call. */
+ * st3r_ctx_peek(which = 8 / 9): rgb [C,H,W,3] / alpha [C,H,W] of the last st3r_gs_train_fwd_bwd call.
+ * bit 10 (1024): st3r_align_run* runs as one persistent kernel with grid barriers instead of two launches per
+ * iteration (A/B, tests; measured not faster, see csrc/align.hip). */
 int st3r_ctx_set_debug(st3r_ctx* ctx, int flags);
 /* Waits for the record count of the last asynchronous training step (st3r_gs_train_fwd_bwd / st3r_gs_train_step with
  * stats_host == NULL) and reports it like the next training call would: ST3R_ERR_CAPACITY if that step outgrew its

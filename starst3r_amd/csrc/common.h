@@ -71,6 +71,7 @@ enum ArenaSlot {
     SLOT_COUNTS,
     SLOT_PSTAGE,
     SLOT_GSTAGE,
+    SLOT_ALIGN_CTL,   // persistent alignment kernel: grid-barrier counter + one learning rate per iteration
     SLOT_COUNT
 };
 
@@ -102,7 +103,9 @@ struct st3r_ctx {
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
     int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test; 1: backward
                       // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks;
-                      // 6: backward gathers rectangle and slot base separately
+                      // 6: backward gathers rectangle and slot base separately; 7 (128): training forward on the quadrant
+                      // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 10 (1024): alignment as one persistent
+                      // kernel instead of two launches per iteration (measured: not faster)
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back
     // still in flight (event), and the capacity the in-flight step was given
