@@ -154,7 +154,7 @@ def align_bench(device, with_cpu=True, views=8):
     out = {"views": views, "anchors": int(flat["anchor_idx"].size), "correspondence_rows": int(flat["corr_a1"].size),
            "iterations": "500+200", "hip_seconds": hip_s, "hip_ms_per_iter": hip_s / 700 * 1e3,
            "loss_stage1": [float(L[0]), float(L[499])], "loss_stage2": [float(L[500]), float(L[-1])],
-           "bound": "launch latency (2 launches/iteration; working set in L2) -- not roofline bound"}
+           "bound": "latency of dependent steps, not launches (measured, tools/align_profile.py): ~12 us residual kernel + ~14 us one-workgroup update kernel (sequential walks over the MST) per iteration; working set in L2 -- not roofline bound"}
     if with_cpu:
         from oracle import align_oracle
         # The loop is ~6400 tiny ATen ops per iteration: more intra-op threads only add

@@ -58,6 +58,8 @@ struct AlignState {
     float* acc;                // [C*ACC_STRIDE + 4]: gradient sums, then [loss, nan flag]
     float* part;               // [workgroups of k_align_resid][C*ACC_STRIDE + 1]: their partial sums
     float* losses;             // [niter1 + niter2]
+    float* chain;              // [12*C]: chained rotations [9C] and translations [3C] of the CURRENT parameters, left by the
+                               // forward half of k_align_update for the backward half of the next call (or NULL)
 };
 
 __device__ __forceinline__ float rho_prime(float d, float gamma, float off, float* rho) {
@@ -367,6 +369,8 @@ struct UpdateArgs {
     int loss_index;    // where to store the loss of the step just evaluated
     int reset_moments; // first step of a stage: fresh optimiser (reconstruct.py:374)
     int opt_pp;        // stage 2 also moves the principal points (reconstruct.py:436)
+    float step_size;   // lr / (1 - 0.9^step) and sqrt(1 - 0.9^step): Adam's bias corrections, evaluated in double on the host
+    float bc2_sqrt;    // (a double-precision pow per thread used to sit on the single workgroup's critical path)
 };
 
 // The chain walks are sequential over the MST edges, but the 12 (forward) / 24 (reverse) numbers of one edge are
@@ -435,6 +439,14 @@ __device__ __forceinline__ void chain_reverse_wave(int lane, int n_edges, const 
 }
 
 // single workgroup; thread i < C owns view i for the element-wise parts, thread 0 walks the chain
+#ifdef ALIGN_PROFILE   // checkpoints of the update phase (thread 0, shader clock): sums over all calls -> g_upd_prof
+__device__ unsigned long long g_upd_prof[8];
+#define UPD_MARK(k) do { if (threadIdx.x == 0) { const long long t_ = (long long)__builtin_readcyclecounter(); \
+                         atomicAdd(&g_upd_prof[k], (unsigned long long)(t_ - upd_t)); upd_t = t_; } } while (0)
+#else
+#define UPD_MARK(k) do { } while (0)
+#endif
+
 template <bool COH>
 __device__ __forceinline__ void align_update_body(const AlignProblem& P, const AlignState& S, const UpdateArgs& U) {
     __shared__ float sRr[MAXC * 9], sRt[MAXC * 9], stt[MAXC * 3];        // relative / chained rotations, chained translation
@@ -445,6 +457,9 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
     __shared__ float s_gs, s_vgs, s_min; __shared__ int s_argmin;
     const int i = threadIdx.x;
     const int C = P.C;
+#ifdef ALIGN_PROFILE
+    long long upd_t = (long long)__builtin_readcyclecounter();
+#endif
     for (int k = i; k < 3 * C; k += blockDim.x) strans[k] = S.trans[k];
     for (int k = i; k < 2 * P.n_edges; k += blockDim.x) sedge[k] = P.edges[k];
     float* flags = S.acc + C * ACC_STRIDE;
@@ -453,9 +468,8 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
                                             // workgroup order (n_part < 0: k_align_reduce has done it)
         const int nacc = C * ACC_STRIDE + 1;
         const float* __restrict__ part = S.part;
-        // loads in flight per thread: 8 (L2 hits between launches) / 32 (persistent kernel: its written-through partials
-        // come from the memory side, ~4x the latency); added strictly in workgroup order either way
-        constexpr int INFL = COH ? 32 : 8;
+        // 32 loads in flight per thread (one round trip for up to 32 workgroups), added strictly in workgroup order
+        constexpr int INFL = 32;
         for (int k = i; k < nacc; k += blockDim.x) {
             float a = 0.f;
             for (int b0 = 0; b0 < U.n_part; b0 += INFL) {
@@ -468,6 +482,7 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
             S.acc[k] = a;
         }
         __syncthreads();
+        UPD_MARK(0);
     }
     if (U.do_backward && i == 0) {
         const float loss = flags[0];
@@ -477,7 +492,10 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
     if (U.reset_moments)
         for (int k = i; k < 11 * C; k += blockDim.x) { S.m[k] = 0.f; S.v[k] = 0.f; }
     __syncthreads();
+    UPD_MARK(1);
 
+    float pv[11];          // this view's parameters (pps 2, log_focal, quat 4, trans 3, log_size) once they are in registers
+    bool have_pv = false;
     // ---------------- backward of make_K_cam_depth + Adam (uses the forward state of the step just evaluated) ----------------
     if (U.do_backward) {
         // recompute the forward pieces this thread needs
@@ -506,8 +524,14 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
             for (int k = 0; k < C; ++k) ties += (ssize[k] == mn) ? 1 : 0;
             s_gs = 1.0f / mn; s_argmin = ties; s_vgs = 0.f; s_min = mn;
         }
-        if (i < 64) chain_forward_wave(i, P.root, P.n_edges, sedge, sRr, strans, sRt, stt);   // rotations + translations
+        // chained rotations + translations of the current parameters: the forward half of the previous call left them
+        // (one parallel load instead of a sequential walk over the MST: ~0.45 us per edge on this one-workgroup kernel)
+        if (S.chain) {
+            for (int k = i; k < 9 * C; k += blockDim.x) sRt[k] = S.chain[k];
+            for (int k = i; k < 3 * C; k += blockDim.x) stt[k] = S.chain[9 * C + k];
+        } else if (i < 64) chain_forward_wave(i, P.root, P.n_edges, sedge, sRr, strans, sRt, stt);
         __syncthreads();
+        UPD_MARK(2);
         const float gs = s_gs;
         float v_f = 0, v_ppx = 0, v_ppy = 0, v_s = 0, vgs_part = 0;
         if (i < C) {
@@ -545,6 +569,7 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
         __syncthreads();
         if (i < 64) chain_reverse_wave(i, P.n_edges, sedge, sRr, strans, sRt, svRt, svtt);
         __syncthreads();
+        UPD_MARK(3);
         if (i < C) {
             if (s == s_min) v_s += s_vgs * (-gs * gs) / (float)s_argmin;  // gs = 1/min(s); s_argmin = tie count
             // quaternion (x,y,z,w): rotmat VJP, then the normalisation VJP
@@ -571,9 +596,14 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
             const int moff[11] = {2 * i, 2 * i + 1, 2 * C + i, 3 * C + 4 * i, 3 * C + 4 * i + 1, 3 * C + 4 * i + 2,
                                   3 * C + 4 * i + 3, 7 * C + 3 * i, 7 * C + 3 * i + 1, 7 * C + 3 * i + 2, 10 * C + i};
             // Adam(lr, betas=(0.9, 0.9), eps=1e-8), torch single-tensor semantics
-            const double bc1 = 1.0 - pow(0.9, (double)U.step), bc2 = bc1;
-            const float step_size = (float)((double)U.lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+            const float step_size = U.step_size, bc2_sqrt = U.bc2_sqrt;
             const float w1 = (float)(1.0 - 0.9), b2 = 0.9f, eps = 1e-8f;
+            // the eleven parameters of the view stay in registers from here to the end of the call (pv): no store ->
+            // load round trips on this one-workgroup kernel's critical path
+#pragma unroll
+            for (int k = 0; k < 11; ++k) pv[k] = *pptr[k];
+            have_pv = true;
+#pragma unroll
             for (int k = 0; k < 11; ++k) {
                 const bool trainable = (k >= 3) || (U.stage == 2 && (k == 2 || U.opt_pp));
                 if (!trainable) continue;
@@ -582,23 +612,34 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
                 mk = fmaf(w1, gk - mk, mk);
                 vk = vk * b2 + (w1 * gk) * gk;
                 S.m[moff[k]] = mk; S.v[moff[k]] = vk;
-                *pptr[k] = *pptr[k] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+                pv[k] = pv[k] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
             }
             // make sure the pose remains well optimizable (reconstruct.py:394-395)
-            float* q = S.quats + 4 * i;
-            const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-            q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
-            for (int k = 0; k < 3; ++k) strans[3 * i + k] = S.trans[3 * i + k];   // own writes: visible to this thread
+            const float n = sqrtf(pv[3] * pv[3] + pv[4] * pv[4] + pv[5] * pv[5] + pv[6] * pv[6]);
+            pv[3] /= n; pv[4] /= n; pv[5] /= n; pv[6] /= n;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const bool trainable = (k >= 3) || (U.stage == 2 && (k == 2 || U.opt_pp));
+                if (trainable) *pptr[k] = pv[k];
+            }
+            for (int k = 0; k < 3; ++k) strans[3 * i + k] = pv[7 + k];
         }
         __syncthreads();
+        UPD_MARK(4);
     }
 
     // ---------------- forward: camera table for the next residual launch ----------------
     if (i < C) {
-        const float s = __expf(S.log_sizes[i]);
+        if (!have_pv) {
+            pv[0] = S.pps[2 * i]; pv[1] = S.pps[2 * i + 1]; pv[2] = S.log_focals[i];
+            for (int k = 0; k < 4; ++k) pv[3 + k] = S.quats[4 * i + k];
+            for (int k = 0; k < 3; ++k) pv[7 + k] = S.trans[3 * i + k];
+            pv[10] = S.log_sizes[i];
+        }
+        const float s = __expf(pv[10]);
         ssize[i] = s;
         float qn[4], inv;
-        quat_to_rot(S.quats + 4 * i, sRr + 9 * i, qn, &inv);
+        quat_to_rot(pv + 3, sRr + 9 * i, qn, &inv);
     }
     __syncthreads();
     if (i == 0) {
@@ -608,13 +649,18 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
     }
     if (i < 64) chain_forward_wave(i, P.root, P.n_edges, sedge, sRr, strans, sRt, stt);
     __syncthreads();
+    UPD_MARK(5);
+    if (S.chain) {
+        for (int k = i; k < 9 * C; k += blockDim.x) S.chain[k] = sRt[k];
+        for (int k = i; k < 3 * C; k += blockDim.x) S.chain[9 * C + k] = stt[k];
+    }
     if (i < C) {
         const float gs = s_gs;
         const float W = P.imsizes[2 * i], H = P.imsizes[2 * i + 1];
-        const float f = fminf(fmaxf(__expf(S.log_focals[i]), P.min_focals[i]), P.max_focals[i]);
+        const float f = fminf(fmaxf(__expf(pv[2]), P.min_focals[i]), P.max_focals[i]);
         const float s = ssize[i], med = P.median[i], bf = P.base_focals[i];
         const float zc = s * med * f / bf;
-        const float ppx = S.pps[2 * i], ppy = S.pps[2 * i + 1];
+        const float ppx = pv[0], ppy = pv[1];
         const float to[3] = {zc * (W / f) * (0.5f - ppx), zc * (H / f) * (0.5f - ppy), zc};
         float* c = S.cam + i * CAM_STRIDE;
         const float* Rt = sRt + 9 * i;
@@ -657,7 +703,7 @@ __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState
 struct PersistArgs {
     int niter1, niter2, n_part1, n_part2, rpt, n_wg, opt_pp, n_anchors;
     float dust_w;
-    const float* lr;       // [niter1 + niter2]
+    const float* lr;       // [3][niter1 + niter2]: learning rate, Adam step size, sqrt of the second bias correction
     unsigned* barrier;     // zeroed before the launch
     float* cam_out; float* pts_out;
 };
@@ -692,7 +738,7 @@ __global__ __launch_bounds__(256) void k_align_persist(AlignProblem P, AlignStat
     float* flags = S.acc + P.C * ACC_STRIDE;
     unsigned epoch = 0;
     if (wg == 0) {
-        UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0, 1};
+        UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0, 1, 0.f, 1.f};
         align_update_body<true>(P, S, U0);
     }
     if (!align_grid_sync(A.barrier, (++epoch) * A.n_wg, flags)) return;
@@ -736,8 +782,9 @@ __global__ __launch_bounds__(256) void k_align_persist(AlignProblem P, AlignStat
 #endif
             if (wg == 0) {
                 UpdateArgs U;
+                const int nit = A.niter1 + A.niter2;
                 U.n_part = n_part; U.do_backward = 1; U.stage = stage; U.lr = A.lr[li]; U.step = it + 1; U.loss_index = li;
-                U.reset_moments = (it == 0); U.opt_pp = A.opt_pp;
+                U.reset_moments = (it == 0); U.opt_pp = A.opt_pp; U.step_size = A.lr[nit + li]; U.bc2_sqrt = A.lr[2 * nit + li];
                 align_update_body<true>(P, S, U);
             }
 #ifdef ALIGN_PROFILE
@@ -794,6 +841,11 @@ __global__ void k_align_points(AlignProblem P, AlignState S, int n_anchors, floa
 ST3R_EXPORT int st3r_debug_align_profile(st3r_ctx* ctx, unsigned long long* out4_host) {
     return hipMemcpy(out4_host, (const char*)ctx->slot_ptr[SLOT_ALIGN_CTL] + 16, 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
+ST3R_EXPORT int st3r_debug_update_profile(unsigned long long* out8_host, int reset) {
+    if (out8_host) (void)hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_upd_prof), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_upd_prof), z, sizeof(z)); }
+    return 0;
+}
 #endif
 
 static float gamma_offset(float gamma) {
@@ -844,6 +896,27 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
     S.pps = pps; S.log_focals = log_focals; S.quats = quats; S.trans = trans; S.log_sizes = log_sizes;
     S.m = work; S.v = work + 11 * C; S.cam = work + 22 * C; S.acc = S.cam + (int64_t)C * CAM_STRIDE;
     S.losses = losses_out;
+    // control words: [0..15] grid-barrier counter (+ profile words) | [16 .. 16+12C) the chain cache of k_align_update |
+    // three per-iteration tables of the persistent kernel
+    const int n_iter_total = niter1 + niter2;
+    float* ctl;
+    {
+        void* pc;
+        int rc = st3r_arena_get(ctx, SLOT_ALIGN_CTL, sizeof(float) * (size_t)(16 + 12 * C + 3 * n_iter_total), &pc);
+        if (rc) return rc;
+        ctl = (float*)pc;
+    }
+    S.chain = ctl + 16;
+    auto lr_of = [&](int stage, int it, int li) -> float {
+        const int niter = stage == 1 ? niter1 : niter2;
+        const float lr_base = stage == 1 ? lr1 : lr2;
+        return lr_host ? lr_host[li]   // the caller's schedule(alpha, lr_base, lr_end), evaluated per iteration
+                       : (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
+    };
+    auto adam_factors = [](float lr, int step, float* step_size, float* bc2_sqrt) {   // Adam(betas = (0.9, 0.9)), torch
+        const double bc1 = 1.0 - pow(0.9, (double)step);
+        *step_size = (float)((double)lr / bc1); *bc2_sqrt = (float)sqrt(bc1);
+    };
     HIP_TRY(hipMemsetAsync(work, 0, sizeof(float) * (size_t)need, s));
     const size_t sh = sizeof(float) * (4 * ((size_t)C * ACC_STRIDE + 1) + (size_t)C * CAM_STRIDE);
     if (sh > 64 * 1024)   // more than ~190 views: the four accumulator copies pass the default dynamic-LDS limit
@@ -880,30 +953,25 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
         A.n_part2 = rows2 > 0 ? ceil_div(rows2, 256 * A.rpt) : 0;
         A.niter1 = niter1; A.niter2 = niter2; A.opt_pp = opt_pp; A.n_anchors = n_anchors; A.dust_w = dust_weight;
         A.cam_out = cam_out; A.pts_out = n_anchors > 0 ? pts_out : nullptr;
-        void* ctl;
-        int rc = st3r_arena_get(ctx, SLOT_ALIGN_CTL, sizeof(float) * (size_t)(16 + niter1 + niter2), &ctl);
-        if (rc) return rc;
         A.barrier = (unsigned*)ctl;
-        float* lr_dev = (float*)ctl + 16;
-        A.lr = lr_dev;
-        std::vector<float> lrs((size_t)niter1 + niter2);
-        for (int st = 1, li = 0; st <= 2; ++st) {
-            const int niter = st == 1 ? niter1 : niter2;
-            const float lr_base = st == 1 ? lr1 : lr2;
-            for (int it = 0; it < niter; ++it, ++li)
-                lrs[li] = lr_host ? lr_host[li]
-                                  : (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
-        }
+        float* tab_dev = ctl + 16 + 12 * C;
+        A.lr = tab_dev;
+        std::vector<float> tab(3 * (size_t)n_iter_total);
+        for (int st = 1, li = 0; st <= 2; ++st)
+            for (int it = 0; it < (st == 1 ? niter1 : niter2); ++it, ++li) {
+                tab[li] = lr_of(st, it, li);
+                adam_factors(tab[li], it + 1, &tab[n_iter_total + li], &tab[2 * (size_t)n_iter_total + li]);
+            }
         HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(float) * 16, s));
-        // (pageable source: the runtime has taken its copy of `lrs` when the call returns)
-        HIP_TRY(hipMemcpyAsync(lr_dev, lrs.data(), sizeof(float) * lrs.size(), hipMemcpyHostToDevice, s));
+        // (pageable source: the runtime has taken its copy of `tab` when the call returns)
+        HIP_TRY(hipMemcpyAsync(tab_dev, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, s));
         if (sh > 24 * 1024)   // 40 KB of static LDS (the update's tables) + the residual's dynamic part
             HIP_TRY(hipFuncSetAttribute((const void*)k_align_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(k_align_persist, dim3(A.n_wg), dim3(256), sh, s, P, S, A);
         LAUNCH_CHECK();
         return ST3R_OK;
     }
-    UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0, 1};
+    UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0, 1, 0.f, 1.f};
     hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U0);
     // The reference returns K / cam2w / depthmaps / pts3d as computed at the START of the last iteration,
     // i.e. one optimiser step behind the returned parameters (optimize_loop builds them before
@@ -922,7 +990,6 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
     int li = 0;
     for (int stage = 1; stage <= 2; ++stage) {
         const int niter = stage == 1 ? niter1 : niter2;
-        const float lr_base = stage == 1 ? lr1 : lr2;
         const int rows = (stage == 1 ? n_corr : n_c2d) + n_dust;
         for (int it = 0; it < niter; ++it) {
             if (stage == last_stage && it == niter - 1) { int rc = export_results(); if (rc) return rc; }
@@ -932,8 +999,8 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
             if (n_part > 32) hipLaunchKernelGGL(k_align_reduce, dim3(ceil_div(nacc, 256)), dim3(256), 0, s, S, nacc, n_part);
             UpdateArgs U;
             U.n_part = n_part > 32 ? -1 : n_part; U.do_backward = 1; U.stage = stage;
-            U.lr = lr_host ? lr_host[li]   // the caller's schedule(alpha, lr_base, lr_end), evaluated per iteration
-                           : (float)(0.0 + ((double)lr_base - 0.0) * (1.0 + cos(((double)it / niter) * M_PI)) / 2.0);  // cosine_schedule
+            U.lr = lr_of(stage, it, li);
+            adam_factors(U.lr, it + 1, &U.step_size, &U.bc2_sqrt);
             U.step = it + 1; U.loss_index = li++; U.reset_moments = (it == 0); U.opt_pp = opt_pp;
             const bool depth_step = opt_depth && stage == 2 && rows > 0;
             if (depth_step)   // before k_align_update: both then see the NaN flag of the EARLIER iterations
