@@ -214,7 +214,10 @@ def sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core
     itself is st3r_align_run_opts.  Implemented: the configuration the reference uses (:61-69) and the options that
     only change constants of the loop -- loss1 / loss2 / lossd = gamma_loss(g) (any g; `gamma_loss` below, Mast3r's own
     closures, or `l1_loss`), any `schedule(alpha, lr_base, lr_end)` callable, `opt_pp`, `opt_depth`.  shared_intrinsics,
-    exp_depth, lora_depth, depth_mode != 'add' and `init` raise.  The stage-1 result is not kept separately (the
+    exp_depth, lora_depth, depth_mode != 'add' and `init` raise.  (shared_intrinsics is not just unimplemented: the
+    reference hands the ONE shared pp / log_focal Parameter to Adam once per view (:193-197, :373), so what a step does
+    to it -- one update or C, with the step count advancing by C -- depends on which torch.optim implementation (for-loop
+    or foreach) the installed torch picks; there is no single behaviour to reproduce.)  The stage-1 result is not kept separately (the
     reference's only caller takes `res_fine or res_coarse`, :113): `res_coarse` is `res_fine` when a second stage ran."""
     if shared_intrinsics or exp_depth or lora_depth or depth_mode != "add" or init:
         raise NotImplementedError("shared_intrinsics, exp_depth, lora_depth, depth_mode != 'add' and per-image `init` are "
