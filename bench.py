@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-drift", action="store_true",
                     help="skip the untimed continuation to 200 steps that shows how the step time drifts as training "
                          "changes the scene (windows.drift; one GPU, only when --steps < 200)")
+    ap.add_argument("--train-only", action="store_true",
+                    help="skip the alignment / matching / condensation benches behind the headline (profiling runs)")
     ap.add_argument("--multi-gpu", choices=("replicated", "gaussian-sharded"), default="replicated",
                     help="how N > 1 GPUs are used (DESIGN.md section 5): replicated = the north_star partition (default)")
     ap.add_argument("--cpu-sample-div", type=int, default=2,
@@ -569,7 +571,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         else:
             out["cpu_baseline"] = None
-        if world == 1:
+        if world == 1 and not args.train_only:
             out["align"] = align_bench(device, with_cpu=not args.no_cpu_baseline)
             # the synthetic condensed problems at 2 / 8 / 32 views (HIP seconds for 500+200 iterations)
             out["align"]["hip_seconds_by_views"] = {str(c): align_bench(device, with_cpu=False, views=c)["hip_seconds"]

@@ -173,7 +173,8 @@ ST3R_EXPORT int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* co
 
 // ---- internal stage launchers (other translation units) ----
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
-                         int64_t* n_isects_host, const uint64_t* pack_rects, uint64_t* pack_out);
+                         int64_t* n_isects_host, const void* pack_rects, int rect32, uint64_t* pack_out,
+                         int32_t** total_dev_out);
 int st3r_isect_emit_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* cum, int tile_size,
                          int tile_w, int tile_h, int64_t* isect_ids, int32_t* flatten_ids);
 int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t* keys_in, int32_t* vals_in,
@@ -184,16 +185,13 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, uint64_t* rects);
-int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
-                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out, const uint64_t* rects,
-                              uint64_t* rects_sorted);
-int st3r_isect_emit_rects_impl(hipStream_t s, int N, int C, const int32_t* perm, const int32_t* cum_sorted,
-                               const uint64_t* rects_sorted, int tile_w, int tile_h, uint32_t* tile_keys,
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32);
+int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
+                               int rect32, const int32_t* cum, int tile_w, int tile_h, uint32_t* tile_keys,
                                int32_t* vals, int64_t cap);
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
                               int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base,
-                              uint64_t* rects);
+                              void* rects, int rect32);
 int st3r_isect_offsets32_impl(hipStream_t s, int64_t n_isects, const uint32_t* keys, int C, int tile_w, int tile_h,
                               int32_t* offsets, const int32_t* n_dev);
 int st3r_sort_depth_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint64_t* keys_in, int32_t* vals_in,
@@ -264,7 +262,7 @@ ST3R_EXPORT int st3r_ctx_settle(st3r_ctx* ctx) {
     }
 
 struct RasterOut {
-    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; uint64_t* rects; uint64_t* rectbase; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
+    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; const uint64_t* rects; uint64_t* rectbase; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
 };
 
 // project -> scan -> emit -> sort -> offsets, all in ctx scratch
@@ -282,7 +280,6 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
         GET(SLOT_SPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, own);
         splats = own;
     }
-    GET(SLOT_TILES, int32_t, n_pairs, tiles);
     GET(SLOT_CUM, int32_t, n_pairs, cum);
     GET(SLOT_OFFSETS, int32_t, (int64_t)C * tile_w * tile_h + 1, offsets);   // + the total (closes the last tile)
     // Two-level sort (see gs_isect.hip): pairs by (camera | depth) first, then the emitted records by
@@ -300,17 +297,19 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_DKEYS_B, uint64_t, n_sort, dkeys_b);
     GET(SLOT_DVALS_A, int32_t, n_sort, dvals_a);
     GET(SLOT_DVALS_B, int32_t, n_sort, perm);
-    GET(SLOT_CUM_D, int32_t, n_pairs, cum_d);
-    GET(SLOT_RECTS, uint64_t, n_pairs, rects);       // packed tile rectangle of every pair (pair-id order)
-    GET(SLOT_RECTS_D, uint64_t, n_pairs, rects_d);   // the same in depth order, written by the depth-order scan
+    // packed tile rectangle of every pair (pair-id order; the tile count of a pair is the area of its rectangle, no
+    // array of its own): 32-bit entries for tile grids up to 255 x 255 (tile_rect.h), 64-bit beyond -- and under debug
+    // flag 64, whose backward reads the 64-bit form
+    const int rect32 = (tile_w <= 255 && tile_h <= 255 && !(ctx->debug_flags & 64)) ? 1 : 0;
+    GET(SLOT_RECTS, uint64_t, rect32 ? (n_pairs + 1) / 2 : n_pairs, rects);
     st3r_prof_begin(ctx, s, STG_PROJECT);
     const uint32_t key_base = key32 ? near_bits : 0u;
     int rc = records_in
-                 ? st3r_records_prepare_impl(s, N, C, splats, tile, tile_w, tile_h, tight, tiles, dkeys_a, dvals_a,
-                                             key_base, rects)
+                 ? st3r_records_prepare_impl(s, N, C, splats, tile, tile_w, tile_h, tight, nullptr, dkeys_a, dvals_a,
+                                             key_base, rects, rect32)
                  : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
-                                     W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, tiles, reg_sums, dkeys_a,
-                                     dvals_a, tight, key_base, rects);
+                                     W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, nullptr, reg_sums, dkeys_a,
+                                     dvals_a, tight, key_base, rects, rect32);
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
@@ -329,11 +328,9 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
         GET(SLOT_RECTBASE, uint64_t, n_pairs, rb);
         rectbase = rb;
     }
-    rc = st3r_isect_scan_impl(ctx, s, n_pairs, tiles, cum, nullptr, rectbase ? rects : nullptr, rectbase);
-    if (rc) return rc;
-    // depth order scan: write positions of the emit kernel
+    // (its total is the record count; the emit kernel finds the write positions of the depth-ordered records itself)
     int32_t* total_dev = nullptr;
-    rc = st3r_isect_scan_perm_impl(ctx, s, n_pairs, tiles, perm, cum_d, &total_dev, rects, rects_d);
+    rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev);
     st3r_prof_end(ctx, s, STG_SCAN);
     if (rc) return rc;
     // The record count is produced on the device.  Steady state (allow_async and a count from an earlier call): no host
@@ -375,7 +372,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
     if (n_isects > 0) {
         st3r_prof_begin(ctx, s, STG_EMIT);
-        rc = st3r_isect_emit_rects_impl(s, N, C, perm, cum_d, rects_d, tile_w, tile_h, tkeys_a, vals_a, n_isects);
+        rc = st3r_isect_emit_chain_impl(ctx, s, N, C, perm, rects, rect32, cum, tile_w, tile_h, tkeys_a, vals_a, n_isects);
         st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
         const int end_bit = bit_length_u32((uint32_t)((int64_t)C * tile_w * tile_h - 1));
@@ -388,7 +385,8 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     rc = st3r_isect_offsets32_impl(s, n_isects, tkeys_b, C, tile_w, tile_h, offsets, n_dev);
     st3r_prof_end(ctx, s, STG_OFFSETS);
     if (rc) return rc;
-    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->rects = rects; o->rectbase = rectbase;
+    o->splats = splats; o->offsets = offsets; o->flat = vals_b; o->cum = cum; o->rects = rect32 ? nullptr : rects;
+    o->rectbase = rectbase;
     o->n_isects = n_isects;
     o->tile_w = tile_w; o->tile_h = tile_h;
     return ST3R_OK;

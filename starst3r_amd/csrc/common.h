@@ -72,6 +72,7 @@ enum ArenaSlot {
     SLOT_PSTAGE,
     SLOT_GSTAGE,
     SLOT_ALIGN_CTL,   // persistent alignment kernel: grid-barrier counter + one learning rate per iteration
+    SLOT_SCAN_CHAIN,  // single-pass scans (gs_isect.hip): ticket, totals, one status word per tile
     SLOT_COUNT
 };
 
@@ -107,6 +108,8 @@ struct st3r_ctx {
                       // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 10 (1024): alignment as one persistent
                       // kernel instead of two launches per iteration (measured: not faster)
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
+    uint32_t scan_gen, scan_ticket[2];   // chained kernels (gs_isect.hip): generation of the status words; tickets handed
+                                         // out so far from queue 0 and from each of the queues 1..7
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back
     // still in flight (event), and the capacity the in-flight step was given
     int64_t isect_hint, count_cap;

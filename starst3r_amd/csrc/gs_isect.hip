@@ -38,98 +38,128 @@ __device__ __forceinline__ int block_incl_scan(int v, int* total) {
     return inc + base;
 }
 
-// `perm` (optional): scan in[perm[idx]] instead of in[idx] (tile counts visited in depth order)
-// `rects` (optional, with perm): packed tile rectangles (x0 | y0 << 16 | w << 32 | h << 48) instead of counts; the
-// gathered rectangles are stored in depth order (rects_sorted) for the emit kernel, which then streams.
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int32_t* __restrict__ in,
-                                                              const int32_t* __restrict__ perm, int64_t n,
-                                                              int32_t* __restrict__ block_sums,
-                                                              int32_t* __restrict__ gathered,
-                                                              const uint64_t* __restrict__ rects,
-                                                              uint64_t* __restrict__ rects_sorted) {
-    // Gathering launch: workgroup b runs on XCD b % 8 (each XCD has its own L2).  XCD x takes the x-th eighth of the
-    // array, i.e. (with 8 views) the pairs of one camera in depth order: its random gathers stay inside that camera's
-    // 8 MB of rectangles instead of every L2 streaming all of them.
-    int bid = blockIdx.x;
-    if (perm) {   // measured at SYNTH-1M: 167 -> 107 us
-        const int G = gridDim.x >> 3;
-        if (bid < (G << 3)) bid = (bid & 7) * G + (bid >> 3);
-    }
-    const int64_t base = (int64_t)bid * SCAN_TILE;
-    int s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
-        if (idx < n) {
-            int v;
-            if (rects) {
-                const uint64_t r = rects[perm[idx]];
-                rects_sorted[idx] = r;
-                v = (int)((r >> 32) & 0xFFFF) * (int)(r >> 48);
-                gathered[idx] = v;
-            } else if (perm) { v = in[perm[idx]]; gathered[idx] = v; }  // the downsweep then reads contiguously
-            else v = in[idx];
-            s += v;
-        }
-    }
-    int total;
-    block_incl_scan(s, &total);
-    if (threadIdx.x == 0) block_sums[bid] = total;
-}
-
-// single block: exclusive scan of block_sums in place; grand total -> total_out[0]
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(int32_t* __restrict__ block_sums, int nblocks,
-                                                                 int32_t* __restrict__ total_out) {
-    // the running total is kept in 64 bits: a grand total past 2^31 - 1 is reported as -1 (the callers turn a
-    // negative count into ST3R_ERR_INVALID) instead of wrapping silently
-    int64_t carry = 0;
-    for (int base = 0; base < nblocks; base += SCAN_THREADS) {
-        int idx = base + threadIdx.x;
-        int v = idx < nblocks ? block_sums[idx] : 0;
-        int total;
-        int inc = block_incl_scan(v, &total);
-        if (idx < nblocks) block_sums[idx] = (int)carry + inc - v;
-        carry += (int64_t)(uint32_t)total;   // a block total < 2^32 (4096 counts < 2^20 each)
-    }
-    if (threadIdx.x == 0) total_out[0] = carry > 2147483647LL ? -1 : (int32_t)carry;
-}
-
-// (in may alias out: the block loads its whole tile before it stores any of it)
+// Single-pass prefix sum (decoupled look-back, Merrill & Garland 2016, restated for wave64): a workgroup owns a tile of
+// 4096 consecutive elements, publishes the tile's sum as soon as it is known, and wave 0 adds up the published sums of
+// its predecessors -- 64 status words per trip, one per lane -- back to the nearest tile whose inclusive prefix is
+// already known.  Round 3 ran three launches per scan (reduce, one workgroup over the tile sums, downsweep) and read the
+// input twice.
+//   status word = flag (2 bits: 1 = tile sum, 2 = inclusive prefix) | launch generation (14 bits) | value (48 bits)
+// in ONE 64-bit word published and polled with relaxed agent-scope atomics: no fences, independent of XCD placement.
+// The generation makes words of earlier launches invisible, so the status array is never cleared between launches
+// (the host clears it when the generation wraps); tiles are handed out by a ticket counter that only ever grows
+// (the host passes the value it had before this launch), so every predecessor of a running tile is itself running.
+//   RECTS  the input is the packed tile rectangle of every element (x0 | y0 << 16 | w << 32 | h << 48), its count w * h
+//   PACK   also leave, per element, exclusive prefix << 32 | x0 | y0 << 10 | w << 20 -- the one word the blend backward
+//          gathers per staged record (slot base + rectangle)
 // Thread t owns SCAN_ITEMS consecutive elements so the scan order is the array order; the tile travels through LDS so
 // that both the loads and the stores are coalesced (padded by one word per 32: the 16-word runs of neighbouring
-// threads would otherwise meet in the same banks).
+// threads would otherwise meet in the same banks).  `in` may alias `out` (a tile is loaded before any of it is stored).
+typedef unsigned long long u64;
 #define SCAN_PAD(i) ((i) + ((i) >> 5))
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, const int32_t* __restrict__ perm,
-                                                            int64_t n, const int32_t* __restrict__ block_sums,
-                                                            int32_t* out, const uint64_t* __restrict__ pack_rects,
-                                                            uint64_t* __restrict__ pack_out) {
-    // pack_rects / pack_out (optional): also leave, per element, exclusive prefix << 32 | x0 | y0 << 10 | w << 20 of its
-    // packed tile rectangle -- the one word the blend backward gathers per staged record (slot base + rectangle; two
-    // separate random reads cost a 64-byte sector each)
+#define SC_VALUE_MASK 0xFFFFFFFFFFFFull
+__device__ __forceinline__ u64 sc_word(u64 flag, uint32_t gen, u64 v) { return (flag << 62) | ((u64)gen << 48) | (v & SC_VALUE_MASK); }
+
+// Look-back of a chained scan by the whole workgroup: thread j polls the status word of the (j+1)-th predecessor of tile
+// `k` (k >= 1) of the chain whose words start at `st`, 256 predecessors per trip; the sums of the published tile totals
+// back to the nearest predecessor whose inclusive prefix is known give this tile's exclusive prefix (returned to every
+// thread).  One wave looking back 64 tiles per trip was measured first: when all tiles of a launch are resident at once
+// nobody has an inclusive prefix early, so tile k needs k / 64 trips of a few microseconds each -- the pair-order scan's
+// 1954 tiles spent 60 us that way.
+__device__ __forceinline__ u64 chain_lookback256(const u64* st, int k, uint32_t gen, u64* s_part, int* s_near) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    u64 excl = 0;
+    for (int t0 = k - 1;; t0 -= 256) {
+        const int tt = t0 - t;
+        u64 wd = sc_word(2, gen, 0);   // in front of the chain's first tile: an inclusive prefix of zero
+        if (tt >= 0) {
+            unsigned spins = 0;
+            for (;;) {
+                wd = __hip_atomic_load(st + tt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((wd >> 62) != 0 && (uint32_t)((wd >> 48) & 0x3FFF) == gen) break;
+                __builtin_amdgcn_s_sleep(1);
+                // a predecessor holds an earlier ticket, i.e. it is running: this bound (seconds) can only trip on a
+                // broken device or a protocol bug, and then it must be loud rather than a hang
+                if (++spins > (1u << 26)) __builtin_trap();
+            }
+        }
+        const u64 incm = __ballot((wd >> 62) == 2);
+        const int nearest = incm ? __builtin_ctzll(incm) : 64;   // nearest predecessor of this wave's 64 with a prefix
+        u64 val = lane <= nearest ? (wd & SC_VALUE_MASK) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off);
+        if (lane == 0) { s_part[w] = val; s_near[w] = nearest; }
+        __syncthreads();
+        bool done = false;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww)
+            if (!done) { excl += s_part[ww]; done = s_near[ww] < 64; }
+        __syncthreads();
+        if (done) break;
+    }
+    return excl;
+}
+
+template <bool RECTS, bool PACK>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const int32_t* in, const void* __restrict__ rects,
+                                                               int rect32, int64_t n, int32_t* out,
+                                                               uint64_t* __restrict__ pack_out, u64* status,
+                                                               uint32_t* ticket, uint32_t ticket_base, uint32_t gen,
+                                                               int32_t* __restrict__ total_out) {
     __shared__ int tile[SCAN_PAD(SCAN_TILE) + 1];
-    const int64_t base0 = (int64_t)blockIdx.x * SCAN_TILE;
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tl = s_tile;
+    const int64_t base0 = (int64_t)tl * SCAN_TILE;
+    if (base0 >= n) return;   // uniform over the workgroup
+    uint32_t geo[PACK ? SCAN_ITEMS : 1];
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         const int e = i * SCAN_THREADS + threadIdx.x;
         const int64_t idx = base0 + e;
-        tile[SCAN_PAD(e)] = idx < n ? (perm ? in[perm[idx]] : in[idx]) : 0;
+        int v = 0;
+        if (RECTS) {
+            uint32_t org = 0, rw = 0, rh = 0;
+            if (idx < n) rect_load(rects, rect32, idx, &org, &rw, &rh);
+            v = (int)(rw * rh);
+            if (PACK) geo[i] = (org & 0x3FF) | (((org >> 16) & 0x3FF) << 10) | ((rw & 0x3FF) << 20);
+        } else if (idx < n) v = in[idx];
+        tile[SCAN_PAD(e)] = v;
     }
     __syncthreads();
     int v[SCAN_ITEMS];
     int s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const int e = threadIdx.x * SCAN_ITEMS + i;
-        v[i] = tile[SCAN_PAD(e)];
+        v[i] = tile[SCAN_PAD(threadIdx.x * SCAN_ITEMS + i)];
         s += v[i];
     }
     int total;
-    int inc = block_incl_scan(s, &total);
-    int run = block_sums[blockIdx.x] + inc - s;
+    const int inc = block_incl_scan(s, &total);
+    // (a tile total < 2^32: 4096 counts < 2^20 each)
+    const u64 tot = (u64)(uint32_t)total;
+    // publish the tile's total, add up the predecessors, publish the inclusive prefix
+    __shared__ u64 s_part[4];
+    __shared__ int s_near[4];
+    u64 excl = 0;
+    if (tl == 0) {
+        if (threadIdx.x == 0) __hip_atomic_store(status, sc_word(2, gen, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (threadIdx.x == 0) __hip_atomic_store(status + tl, sc_word(1, gen, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        excl = chain_lookback256(status, (int)tl, gen, s_part, s_near);
+        if (threadIdx.x == 0)
+            __hip_atomic_store(status + tl, sc_word(2, gen, excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0 && base0 + SCAN_TILE >= n) {   // the last tile: the grand total (past 2^31 - 1 it is reported as -1
+        const u64 all = excl + tot;                     // -- the callers turn a negative count into an error -- instead of
+        total_out[0] = all > 2147483647ull ? -1 : (int32_t)all;   // wrapping silently)
+    }
+    const int tile_excl = (int)(uint32_t)excl;
+    int run = tile_excl + inc - s;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
         run += v[i];
-        tile[SCAN_PAD(threadIdx.x * SCAN_ITEMS + i)] = run;   // own elements only: no barrier needed before
+        tile[SCAN_PAD(threadIdx.x * SCAN_ITEMS + i)] = run;
     }
     __syncthreads();
 #pragma unroll
@@ -138,52 +168,67 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const int32_t* in, c
         const int64_t idx = base0 + e;
         if (idx < n) {
             out[idx] = tile[SCAN_PAD(e)];
-            if (pack_out) {
-                const uint32_t excl = (uint32_t)(e == 0 ? block_sums[blockIdx.x] : tile[SCAN_PAD(e - 1)]);
-                const uint64_t r = pack_rects[idx];
-                const uint32_t geo = (uint32_t)(r & 0x3FF) | ((uint32_t)((r >> 16) & 0x3FF) << 10) |
-                                     ((uint32_t)((r >> 32) & 0x3FF) << 20);
-                pack_out[idx] = ((uint64_t)excl << 32) | geo;
+            if (PACK) {
+                const uint32_t ex = (uint32_t)(e == 0 ? tile_excl : tile[SCAN_PAD(e - 1)]);
+                pack_out[idx] = ((uint64_t)ex << 32) | geo[i];
             }
         }
     }
 }
 
-// out = inclusive scan(in); the grand total is left in the SLOT_SCAN_TMP buffer at [nblocks]
-int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, const int32_t* perm, int32_t* out,
-                            int64_t n, int32_t** total_dev, const uint64_t* rects = nullptr,
-                            uint64_t* rects_sorted = nullptr, const uint64_t* pack_rects = nullptr,
-                            uint64_t* pack_out = nullptr) {
-    int nblocks = ceil_div(n, SCAN_TILE);
-    void* tmp;
-    int rc = st3r_arena_get(ctx, SLOT_SCAN_TMP, sizeof(int32_t) * (size_t)(nblocks + 4), &tmp);
+// Control block of the chained kernels (scan, emit) in one arena slot: eight ticket counters, four rotating totals,
+// then one status word per tile.  Nothing is cleared between launches (generation-stamped words, tickets that only
+// grow); the host clears the block when it is (re)allocated and when the 14-bit generation is about to repeat.
+struct ChainCtl { uint32_t* tickets; int32_t* total; u64* status; uint32_t gen; };
+static int chain_ctl(st3r_ctx* ctx, hipStream_t s, int64_t nwords, ChainCtl* c) {
+    void* p; int grown = 0;
+    int rc = st3r_arena_get2(ctx, SLOT_SCAN_CHAIN, sizeof(u64) * ((size_t)nwords + 16), &p, &grown);
     if (rc) return rc;
-    int32_t* bs = (int32_t*)tmp;
-    // with a permutation the gathered values are parked in `out` by the reduce pass and scanned in place
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(SCAN_THREADS), 0, s, in, perm, n, bs, out, rects, rects_sorted);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_THREADS), 0, s, bs, nblocks, bs + nblocks);
-    hipLaunchKernelGGL(k_scan_down, dim3(nblocks), dim3(SCAN_THREADS), 0, s, perm ? out : in,
-                       (const int32_t*)nullptr, n, bs, out, pack_rects, pack_out);
-    LAUNCH_CHECK();
-    if (total_dev) *total_dev = bs + nblocks;
+    if (grown || ctx->scan_gen >= 0x3FFF) {
+        HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_SCAN_CHAIN], s));
+        ctx->scan_gen = 0;
+        memset(ctx->scan_ticket, 0, sizeof(ctx->scan_ticket));
+    }
+    u64* ctl = (u64*)p;
+    c->gen = ++ctx->scan_gen;
+    c->tickets = (uint32_t*)ctl;                           // ctl[0..3]
+    c->total = (int32_t*)(ctl + 4) + (c->gen & 3);         // ctl[4..5]
+    c->status = ctl + 16;
     return ST3R_OK;
 }
 
-// inclusive scan of tiles[perm[.]] (perm may be NULL); optional synchronous read-back of the total
-int st3r_isect_scan_perm_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles,
-                              const int32_t* perm, int32_t* cum, int32_t** total_dev_out, const uint64_t* rects,
-                              uint64_t* rects_sorted) {
-    if (n_pairs == 0) return ST3R_OK;
-    return st3r_scan_inclusive_i32(ctx, s, tiles, perm, cum, n_pairs, total_dev_out, rects, rects_sorted);
+// out = inclusive scan of in (counts) or of the areas of the packed rectangles `rects`; the grand total is left in
+// device memory (*total_dev)
+int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, const void* rects, int rect32, int32_t* out,
+                            int64_t n, int32_t** total_dev, uint64_t* pack_out = nullptr) {
+    const int ntiles = ceil_div(n, SCAN_TILE);
+    ChainCtl c;
+    int rc = chain_ctl(ctx, s, ntiles, &c);
+    if (rc) return rc;
+#define SCAN_LAUNCH(R, P)                                                                                                \
+    hipLaunchKernelGGL((k_scan_chained<R, P>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, in, rects, rect32, n, out, pack_out, \
+                       c.status, c.tickets, ctx->scan_ticket[0], c.gen, c.total)
+    if (rects && pack_out) SCAN_LAUNCH(true, true);
+    else if (rects) SCAN_LAUNCH(true, false);
+    else SCAN_LAUNCH(false, false);
+#undef SCAN_LAUNCH
+    LAUNCH_CHECK();
+    ctx->scan_ticket[0] += (uint32_t)ntiles;   // every launched workgroup takes exactly one ticket
+    if (total_dev) *total_dev = c.total;
+    return ST3R_OK;
 }
 
+// Pair-id order scan.  tiles: the counts (stage API), or NULL with pack_rects = the pairs' packed rectangles (fused
+// path; pack_out then also receives slot base | rectangle per pair when it is not NULL).
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
-                         int64_t* n_isects_host, const uint64_t* pack_rects, uint64_t* pack_out) {
+                         int64_t* n_isects_host, const void* pack_rects, int rect32, uint64_t* pack_out,
+                         int32_t** total_dev_out) {
     if (n_pairs == 0) { if (n_isects_host) *n_isects_host = 0; return ST3R_OK; }
     int32_t* total_dev = nullptr;
-    int rc = st3r_scan_inclusive_i32(ctx, s, tiles, nullptr, cum, n_pairs, &total_dev, nullptr, nullptr, pack_rects,
-                                     pack_out);
+    int rc = st3r_scan_inclusive_i32(ctx, s, tiles, tiles ? nullptr : pack_rects, rect32, cum, n_pairs, &total_dev,
+                                     tiles ? nullptr : pack_out);
     if (rc) return rc;
+    if (total_dev_out) *total_dev_out = total_dev;
     if (n_isects_host) {
         int32_t* pin = (int32_t*)ctx->pinned;
         HIP_TRY(hipMemcpyAsync(pin, total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -197,7 +242,7 @@ ST3R_EXPORT int st3r_gs_isect_scan(st3r_ctx* ctx, void* stream, int64_t n_pairs,
                                    int32_t* cum_tiles, int64_t* n_isects_host) {
     ARG_CHECK(ctx && n_pairs >= 0 && tiles_per_gauss && cum_tiles && n_isects_host);
     return st3r_isect_scan_impl(ctx, (hipStream_t)stream, n_pairs, tiles_per_gauss, cum_tiles, n_isects_host, nullptr,
-                                nullptr);
+                                0, nullptr, nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_isect_emit(int N, int64_t n_pairs, const float4* __restrict__ splats,
@@ -360,25 +405,24 @@ __global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs,
                                                          int tile_size, int tile_w, int tile_h, int tight,
                                                          int32_t* __restrict__ tiles, uint64_t* __restrict__ depth_keys,
                                                          int32_t* __restrict__ depth_vals, uint32_t key_base,
-                                                         uint64_t* __restrict__ rects) {
+                                                         void* __restrict__ rects, int rect32) {
     const int64_t pid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= n_pairs) return;
     const float4 r2 = splats[pid * 3 + 2];
     const int radius = __float_as_int(r2.z);
     int ntiles = 0;
-    uint64_t rect = 0;
+    TileRect tr = {0, 0, 0, 0};
     if (radius > 0) {
         const float4 r0 = splats[pid * 3 + 0];
-        TileRect tr = ref_tile_rect(r0.x, r0.y, (float)radius, tile_size, tile_w, tile_h);
+        tr = ref_tile_rect(r0.x, r0.y, (float)radius, tile_size, tile_w, tile_h);
         if (tight) {
             const float4 r1 = splats[pid * 3 + 1];
             tr = tight_tile_rect(tr, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
         }
         ntiles = (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
-        rect = pack_rect(tr);
     }
-    tiles[pid] = ntiles;
-    if (rects) rects[pid] = rect;
+    if (tiles) tiles[pid] = ntiles;
+    if (rects) rect_store(rects, rect32, pid, tr);
     const uint32_t dbits = radius > 0 ? (uint32_t)__float_as_int(r2.y) : 0xFFFFFFFFu;
     if (key_base)   // same packed key as k_project_sh_fwd
         reinterpret_cast<uint32_t*>(depth_keys)[pid] =
@@ -390,85 +434,224 @@ __global__ __launch_bounds__(256) void k_records_prepare(int N, int64_t n_pairs,
 
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
                               int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base,
-                              uint64_t* rects) {
+                              void* rects, int rect32) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
     hipLaunchKernelGGL(k_records_prepare, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs,
                        (const float4*)splats, tile_size, tile_w, tile_h, tight, tiles, depth_keys, depth_vals, key_base,
-                       rects);
+                       rects, rect32);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
 
-// Emission from the depth-ordered packed rectangles (written by the depth-order scan): everything this kernel
-// reads is sequential -- no gather of 48-byte records, no floating point.  The 256 pairs of a block own one
-// contiguous output range.  Work is dealt by OUTPUT element, not by pair: a thread finds the pair that owns its
-// element with a binary search over the block's 256 scan entries (LDS) and decodes the tile from the element's index
-// inside the pair's rectangle -- coalesced stores, no per-thread loops over rectangles of very different sizes
-// (one thread per pair with the range assembled in LDS: 0.123 ms at SYNTH-1M, this: 0.083 ms), any range length.
-__global__ __launch_bounds__(256) void k_isect_emit_rects(int N, int64_t n_pairs, const int32_t* __restrict__ perm,
-                                                          const int32_t* __restrict__ cum_sorted,
-                                                          const uint64_t* __restrict__ rects_sorted, int tile_w,
-                                                          int tile_h, uint32_t* __restrict__ tile_keys,
-                                                          int32_t* __restrict__ vals, int64_t cap) {
-    // cap: capacity of tile_keys / vals.  With the record count on the device the buffers are sized from the previous
-    // step's count; records past the capacity are dropped here (the host notices the overflow when it reads the count
-    // back before the next step and fails loudly) -- never written out of bounds
-    __shared__ int s_end[256];        // inclusive scan of the block's tile counts, relative to the block's base
-    __shared__ uint32_t s_geo[256];   // x0 | y0 << 16
-    __shared__ uint32_t s_w[256];     // rectangle width
-    __shared__ uint32_t s_key0[256];  // camera * tiles
-    __shared__ int32_t s_pid[256];
+
+// Emission of the fused path: records leave in (camera, depth) order, so that the stable (camera, tile) sort behind
+// these kernels keeps depth order inside every tile.  Two launches (round 3: four -- a depth-order scan made of gather +
+// reduce, tile sums and downsweep, then the emission):
+//   k_isect_gather   a workgroup owns EP consecutive pairs of ONE camera in depth order (perm[] from the level-1 sort)
+//                    and gathers their packed rectangles by pair id -- the only random access of the front end -- into
+//                    depth order, plus the workgroup's tile count.  With eight views (or a multiple) the workgroups of
+//                    a camera run on one XCD (workgroup b runs on XCD b % 8), whose L2 then serves that camera's
+//                    rectangles: 4 MB at 1 M Gaussians in the 32-bit form;
+//   k_isect_emit     the same workgroup shape: scans its pairs' tile counts (rectangle areas), finds its first output
+//                    position as  cum[c N - 1]  (pair ids are camera-major too: the first record of camera c sits at the
+//                    pair-order scan's value in front of it)  +  the tile counts of the camera's earlier workgroups (at
+//                    most a few KB of sequential reads), and emits.  Work is dealt by OUTPUT element, not by pair:
+//                    every pair with tiles marks its first output with its index, a prefix maximum over the chunk
+//                    spreads the marks to the right (thread t scans 16 consecutive entries in registers, the thread
+//                    maxima meet in one workgroup scan), then the outputs are dealt to the threads with a stride of 256
+//                    and decode their tile from the index inside the owner's rectangle -- coalesced stores, no
+//                    per-thread loops over rectangles of very different sizes.
+// Measured on the way (SYNTH-1M): ONE kernel doing gather + chained scan with decoupled look-back per camera + emission
+// took 0.22 ms, of which 0.09 ms were workgroups waiting for the slowest gather among their predecessors (0.13 ms with
+// the look-back compiled out, 0.15 ms with sequential instead of gathered rectangles); a binary search over the scan
+// entries per output (round 3's emission) costs ten dependent LDS reads.
+// Everything the emission reads is sequential; no floating point except one reciprocal for the row of a tile.
+// cap: capacity of tile_keys / vals.  With the record count on the device the buffers are sized from the previous
+// step's count; records past the capacity are dropped here (the host notices the overflow when it reads the count
+// back before the next step and fails loudly) -- never written out of bounds.
+#ifndef EP
+#define EP 1024               // pairs per workgroup
+#endif
+#define EPT (EP / 256)        // pairs per thread
+#define ECH 4096              // outputs per emission chunk (16 per thread)
+
+// workgroup -> (camera, chunk of EP pairs).  Views a multiple of 8: workgroup b serves a camera c = b (mod 8).
+__device__ __forceinline__ void emit_item(int C, int bpc, int* c, int* k) {
+    const int b = blockIdx.x;
+    if ((C & 7) == 0) { const int j = b >> 3; *c = (b & 7) + 8 * (j / bpc); *k = j % bpc; }
+    else { *c = b / bpc; *k = b % bpc; }
+}
+
+__global__ __launch_bounds__(256) void k_isect_gather(int N, int C, int bpc, const int32_t* __restrict__ perm,
+                                                      const void* __restrict__ rects, int rect32,
+                                                      void* __restrict__ rects_d, int32_t* __restrict__ wg_tiles) {
+    int c, k;
+    emit_item(C, bpc, &c, &k);
     const int t = threadIdx.x;
-    const int64_t first = (int64_t)blockIdx.x * 256;
-    const int np = (int)min((int64_t)256, n_pairs - first);
-    const int base = first == 0 ? 0 : cum_sorted[first - 1];
-    {
-        const int64_t sidx = first + min(t, np - 1);
-        const uint64_t r = rects_sorted[sidx];
-        const int32_t pid = perm[sidx];
-        s_end[t] = cum_sorted[sidx] - base;
-        s_geo[t] = (uint32_t)(r & 0xFFFFFFFFull);
-        s_w[t] = (uint32_t)((r >> 32) & 0xFFFF);
-        s_key0[t] = (uint32_t)(pid / N) * (uint32_t)(tile_w * tile_h);
-        s_pid[t] = pid;
-    }
-    __syncthreads();
-    const int total = s_end[np - 1];
-    for (int o = t; o < total; o += 256) {
-        // first pair whose inclusive end exceeds o (pairs without tiles repeat their predecessor's end: skipped)
-        int lo = 0, hi = np - 1;
+    const int64_t first = (int64_t)c * N + (int64_t)k * EP;
+    const int np = (int)min((int64_t)EP, (int64_t)(c + 1) * N - first);
+    int32_t pid[EPT];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const bool right = s_end[mid] <= o;
-            lo = right ? mid + 1 : lo;
-            hi = right ? hi : mid;
+    for (int j = 0; j < EPT; ++j) pid[j] = j * 256 + t < np ? perm[first + j * 256 + t] : -1;
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        if (pid[j] >= 0) {
+            const int64_t dst = first + j * 256 + t;
+            if (rect32) {
+                const uint32_t r = reinterpret_cast<const uint32_t*>(rects)[pid[j]];
+                reinterpret_cast<uint32_t*>(rects_d)[dst] = r;
+                sum += (int)((r >> 16) & 0xFFu) * (int)(r >> 24);
+            } else {
+                const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[pid[j]];
+                reinterpret_cast<uint64_t*>(rects_d)[dst] = r;
+                sum += (int)((r >> 32) & 0xFFFF) * (int)(r >> 48);
+            }
         }
-        const int p = lo;
-        const int k = o - (p == 0 ? 0 : s_end[p - 1]);   // index inside the pair's rectangle, row major
-        const uint32_t w = s_w[p], geo = s_geo[p];
-        // k / w with k < w * h <= 2^20 and w < 2^10: float estimate, corrected by one either way
-        int q = (int)((float)k * __builtin_amdgcn_rcpf((float)w));
-        int rem = k - q * (int)w;
-        if (rem < 0) { --q; rem += (int)w; }
-        if (rem >= (int)w) { ++q; rem -= (int)w; }
-        const uint32_t tx = (geo & 0xFFFF) + (uint32_t)rem, ty = (geo >> 16) + (uint32_t)q;
-        // (a true total above 2^31 wraps the int32 scan: a negative position must not pass the capacity test)
-        if ((int64_t)base + o >= 0 && (int64_t)base + o < cap) {
-            tile_keys[base + o] = s_key0[p] + ty * (uint32_t)tile_w + tx;
-            vals[base + o] = s_pid[p];
+    }
+    int total;
+    block_incl_scan(sum, &total);
+    if (t == 0) wg_tiles[c * bpc + k] = total;   // < 2^30: 1024 rectangles of < 2^20 tiles
+}
+
+__global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, const int32_t* __restrict__ perm,
+                                                      const void* __restrict__ rects_d, int rect32,
+                                                      const int32_t* __restrict__ wg_tiles,
+                                                      const int32_t* __restrict__ cum, int tile_w, int tile_h,
+                                                      uint32_t* __restrict__ tile_keys, int32_t* __restrict__ vals,
+                                                      int64_t cap) {
+    __shared__ int s_end[EP];         // inclusive scan of the workgroup's tile counts
+    __shared__ uint32_t s_org[EP];    // x0 | y0 << 16
+    __shared__ uint32_t s_w[EP];      // rectangle width
+    __shared__ int32_t s_pid[EP];
+    __shared__ uint16_t s_own[ECH];   // owner (pair index + 1) of every output of the current emission chunk
+    __shared__ unsigned s_wmax[4];
+    __shared__ long long s_wsum[4];
+    int c, k;
+    emit_item(C, bpc, &c, &k);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t first = (int64_t)c * N + (int64_t)k * EP;
+    const int np = (int)min((int64_t)EP, (int64_t)(c + 1) * N - first);
+    // first output position: the camera's first record + the tile counts of the camera's earlier workgroups
+    long long before = 0;
+    for (int j = t; j < k; j += 256) before += wg_tiles[c * bpc + j];
+    int cnt[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int e = j * 256 + t;
+        int32_t pid = 0;
+        uint32_t org = 0, rw = 0, rh = 0;
+        if (e < np) {
+            pid = perm[first + e];
+            rect_load(rects_d, rect32, first + e, &org, &rw, &rh);
         }
+        s_pid[e] = pid; s_org[e] = org; s_w[e] = rw;
+        cnt[j] = (int)(rw * rh);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if (lane == 0) s_wsum[w] = before;
+    // scan in pair order: EPT block scans of 256 consecutive pairs, the carry in a register
+    int carry = 0;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        int tot;
+        const int inc = block_incl_scan(cnt[j], &tot);
+        s_end[j * 256 + t] = carry + inc;
+        carry += tot;
+    }
+    const int total = carry;
+    __syncthreads();
+    // (a true count above 2^31 wraps the int32 pair-order scan: the position test below keeps such writes out)
+    const long long base = (long long)(uint32_t)(c == 0 ? 0 : cum[(int64_t)c * N - 1]) +
+                           ((s_wsum[0] + s_wsum[1]) + (s_wsum[2] + s_wsum[3]));
+    const uint32_t key0 = (uint32_t)c * (uint32_t)(tile_w * tile_h);
+    int carry_owner = 0;   // owner (+1) of the last output of the previous chunk (uniform)
+    for (int c0 = 0; c0 < total; c0 += ECH) {
+        reinterpret_cast<uint4*>(s_own)[t] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(s_own)[t + 256] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int e = j * 256 + t;
+            if (e < np) {
+                const int start = e ? s_end[e - 1] : 0;
+                if (s_end[e] > start && start >= c0 && start < c0 + ECH) s_own[start - c0] = (uint16_t)(e + 1);
+            }
+        }
+        __syncthreads();
+        uint4 a = reinterpret_cast<const uint4*>(s_own)[2 * t], b = reinterpret_cast<const uint4*>(s_own)[2 * t + 1];
+        unsigned wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned run = 0;   // running maximum over this thread's 16 entries
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned lo = max(run, wv[i] & 0xFFFFu);
+            run = max(lo, wv[i] >> 16);
+            wv[i] = lo | (run << 16);
+        }
+        unsigned inc = run;   // inclusive prefix maximum over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off);
+            if (lane >= off) inc = max(inc, o);
+        }
+        if (lane == 63) s_wmax[w] = inc;
+        unsigned excl_m = __shfl_up(inc, 1);
+        if (lane == 0) excl_m = 0;
+        __syncthreads();
+        unsigned pre = max((unsigned)carry_owner, excl_m);
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww)
+            if (ww < w) pre = max(pre, s_wmax[ww]);
+        carry_owner = (int)max(max(max((unsigned)carry_owner, s_wmax[0]), max(s_wmax[1], s_wmax[2])), s_wmax[3]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned lo = max(wv[i] & 0xFFFFu, pre), hi = max(wv[i] >> 16, pre);
+            wv[i] = lo | (hi << 16);
+        }
+        reinterpret_cast<uint4*>(s_own)[2 * t] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        reinterpret_cast<uint4*>(s_own)[2 * t + 1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+        __syncthreads();
+        const int lim = min(ECH, total - c0);
+        for (int i = t; i < lim; i += 256) {
+            const int p = (int)s_own[i] - 1;
+            const int o = c0 + i;
+            const int kk = o - (p == 0 ? 0 : s_end[p - 1]);   // index inside the pair's rectangle, row major
+            const uint32_t w_ = s_w[p], org = s_org[p];
+            // kk / w with kk < w * h <= 2^20 and w < 2^10: float estimate, corrected by one either way
+            int qq = (int)((float)kk * __builtin_amdgcn_rcpf((float)w_));
+            int rem = kk - qq * (int)w_;
+            if (rem < 0) { --qq; rem += (int)w_; }
+            if (rem >= (int)w_) { ++qq; rem -= (int)w_; }
+            const uint32_t tx = (org & 0xFFFF) + (uint32_t)rem, ty = (org >> 16) + (uint32_t)qq;
+            const long long pos = base + o;
+            if (pos >= 0 && pos < cap) {
+                tile_keys[pos] = key0 + ty * (uint32_t)tile_w + tx;
+                vals[pos] = s_pid[p];
+            }
+        }
+        __syncthreads();
     }
 }
 
-int st3r_isect_emit_rects_impl(hipStream_t s, int N, int C, const int32_t* perm, const int32_t* cum_sorted,
-                               const uint64_t* rects_sorted, int tile_w, int tile_h, uint32_t* tile_keys,
+int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
+                               int rect32, const int32_t* cum, int tile_w, int tile_h, uint32_t* tile_keys,
                                int32_t* vals, int64_t cap) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
-    hipLaunchKernelGGL(k_isect_emit_rects, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, N, n_pairs, perm, cum_sorted,
-                       rects_sorted, tile_w, tile_h, tile_keys, vals, cap);
+    const int bpc = ceil_div(N, EP);
+    const int grid = C * bpc;
+    void* p;
+    int rc = st3r_arena_get(ctx, SLOT_RECTS_D, (rect32 ? sizeof(uint32_t) : sizeof(uint64_t)) * (size_t)n_pairs, &p);
+    if (rc) return rc;
+    void* rects_d = p;
+    rc = st3r_arena_get(ctx, SLOT_CUM_D, sizeof(int32_t) * (size_t)grid, &p);
+    if (rc) return rc;
+    int32_t* wg_tiles = (int32_t*)p;
+    hipLaunchKernelGGL(k_isect_gather, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects, rect32, rects_d, wg_tiles);
+    hipLaunchKernelGGL(k_isect_emit_d, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects_d, rect32, wg_tiles, cum, tile_w,
+                       tile_h, tile_keys, vals, cap);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
     float near_plane, float far_plane, float radius_clip, float4* __restrict__ splats,
     int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_part,
     uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals, int tight, uint32_t key_base,
-    uint64_t* __restrict__ rects) {
+    void* __restrict__ rects, int rect32) {
     extern __shared__ float cam[];
     __shared__ float red[8];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         }
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
         int ntiles = 0;
-        uint64_t rect = 0;
+        TileRect tr = {0, 0, 0, 0};
         if (valid) {
             // SH colour (degree 1) + clamp_min(c + 0.5, 0)
             float dx = mx - o[20], dy = my - o[21], dz = mz - o[22];
@@ -174,11 +174,10 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
                 col[ch] = r < 0.0f ? 0.0f : r;
             }
             // tile rectangle (isect_tiles pass 1)
-            TileRect tr = ref_tile_rect(m2x, m2y, radius, tile_size, tile_w, tile_h);
+            tr = ref_tile_rect(m2x, m2y, radius, tile_size, tile_w, tile_h);
             n_ref += (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
             if (tight) tr = tight_tile_rect(tr, m2x, m2y, opac, ca, cb, cc);  // fused train path only
             ntiles = (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
-            rect = pack_rect(tr);
             r0 = make_float4(m2x, m2y, opac, ca);
             r1 = make_float4(cb, cc, col[0], col[1]);
             r2 = make_float4(col[2], z, __int_as_float((int)radius), 0.0f);
@@ -186,8 +185,8 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         splats[pid * 3 + 0] = r0;
         splats[pid * 3 + 1] = r1;
         splats[pid * 3 + 2] = r2;
-        tiles_per_gauss[pid] = ntiles;
-        if (rects) rects[pid] = rect;
+        if (tiles_per_gauss) tiles_per_gauss[pid] = ntiles;
+        if (rects) rect_store(rects, rect32, pid, tr);
         if (depth_keys) {  // (camera | depth bits) key of the two-level sort; culled pairs sort last
             const uint32_t dbits = valid ? (uint32_t)__float_as_int(z) : 0xFFFFFFFFu;
             if (key_base)   // packed 32-bit key: camera (<= 8) | depth bits above those of the near plane (29 bits)
@@ -235,7 +234,7 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, uint64_t* rects) {
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32) {
     if (N == 0) return ST3R_OK;
     int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
     dim3 grid(ceil_div(N, 256)), block(256);
@@ -250,7 +249,7 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
     hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
                        viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
                        radius_clip, (float4*)splats, tiles_per_gauss, reg_part, depth_keys, depth_vals, tight, key_base,
-                       rects);
+                       rects, rect32);
     if (reg_sums) hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(256), 0, s, (int)grid.x, reg_part, reg_sums);
     LAUNCH_CHECK();
     return ST3R_OK;
@@ -266,5 +265,5 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
     return st3r_project_impl(ctx, (hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
                              campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,
-                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0, 0u, nullptr);
+                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0, 0u, nullptr, 0);
 }

@@ -73,6 +73,29 @@ __device__ __forceinline__ uint64_t pack_rect(TileRect r) {
     return (uint64_t)r.x0 | ((uint64_t)r.y0 << 16) | (w << 32) | (h << 48);
 }
 
+// The fused path keeps one packed rectangle per (camera, Gaussian) pair and gathers it by pair id (emit kernel): half
+// the bytes per entry is half the cache footprint of that gather, so tile grids of up to 255 x 255 tiles (images up
+// to 4080 pixels a side: every BASELINE configuration) use a 32-bit form, x0 | y0 << 8 | w << 16 | h << 24.
+__device__ __forceinline__ uint32_t pack_rect32(TileRect r) {
+    const uint32_t w = (uint32_t)(r.x1 - r.x0), h = (uint32_t)(r.y1 - r.y0);
+    if (w == 0 || h == 0) return 0u;
+    return (uint32_t)r.x0 | ((uint32_t)r.y0 << 8) | (w << 16) | (h << 24);
+}
+__device__ __forceinline__ void rect_store(void* rects, int is32, int64_t i, TileRect r) {
+    if (is32) reinterpret_cast<uint32_t*>(rects)[i] = pack_rect32(r);
+    else reinterpret_cast<uint64_t*>(rects)[i] = pack_rect(r);
+}
+// entry i of either form: origin x0 | y0 << 16, width, height (is32 is uniform over the launch)
+__device__ __forceinline__ void rect_load(const void* rects, int is32, int64_t i, uint32_t* org, uint32_t* w, uint32_t* h) {
+    if (is32) {
+        const uint32_t r = reinterpret_cast<const uint32_t*>(rects)[i];
+        *org = (r & 0xFFu) | ((r & 0xFF00u) << 8); *w = (r >> 16) & 0xFFu; *h = r >> 24;
+    } else {
+        const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[i];
+        *org = (uint32_t)(r & 0xFFFFFFFFull); *w = (uint32_t)((r >> 32) & 0xFFFF); *h = (uint32_t)(r >> 48);
+    }
+}
+
 // ---- exact culling: does the ellipse {sigma(p - mean) <= tau} reach a square of pixel centres? ----
 // sigma(d) = (A dx^2 + C dy^2)/2 + B dx dy with the conic (A, B, C).  sigma is convex, so when the mean lies
 // outside the square its minimum over the square sits on one of the four edges; on an edge it is a 1-D quadratic

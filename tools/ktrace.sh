@@ -1,14 +1,11 @@
 #!/bin/bash
-# quick per-kernel times of the SYNTH-1M train step (run on the GPU box from the repo root):
-#   bash tools/ktrace.sh <tag> [extra bench args]   -> gpurun_out/kt_<tag>.md
-set -u
-TAG=${1:-x}; shift
-ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/kt_$TAG
-mkdir -p $OUT
+# rocprofv3 kernel trace of a short bench run, summarised per kernel (GPU box):  bash tools/ktrace.sh <tag> [bench args]
+TAG=${1:-k}; shift
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/kt_$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-drift --train-only "$@" > $OUT/trace.log 2>&1
 cd $ROOT
-F=$(find $OUT -name "*kernel_trace.csv" | head -1)
-python tools/rocprof_summary.py $F --skip-first 2 > gpurun_out/kt_$TAG.md 2>&1
-head -30 gpurun_out/kt_$TAG.md
+F=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
+python tools/rocprof_summary.py $F > $OUT/summary.md
+head -32 $OUT/summary.md
+find $OUT/trace -name "*.csv" ! -name "*kernel_stats*" -delete; find $OUT/trace -name "*.db" -delete
