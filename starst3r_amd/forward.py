@@ -12,13 +12,50 @@ so that a second call with more images (Scene.add_images, starster/scene.py:117-
 "0.png", "1.png", ...) only infers the new pairs.  SURVEY 8(f) row 4 (pair cache) and the caller side of path A.
 
 Model protocol: `model.symmetric_inference(img1, img2, device)` -> (res11, res21, res22, res12), dicts with
-'pts3d' [1,H,W,3], 'conf' [1,H,W], 'desc' [1,H,W,D], 'desc_conf' [1,H,W] like Mast3r's heads."""
+'pts3d' [1,H,W,3], 'conf' [1,H,W], 'desc' [1,H,W,D], 'desc_conf' [1,H,W] like Mast3r's heads.  A Mast3r network itself
+(mast3r.model.AsymmetricMASt3R, what the reference hands over: main.py:46, starster/__init__.py:3) has no such method --
+upstream it is the module-level function mast3r.cloud_opt.sparse_ga.symmetric_inference(model, img1, img2, device) [U]
+-- so `wrap_network` puts the `Mast3rNetwork` adaptor around any object without the protocol: the ViT runs through
+Mast3r's own function, everything behind it (matching, cache, condensation, alignment, dense points) in this library."""
 import hashlib
 import os
 
 import torch
 
 from . import matching
+
+
+class Mast3rNetwork:
+    """Adaptor for the reference's own model type.  `model` is the network object of the reference's call
+    `reconstruct_scene(model, ...)` (starster/reconstruct.py:19,95-99: an AsymmetricMASt3R instance); the head outputs
+    of a pair come from Mast3r's `symmetric_inference(model, img1, img2, device)` [U], imported when first needed (the
+    package is not vendored by the reference -- empty submodule -- so its absence is reported then, loudly)."""
+
+    def __init__(self, model, subsample=8):
+        self.model = model
+        self.subsample = subsample
+        self._fn = None
+
+    def symmetric_inference(self, img1, img2, device):
+        if self._fn is None:
+            try:
+                from mast3r.cloud_opt.sparse_ga import symmetric_inference
+            except ImportError as e:
+                raise ImportError(
+                    "a Mast3r network needs the `mast3r` package for its pairwise inference "
+                    "(mast3r.cloud_opt.sparse_ga.symmetric_inference); it is not vendored by the reference (empty "
+                    "submodule).  Without it pass a model that implements symmetric_inference(img1, img2, device), "
+                    "forward_pairs(...) or condense(...) (starst3r_amd.reconstruct)") from e
+            self._fn = symmetric_inference
+        return self._fn(self.model, img1, img2, device)
+
+
+def wrap_network(model):
+    """`model` itself when it implements one of the model protocols of starst3r_amd.reconstruct, else the Mast3rNetwork
+    adaptor around it (a Mast3r network: the reference's own model type)."""
+    if any(hasattr(model, a) for a in ("symmetric_inference", "forward_pairs", "condense")):
+        return model
+    return Mast3rNetwork(model, getattr(model, "subsample", 8))
 
 
 def hash_md5(s):

@@ -10,8 +10,9 @@ What runs where:
   * the condensation between them (canonical pointmaps, focals, MST, anchors; Mast3r prepare_canonical_data /
     compute_min_spanning_tree / condense_data) -> starst3r_amd.condense (HIP kernels + host lists).
 
-Model protocol.  The Mast3r package is not vendored by the reference (empty submodule) and its weights
-cannot be fetched offline, so `model` is any object with one of
+Model protocol.  `model` is a Mast3r network like in the reference (its ViT forward then runs through Mast3r's own
+`symmetric_inference`, wrapped by starst3r_amd.forward.Mast3rNetwork; the package is not vendored by the reference --
+empty submodule -- and must be installed for that), or any object with one of
       model.symmetric_inference(img1, img2, device) -> (res11, res21, res22, res12)
 the network alone (head outputs 'pts3d', 'conf', 'desc', 'desc_conf' per pair, like Mast3r's symmetric_inference):
 pair list, reciprocal matching, the resumable disk cache (starst3r_amd.forward), condensation and alignment run here;
@@ -240,85 +241,82 @@ def sparse_scene_optimizer_slam(imgs, subsample, imsizes, pps, base_focals, core
     return imgs, out, (out if niter2 else None), params_ret
 
 
+def _images_of_pairs(filelist, pairs):
+    """The resized GT images, HxWx3 in [0,1], per file of `filelist` -- from the (3,H,W) tensors in [-1,1] the pair
+    dicts carry (Mast3r's SparseGA keeps exactly these as `.imgs`, scene.py:133)."""
+    found = {}
+    for pair in pairs:
+        for v in pair:
+            if v["instance"] not in found:
+                im = v["img"][0] if v["img"].dim() == 4 else v["img"]
+                found[v["instance"]] = ((im.detach().float().cpu().permute(1, 2, 0) + 1) / 2).clamp(0, 1).numpy()
+    return [found[n] for n in filelist]
+
+
 def run_sparse_ga(imgs, pairs_in=None, cache_path=None, model=None, subsample=8, desc_conf="desc_conf", device="cuda",
                   dtype=torch.float32, shared_intrinsics=False, optim_params=None, **kw):
     """Reference signature (starster/reconstruct.py:75-113): returns (scene, optim_params).
 
     Two ways in:
       * `imgs` is the condensed dict of the `model.condense()` protocol (module docstring): aligned directly;
-      * `imgs` is the reference's file list and `model` a Mast3r network: the pairwise inference, matching and
-        condensation are Mast3r's own functions (forward_mast3r, prepare_canonical_data, compute_min_spanning_tree,
-        condense_data), imported from the `mast3r` package when it is installed -- it is not vendored by the
-        reference (empty submodule) and cannot be fetched offline, so this branch is untested here."""
+      * `imgs` is the reference's file list, `pairs_in` the list of (view dict, view dict) pairs and `model` a network:
+        the reference's own sequence (:95-113) -- pair naming, forward_mast3r (pairwise inference through the network,
+        reciprocal matching = path A, resumable disk cache), prepare_canonical_data / compute_min_spanning_tree /
+        condense_data, the alignment (path B), and a scene object with the members of Mast3r's SparseGA
+        the reference touches -- every step in this library (starst3r_amd.forward / condense / align).  A Mast3r network
+        (the reference's model type) is wrapped in forward.Mast3rNetwork: only the ViT forward is Mast3r's."""
     kw.setdefault("lr1", 0.07); kw.setdefault("niter1", 500); kw.setdefault("lr2", 0.014); kw.setdefault("niter2", 200)
+    dev = "cuda:0" if str(device) == "cuda" else str(device)
     if isinstance(imgs, dict):
         condensed = imgs
-        res, params = align.run(condensed, lr1=kw["lr1"], niter1=kw["niter1"], lr2=kw["lr2"], niter2=kw["niter2"],
-                                prev_params=optim_params, device=device)
-        return SparseGAResult(condensed.get("imgs"), res, condensed.get("dense")), params
-    try:
-        from mast3r.cloud_opt.sparse_ga import (SparseGA, compute_min_spanning_tree, condense_data,
-                                                convert_dust3r_pairs_naming, forward_mast3r, prepare_canonical_data)
-    except ImportError as e:
-        raise ImportError("run_sparse_ga(filelist, pairs, cache, model) needs the `mast3r` package for the pairwise "
-                          "inference and condensation; without it pass a model that implements condense()") from e
-    pairs_in = convert_dust3r_pairs_naming(imgs, pairs_in)
-    pairs, cache_path = forward_mast3r(pairs_in, model, cache_path=cache_path, subsample=subsample, desc_conf=desc_conf,
-                                       device=device)
-    tmp_pairs, pairwise_scores, canonical_views, canonical_paths, preds_21 = prepare_canonical_data(
-        imgs, pairs, subsample, cache_path=cache_path, mode="avg-angle", device=device)
-    mst = compute_min_spanning_tree(pairwise_scores)
-    imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21 = condense_data(
-        imgs, tmp_pairs, canonical_views, preds_21, dtype)
-    kw.pop("opt_depth", None); kw.pop("matching_conf_thr", None)
-    imgs, res_coarse, res_fine, optim_params = sparse_scene_optimizer_slam(
-        imgs, subsample, imsizes, pps, base_focals, core_depth, anchors, corres, corres2d, preds_21, canonical_paths, mst,
-        shared_intrinsics=shared_intrinsics, cache_path=cache_path, device=device, dtype=dtype, opt_depth=False,
-        matching_conf_thr=5, prev_params=optim_params, **kw)
-    return SparseGA(imgs, pairs_in, res_fine or res_coarse, anchors, canonical_paths), optim_params
+    else:
+        if shared_intrinsics:
+            raise NotImplementedError("shared_intrinsics is not implemented on the HIP path (see sparse_scene_optimizer_slam)")
+        if kw.get("opt_depth"):
+            raise NotImplementedError("run_sparse_ga aligns with opt_depth=False like the reference's call (:66)")
+        from . import condense as _condense
+        from .forward import forward_mast3r, wrap_network
+        filelist = list(imgs)
+        pairs = list(pairs_in)
+        for pair in pairs:                                           # convert_dust3r_pairs_naming (:95)
+            for v in pair:
+                v["instance"] = filelist[v["idx"]]
+        tmp_pairs, cache_path = forward_mast3r(pairs, wrap_network(model), cache_path, desc_conf=desc_conf, device=dev,
+                                               subsample=subsample)
+        condensed = _condense.condense(filelist, tmp_pairs, subsample, device=dev, with_dense=True,
+                                       matching_conf_thr=float(kw.get("matching_conf_thr", 5.0)))
+        condensed["imgs"] = _images_of_pairs(filelist, pairs)
+    res, params = align.run(condensed, lr1=kw["lr1"], niter1=kw["niter1"], lr2=kw["lr2"], niter2=kw["niter2"],
+                            prev_params=optim_params, device=dev)
+    return SparseGAResult(condensed.get("imgs"), res, condensed.get("dense")), params
 
 
 def reconstruct_scene(model, imgs, filelist, device, optim_params=None, tmpdir=None):
     """Run the reconstruction pipeline: pairwise inference + matching (`model`), then global alignment.
 
     Returns (scene, optim_params); pass optim_params back in to warm start after adding images
-    (starster/reconstruct.py:19-72)."""
+    (starster/reconstruct.py:19-72).  `model`: a Mast3r network like in the reference, or any object implementing one
+    of the protocols of the module docstring."""
     if tmpdir is None:
         tmpdir = tempfile.mkdtemp()
-    if hasattr(model, "symmetric_inference"):
-        # the network only: pair bookkeeping, matching (path A), the disk cache, condensation and alignment run here
-        from . import condense as _condense
-        from .forward import forward_mast3r
-        from .image import make_pair_indices, prepare_images_for_mast3r
-        views = prepare_images_for_mast3r(imgs)
-        for v in views:
-            v["instance"] = filelist[v["idx"]]                      # convert_dust3r_pairs_naming (reconstruct.py:95)
-        pairs = [(views[i], views[j]) for i, j in make_pair_indices(len(views), symmetric=True)]
-        sub = getattr(model, "subsample", 8)
-        tmp_pairs, _ = forward_mast3r(pairs, model, tmpdir, device=device, subsample=sub)
-        condensed = _condense.condense(list(filelist), tmp_pairs, sub, device=device, with_dense=True)
-        condensed["imgs"] = [((im.detach().float().cpu().permute(1, 2, 0) + 1) / 2).clamp(0, 1).numpy() for im in imgs]
-        return run_sparse_ga(condensed, device=device, optim_params=optim_params)
-    if hasattr(model, "forward_pairs"):
+    if hasattr(model, "forward_pairs") and not hasattr(model, "symmetric_inference"):
         from . import condense as _condense
         tmp_pairs, images = model.forward_pairs(imgs, filelist, device, tmpdir)
         condensed = _condense.condense(list(filelist), tmp_pairs, getattr(model, "subsample", 8), device=device,
                                        with_dense=True)
         condensed["imgs"] = images
         return run_sparse_ga(condensed, device=device, optim_params=optim_params)
-    if hasattr(model, "condense"):
+    if hasattr(model, "condense") and not hasattr(model, "symmetric_inference"):
         condensed = model.condense(imgs, filelist, device, tmpdir)
         return run_sparse_ga(condensed, device=device, optim_params=optim_params)
-    # a Mast3r network: the reference's own call sequence (reconstruct.py:51-72), Mast3r's package doing its part
-    try:
-        from dust3r.image_pairs import make_pairs
-    except ImportError as e:
-        raise NotImplementedError(
-            "reconstruct_scene needs either a model that implements condense(imgs, filelist, device, cache_dir) or the "
-            "mast3r / dust3r packages for a Mast3r network (absent from the reference tree: empty submodule)") from e
-    from .image import prepare_images_for_mast3r
-    pairs = make_pairs(prepare_images_for_mast3r(imgs), scene_graph="complete", prefilter=None, symmetrize=True)
-    return run_sparse_ga(filelist, pairs, tmpdir, model, device=device, optim_params=optim_params)
+    # the network only -- an object with symmetric_inference, or a Mast3r network (wrapped by run_sparse_ga): the
+    # reference's own sequence (reconstruct.py:51-69): views, the complete symmetrized pair graph, run_sparse_ga
+    from .image import make_pair_indices, prepare_images_for_mast3r
+    views = prepare_images_for_mast3r(imgs)
+    pairs = [(views[i], views[j]) for i, j in make_pair_indices(len(views), symmetric=True)]
+    return run_sparse_ga(filelist, pairs, tmpdir, model, subsample=getattr(model, "subsample", 8), device=device,
+                         optim_params=optim_params, lr1=0.07, niter1=500, lr2=0.014, niter2=200, opt_depth=False,
+                         matching_conf_thr=5, shared_intrinsics=False)
 
 
 reconstruct = reconstruct_scene  # alias for the wording of BASELINE.json's north_star
