@@ -543,7 +543,8 @@ def main():
                          # (the whole step under the other exchange forms -- ranges, rs_ag -- is timed AFTER this line is
                          # out and reported on stderr / gpurun_out/exchange_forms_n<N>.json: those forms have never run
                          # with more than one rank, and a hang there must not cost the measurement)
-                         "exchange": os.environ.get("ST3R_EXCHANGE", "allreduce" if dist is not None else "none")},
+                         "exchange": ops.get_exchange(ctx) if (dist is not None and native_comm) else
+                                     ("allreduce (torch.distributed)" if dist is not None else "none")},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -588,10 +589,10 @@ def main():
         wd = threading.Timer(120.0, lambda: (sys.stderr.write("bench.py: exchange-form timing timed out\n"), os._exit(0)))
         wd.daemon = True; wd.start()
         forms_ms = {}
-        keep = os.environ.get("ST3R_EXCHANGE")
+        keep = ops.get_exchange(ctx)
         it_x = total - 1
         for form in ("allreduce", "ranges", "rs_ag"):
-            os.environ["ST3R_EXCHANGE"] = form
+            ops.set_exchange(ctx, form)
             step(it_x)                                   # warm-up of the form (streams, staging buffers)
             dist.barrier(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -602,10 +603,7 @@ def main():
             t = torch.tensor([e0.elapsed_time(e1) / 5], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             forms_ms[form] = float(t.item())
-        if keep is None:
-            os.environ.pop("ST3R_EXCHANGE", None)
-        else:
-            os.environ["ST3R_EXCHANGE"] = keep
+        ops.set_exchange(ctx, keep)
         wd.cancel()
         if rank == 0:
             rec = {"n_gpus": world, "exchange_forms_ms_per_step": forms_ms}

@@ -49,6 +49,7 @@ extern "C" {
 #define ST3R_ERR_HIP (-2)      /* a HIP runtime call failed */
 #define ST3R_ERR_CAPACITY (-3) /* caller-supplied capacity too small */
 #define ST3R_ERR_NOMEM (-4)
+#define ST3R_ERR_PEER (-5)     /* the previous exchanged training step failed on another rank: nobody applied it */
 
 #define ST3R_SPLAT_STRIDE 12
 #define ST3R_MAX_VIEWS 256    /* views per call (the camera table lives in LDS: 128 B per view) */
@@ -351,8 +352,29 @@ int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset,
  *   st3r_gs_train_step   st3r_gs_train_fwd_bwd -> st3r_grad_allreduce -> st3r_adam_step in one call:
  *                        one iteration of starster/gs.py:143-164 for this rank's views.  loss_out holds
  *                        this rank's part of the loss (sum over ranks = the reference's loss).
+ *
+ * The exchange inside st3r_gs_train_step takes one of three forms, a setting of the ctx (st3r_comm_set_exchange):
+ *   ST3R_EXCHANGE_ALLREDUCE  one all-reduce of the 23N floats after the backward, then Adam (default)
+ *   ST3R_EXCHANGE_RANGES     the projection backward runs per Gaussian range, a range's all-reduce overlaps the next
+ *                            range's backward and the previous range's Adam
+ *   ST3R_EXCHANGE_RS_AG      reduce-scatter -> Adam on the rank's piece -> all-gather of the parameters; the Adam
+ *                            moments are then maintained on the own piece only (st3r_comm_allgather_pieces replicates
+ *                            them again before the form is left)
+ * A communicator starts with the form the environment variable ST3R_EXCHANGE names (allreduce | ranges | rs_ag; read once,
+ * when the communicator is created or attached; never written by the library), else with the all-reduce.  All ranks must
+ * use the same form.
+ *
+ * Errors under a communicator: a step that fails on one rank (that rank returns the error) is applied on NO rank -- the
+ * failing rank still takes part in every collective, a max-reduced status word guards the update on the device -- and
+ * every other rank's next training call (or st3r_ctx_settle) returns ST3R_ERR_PEER: replicas stay identical, nobody hangs.
  * ---------------------------------------------------------------------------------- */
 #define ST3R_COMM_ID_BYTES 128
+#define ST3R_EXCHANGE_ALLREDUCE 0
+#define ST3R_EXCHANGE_RANGES 1
+#define ST3R_EXCHANGE_RS_AG 2
+int st3r_comm_set_exchange(st3r_ctx* ctx, int form);
+int st3r_comm_get_exchange(st3r_ctx* ctx, int* form);
+int st3r_comm_allgather_pieces(st3r_ctx* ctx, void* stream, float* buf, int64_t count);
 int st3r_comm_unique_id(char* id_out);
 int st3r_comm_init(st3r_ctx* ctx, int world_size, int rank, const char* id);
 int st3r_comm_attach(st3r_ctx* ctx, void* rccl_comm, int world_size, int rank);

@@ -60,6 +60,9 @@ SIGNATURES = {
     "st3r_comm_attach": [vp, vp, i32, i32],
     "st3r_comm_destroy": [vp],
     "st3r_comm_world": [vp, C.POINTER(i32), C.POINTER(i32)],
+    "st3r_comm_set_exchange": [vp, i32],
+    "st3r_comm_get_exchange": [vp, C.POINTER(i32)],
+    "st3r_comm_allgather_pieces": [vp, vp, vp, i64],
     "st3r_grad_allreduce": [vp, vp, vp, i64],
     "st3r_gs_train_step": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp,
                            vp, f64, f64, f64, f64, i32, vp, C.POINTER(i64)],

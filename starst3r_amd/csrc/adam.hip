@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256) void k_adam(int64_t N, float* __restrict__ mea
     // buffers dropped records, so its gradients are incomplete: the update is skipped HERE, on the device, and the next
     // call reports ST3R_ERR_CAPACITY -- the caller repeats the iteration with nothing to undo (a count above 2^31 wraps
     // negative: the unsigned compare catches it).
-    if (count_dev && (uint32_t)count_dev[0] > count_cap) return;
+    // Under a communicator the same buffer carries the step's max-reduced status word (comm.hip): a step that failed on
+    // any rank is applied on none.
+    if (count_dev && ((uint32_t)count_dev[0] > count_cap || count_dev[4] != 0)) return;
     const bool by_gaussian = g1 - g0 < N || gstage;
     const int64_t n = g1 - g0;
     const int64_t total = by_gaussian ? 23 * n : i1 - i0;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void k_params_from_stage(int64_t N, float* __r
                                                            const float* __restrict__ pstage, int64_t i0, int64_t i1,
                                                            int64_t lim, const int32_t* __restrict__ count_dev,
                                                            uint32_t count_cap) {
-    if (count_dev && (uint32_t)count_dev[0] > count_cap) return;
+    if (count_dev && ((uint32_t)count_dev[0] > count_cap || count_dev[4] != 0)) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < lim; i += stride) {
         if (i >= i0 && i < i1) continue;
@@ -128,10 +130,14 @@ int st3r_params_from_stage_impl(hipStream_t s, int N, float* means, float* quats
 }
 
 // the device-side guard of an asynchronous step that is still in flight (see k_adam)
+// (word 0 of the counts buffer: the record count of the step, compared with its capacity; word 4: the status word of
+// an exchanged step -- zero unless a communicator is attached.  With a communicator every step is sized exactly, so
+// only the status word guards: the capacity then is "no limit".)
 void st3r_adam_guard(st3r_ctx* ctx, const int32_t** count_dev, uint32_t* count_cap) {
-    const bool guard = ctx->count_pending && ctx->slot_ptr[SLOT_COUNTS];
+    const bool have = ctx->slot_ptr[SLOT_COUNTS] != nullptr;
+    const bool guard = have && (ctx->count_pending || ctx->comm);
     *count_dev = guard ? (const int32_t*)ctx->slot_ptr[SLOT_COUNTS] : nullptr;
-    *count_cap = guard ? (uint32_t)ctx->count_cap : 0u;
+    *count_cap = (guard && ctx->count_pending) ? (uint32_t)ctx->count_cap : 0xFFFFFFFFu;
 }
 
 ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,

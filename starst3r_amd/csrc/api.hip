@@ -40,6 +40,7 @@ ST3R_EXPORT int st3r_ctx_destroy(st3r_ctx* ctx) {
         if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->count_event) (void)hipEventDestroy(ctx->count_event);
+    if (ctx->peer_event) (void)hipEventDestroy(ctx->peer_event);
     if (ctx->comm_stream) {
         for (int j = 0; j < ST3R_MAX_RANGES; ++j) {
             (void)hipEventDestroy(ctx->ev_range_bwd[j]); (void)hipEventDestroy(ctx->ev_range_red[j]);
@@ -247,9 +248,24 @@ static int settle_pending_count(st3r_ctx* ctx) {
     return ST3R_OK;
 }
 
+int st3r_peer_status_settle(st3r_ctx* ctx);   // comm.hip
+
 ST3R_EXPORT int st3r_ctx_settle(st3r_ctx* ctx) {
     ARG_CHECK(ctx);
+    int rc = st3r_peer_status_settle(ctx);
+    if (rc) return rc;
     return settle_pending_count(ctx);
+}
+
+// The 16 device words next to the fused steps: [0] record count of an asynchronous step (k_adam compares it with the
+// step's capacity), [4] status word of an exchanged step (comm.hip).  Zeroed when allocated.
+int st3r_counts_buffer(st3r_ctx* ctx, hipStream_t s, int32_t** out) {
+    void* p; int grown = 0;
+    int rc = st3r_arena_get2(ctx, SLOT_COUNTS, sizeof(int32_t) * 16, &p, &grown);
+    if (rc) return rc;
+    if (grown) HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_COUNTS], s));
+    *out = (int32_t*)p;
+    return ST3R_OK;
 }
 
 #define GET(slot, type, count, var)                                                          \
@@ -342,7 +358,8 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     const int64_t sig = ((int64_t)N << 34) ^ ((int64_t)C << 26) ^ ((int64_t)W << 13) ^ (int64_t)H;
     const bool async = allow_async && ctx->isect_hint > 0 && ctx->hint_sig == sig;
     if (async) {
-        GET(SLOT_COUNTS, int32_t, 16, counts);
+        int32_t* counts;
+        { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
         HIP_TRY(hipMemcpyAsync(counts, total_dev, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + 8), total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (!ctx->count_event) HIP_TRY(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
@@ -442,16 +459,20 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     // a range's gradients can be reduced while the next range is still being computed.  Only for a whole call in one
     // pass: the later view chunks of a chunked call ADD to every range.
     ctx->ranges_recorded = 0;
-    if (ctx->n_ranges > 1 && !accumulate && ctx->comm_stream) {
+    if (ctx->n_ranges > 1 && ctx->comm_stream) {
         // the gradients of a range go to the ctx's staging buffer in range-major order (one contiguous piece per range);
-        // Adam reads them from there and leaves them in the caller's buffer in its block layout (comm.hip)
+        // Adam reads them from there and leaves them in the caller's buffer in its block layout (comm.hip).  The later
+        // view chunks of a chunked call ADD to the staged gradients and record the range events again (the exchange waits
+        // for an event's LAST record): whether a rank walks its views in chunks or not, it stages every range and takes
+        // part in the same K collectives (round 3 sent the first chunk to the staging buffer and the others to the
+        // caller's buffer, and fell back to one all-reduce on that rank only)
         GET(SLOT_GSTAGE, float, (int64_t)23 * N, gstage);
         const int K = ctx->n_ranges;
         for (int j = 0; j < K && !rc; ++j) {
             const int g0 = (int)((int64_t)N * j / K), g1 = (int)((int64_t)N * (j + 1) / K);
             rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
-                                          H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, gstage, false, g0, g1,
-                                          true);
+                                          H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, gstage, accumulate, g0,
+                                          g1, true);
             if (!rc) HIP_TRY(hipEventRecord(ctx->ev_range_bwd[j], s));
         }
         if (!rc) ctx->ranges_recorded = K;

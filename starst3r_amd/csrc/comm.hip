@@ -4,7 +4,10 @@
 // The reference is single-process (starster/gs.py:143-164 loops over all views on one device); sharding the
 // views over one process per GPU is valid because the loss is a plain sum over views (gs.py:149-152).
 //
-// The exchange itself comes in three forms (ST3R_EXCHANGE = allreduce | ranges | rs_ag; default: allreduce).  All three leave every replica with the same parameters; what differs is what overlaps:
+// The exchange itself comes in three forms, a setting of the ctx (st3r_comm_set_exchange; a communicator starts with the
+// form named by the environment variable ST3R_EXCHANGE = allreduce | ranges | rs_ag when it is set -- read ONCE, when the
+// communicator is created or attached, never written -- and with the plain all-reduce otherwise).  All three leave every
+// replica with the same parameters; what differs is what overlaps:
 //   allreduce  one ncclAllReduce of the 23N floats on the caller's stream after the whole backward, Adam after it
 //              (round 1 / 2).  Nothing overlaps: 92 MB at 1 M Gaussians.
 //   ranges     the projection backward, the last kernel of the backward, runs once per Gaussian range (K = 4) with an
@@ -87,6 +90,29 @@ RcclApi* rccl_api() {
         }                                                                                         \
     } while (0)
 
+// The form a new communicator starts with.  Default: the plain all-reduce.  The exchange follows the LAST kernels of the
+// iteration, so the range-wise form can hide at most the projection backward and Adam (0.05 + 0.14 ms at one view per
+// GPU) behind four collectives' latencies, and rs_ag keeps the moments on the own piece only; neither has been measured
+// on more than one GPU -- bench.py --gpus N times all three (per_rank.exchange_forms_ms_per_step).
+static int exchange_from_env() {
+    const char* e = getenv("ST3R_EXCHANGE");
+    if (e && !strcmp(e, "ranges")) return ST3R_EXCHANGE_RANGES;
+    if (e && !strcmp(e, "rs_ag")) return ST3R_EXCHANGE_RS_AG;
+    return ST3R_EXCHANGE_ALLREDUCE;
+}
+
+ST3R_EXPORT int st3r_comm_set_exchange(st3r_ctx* ctx, int form) {
+    ARG_CHECK(ctx && (form == ST3R_EXCHANGE_ALLREDUCE || form == ST3R_EXCHANGE_RANGES || form == ST3R_EXCHANGE_RS_AG));
+    ctx->exchange = form;
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_comm_get_exchange(st3r_ctx* ctx, int* form) {
+    ARG_CHECK(ctx && form);
+    *form = ctx->exchange;
+    return ST3R_OK;
+}
+
 ST3R_EXPORT int st3r_comm_unique_id(char* id_out) {
     ARG_CHECK(id_out);
     RcclApi* api = rccl_api();
@@ -107,6 +133,7 @@ ST3R_EXPORT int st3r_comm_init(st3r_ctx* ctx, int world_size, int rank, const ch
     ncclComm_t comm;
     RCCL_TRY(api, api->comm_init_rank(&comm, world_size, uid, rank));
     ctx->comm = comm; ctx->comm_owned = 1; ctx->comm_rank = rank; ctx->comm_size = world_size;
+    ctx->exchange = exchange_from_env();
     return ST3R_OK;
 }
 
@@ -114,6 +141,7 @@ ST3R_EXPORT int st3r_comm_attach(st3r_ctx* ctx, void* rccl_comm, int world_size,
     ARG_CHECK(ctx && rccl_comm && world_size >= 1 && rank >= 0 && rank < world_size && !ctx->comm);
     if (!rccl_api()) return ST3R_ERR_HIP;
     ctx->comm = rccl_comm; ctx->comm_owned = 0; ctx->comm_rank = rank; ctx->comm_size = world_size;
+    ctx->exchange = exchange_from_env();
     return ST3R_OK;
 }
 
@@ -151,19 +179,22 @@ int st3r_params_from_stage_impl(hipStream_t s, int N, float* means, float* quats
                                 const int32_t* count_dev, uint32_t count_cap);
 void st3r_adam_guard(st3r_ctx* ctx, const int32_t** count_dev, uint32_t* count_cap);
 
-enum { EXCH_ALLREDUCE = 0, EXCH_RANGES = 1, EXCH_RS_AG = 2 };
 #define EXCH_RANGES_K 4
 
-static int exchange_mode(const st3r_ctx* ctx) {
-    const char* e = getenv("ST3R_EXCHANGE");
-    if (e && !strcmp(e, "allreduce")) return EXCH_ALLREDUCE;
-    if (e && !strcmp(e, "ranges")) return EXCH_RANGES;
-    if (e && !strcmp(e, "rs_ag")) return EXCH_RS_AG;
-    // Default: the plain all-reduce.  The exchange follows the LAST kernels of the iteration, so the range-wise form can
-    // hide at most the projection backward and Adam (0.05 + 0.14 ms at one view per GPU) behind four collectives'
-    // latencies, and rs_ag keeps the moments on the own piece only; neither has been measured on more than one GPU --
-    // bench.py --gpus N times all three (per_rank.exchange_forms_ms_per_step).
-    return EXCH_ALLREDUCE;
+// Under st3r_gs_train_step with ST3R_EXCHANGE_RS_AG a rank maintains the Adam moments of ITS piece of the 23N buffer
+// only (w equal contiguous pieces in buffer order; the < w floats that do not divide are maintained by everyone).
+// Leaving that form -- e.g. for a refinement run that grows the Gaussian set and so moves the piece boundaries -- needs
+// the moments replicated again: in-place all-gather of the ranks' pieces of `buf` (count = 23 N floats).
+ST3R_EXPORT int st3r_comm_allgather_pieces(st3r_ctx* ctx, void* stream, float* buf, int64_t count) {
+    ARG_CHECK(ctx && count >= 0 && (count == 0 || buf));
+    if (!ctx->comm || count == 0) return ST3R_OK;
+    RcclApi* api = rccl_api();
+    if (!api) return ST3R_ERR_HIP;
+    const int64_t q = count / ctx->comm_size;
+    if (q > 0)
+        RCCL_TRY(api, api->all_gather(buf + (int64_t)ctx->comm_rank * q, buf, (size_t)q, ncclFloat32, (ncclComm_t)ctx->comm,
+                                      (hipStream_t)stream));
+    return ST3R_OK;
 }
 
 static int ensure_comm_stream(st3r_ctx* ctx) {
@@ -178,6 +209,29 @@ static int ensure_comm_stream(st3r_ctx* ctx) {
     return ST3R_OK;
 }
 
+// ---- a step that fails on ONE rank must not strand the others inside a collective ----
+// Every step under a communicator carries a status word: 1 on a rank whose forward / backward failed (out of memory,
+// an invalid argument that only its shard triggers, ...), max-all-reduced together with the gradients.  The failing
+// rank still issues every collective of the step -- on whatever its buffers hold -- and then returns its error; on ALL
+// ranks the Adam update of the step is skipped on the device (k_adam's guard reads the reduced word), and every other
+// rank learns about it at its next training call (or st3r_ctx_settle): ST3R_ERR_PEER, parameters untouched,
+// replicas still identical.
+int st3r_counts_buffer(st3r_ctx* ctx, hipStream_t s, int32_t** out);   // api.hip: 16 device words, zeroed when allocated
+#define PEER_WORD 4           // index of the status word inside the counts buffer
+#define PEER_PINNED 24        // its read-back slot in ctx->pinned (int64 units)
+
+int st3r_peer_status_settle(st3r_ctx* ctx) {
+    if (!ctx->peer_pending) return ST3R_OK;
+    HIP_TRY(hipEventSynchronize(ctx->peer_event));
+    ctx->peer_pending = 0;
+    if (((volatile int32_t*)(ctx->pinned + PEER_PINNED))[0] != 0) {
+        st3r_set_error("the previous training step failed on another rank of the communicator: no rank applied its "
+                       "update (replicas are unchanged and identical) -- see that rank's error");
+        return ST3R_ERR_PEER;
+    }
+    return ST3R_OK;
+}
+
 // One whole iteration of starster/gs.py:143-164 for this rank's C views: render -> loss -> backward ->
 // (exchange of the gradients when a communicator is attached: see the head of this file) -> Adam.  Asynchronous apart
 // from the intersection-count read-back inside the rasterizer.
@@ -187,74 +241,109 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
                                    float opac_fac, float scale_fac, float* grads, float* m, float* v, double lr,
                                    double beta1, double beta2, double eps, int step, float* loss_out,
                                    int64_t* stats_host) {
-    ARG_CHECK(ctx && grads && m && v && step >= 1);
+    ARG_CHECK(ctx && grads && m && v && step >= 1 && N > 0);
     hipStream_t s = (hipStream_t)stream;
-    const int mode = ctx->comm ? exchange_mode(ctx) : EXCH_ALLREDUCE;
-    RcclApi* api = ctx->comm ? rccl_api() : nullptr;
-    if (ctx->comm && !api) return ST3R_ERR_HIP;
-    if (mode == EXCH_RANGES) {
-        int rc0 = ensure_comm_stream(ctx);
-        if (rc0) return rc0;
-        ctx->n_ranges = N >= 4096 ? EXCH_RANGES_K : 1;
+    if (!ctx->comm) {   // a single replica: no exchange
+        int rc = st3r_gs_train_fwd_bwd(ctx, stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
+                                       campos, gt_images, width, height, ssim_fac, opac_fac, scale_fac, grads, loss_out,
+                                       stats_host);
+        if (rc) return rc;
+        return st3r_adam_step(ctx, stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2,
+                              eps, step);
     }
-    int rc = st3r_gs_train_fwd_bwd(ctx, stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
-                                   campos, gt_images, width, height, ssim_fac, opac_fac, scale_fac, grads, loss_out,
-                                   stats_host);
-    ctx->n_ranges = 0;
+    RcclApi* api = rccl_api();
+    if (!api) return ST3R_ERR_HIP;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    int rc = st3r_peer_status_settle(ctx);   // did the previous step fail somewhere else?
     if (rc) return rc;
+    const int mode = ctx->exchange;
+    int32_t* counts = nullptr;
+    // (failures from here to the collectives below are failures of the machinery the protocol itself needs: they are
+    // returned at once -- nothing can be promised to the other ranks without a stream, an event or 64 bytes of memory)
+    rc = st3r_counts_buffer(ctx, s, &counts);
+    if (rc) return rc;
+    if (!ctx->peer_event) HIP_TRY(hipEventCreateWithFlags(&ctx->peer_event, hipEventDisableTiming));
+    const int K = (mode == ST3R_EXCHANGE_RANGES && N >= 4096) ? EXCH_RANGES_K : 1;   // (a function of N alone: rank-consistent)
+    if (mode == ST3R_EXCHANGE_RANGES) {
+        rc = ensure_comm_stream(ctx);
+        if (rc) return rc;
+        ctx->n_ranges = K;
+    }
+    int rc_local = (ctx->debug_flags & 2048)   // test hook: this rank "fails" before it has computed anything
+                       ? (st3r_set_error("debug flag 2048: simulated failure of this rank's step"), ST3R_ERR_NOMEM)
+                       : st3r_gs_train_fwd_bwd(ctx, stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats,
+                                               Ks, campos, gt_images, width, height, ssim_fac, opac_fac, scale_fac, grads,
+                                               loss_out, stats_host);
+    ctx->n_ranges = 0;
+    char first_error[512];
+    if (rc_local) snprintf(first_error, sizeof(first_error), "%s", st3r_last_error());
+    // ---- the status word, reduced with the gradients
+    HIP_TRY(hipMemsetAsync(counts + PEER_WORD, rc_local ? 1 : 0, sizeof(int32_t), s));
+    RCCL_TRY(api, api->all_reduce(counts + PEER_WORD, counts + PEER_WORD, 1, ncclInt32, ncclMax, comm, s));
+    HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + PEER_PINNED), counts + PEER_WORD, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(ctx->peer_event, s));
+    ctx->peer_pending = 1;
     const int64_t total = (int64_t)23 * N;
-    const int32_t* count_dev; uint32_t count_cap;
-    st3r_adam_guard(ctx, &count_dev, &count_cap);
-    if (mode == EXCH_RANGES && ctx->ranges_recorded > 1) {
-        // ---- range-wise: all-reduce of range j behind its backward event, Adam of range j behind its all-reduce
-        const int K = ctx->ranges_recorded;
-        ncclComm_t comm = (ncclComm_t)ctx->comm;
-        float* gstage = (float*)ctx->slot_ptr[SLOT_GSTAGE];   // range-major: range j = 23 (g1 - g0) floats at 23 g0
+    const int32_t* guard; uint32_t count_cap;
+    st3r_adam_guard(ctx, &guard, &count_cap);
+    rc = ST3R_OK;
+    if (mode == ST3R_EXCHANGE_RANGES && K > 1) {
+        // ---- range-wise: all-reduce of range j behind its backward event, Adam of range j behind its all-reduce.
+        // (A rank whose step failed before the staging buffer existed sends its gradient buffer instead -- the sums are
+        // discarded anyway --; its range events were never recorded, which hipStreamWaitEvent treats as complete.)
+        float* gstage = ctx->ranges_recorded == K ? (float*)ctx->slot_ptr[SLOT_GSTAGE] : nullptr;
+        float* sendbuf = gstage ? gstage : grads;
         for (int j = 0; j < K; ++j) {
             const int64_t g0 = (int64_t)N * j / K, g1 = (int64_t)N * (j + 1) / K;
-            HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_range_bwd[j], 0));
-            RCCL_TRY(api, api->all_reduce(gstage + 23 * g0, gstage + 23 * g0, (size_t)(23 * (g1 - g0)), ncclFloat32, ncclSum,
+            HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, gstage ? ctx->ev_range_bwd[j] : ctx->peer_event, 0));
+            RCCL_TRY(api, api->all_reduce(sendbuf + 23 * g0, sendbuf + 23 * g0, (size_t)(23 * (g1 - g0)), ncclFloat32, ncclSum,
                                           comm, ctx->comm_stream));
             HIP_TRY(hipEventRecord(ctx->ev_range_red[j], ctx->comm_stream));
         }
         st3r_prof_begin(ctx, s, STG_ADAM);
-        for (int j = 0; j < K && !rc; ++j) {
+        for (int j = 0; j < K; ++j) {
             const int64_t g0 = (int64_t)N * j / K, g1 = (int64_t)N * (j + 1) / K;
             HIP_TRY(hipStreamWaitEvent(s, ctx->ev_range_red[j], 0));
-            rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
-                                step, count_dev, count_cap, -1, -1, g0, g1, nullptr, gstage, grads);
+            if (gstage && !rc)
+                rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
+                                    step, guard, count_cap, -1, -1, g0, g1, nullptr, gstage, grads);
         }
         st3r_prof_end(ctx, s, STG_ADAM);
-        return rc;
-    }
-    if (mode == EXCH_RS_AG) {
+    } else if (mode == ST3R_EXCHANGE_RS_AG) {
         // ---- reduce-scatter -> Adam on the own piece -> all-gather of the parameters
         const int w = ctx->comm_size, r = ctx->comm_rank;
         const int64_t q = total / w, tail0 = q * w;
-        ncclComm_t comm = (ncclComm_t)ctx->comm;
-        void* ps;
-        rc = st3r_arena_get(ctx, SLOT_PSTAGE, sizeof(float) * (size_t)total, &ps);
-        if (rc) return rc;
-        float* pstage = (float*)ps;
+        void* ps = nullptr;
+        const int rc_ps = st3r_arena_get(ctx, SLOT_PSTAGE, sizeof(float) * (size_t)total, &ps);
+        float* pstage = rc_ps ? nullptr : (float*)ps;
+        if (rc_ps && !rc_local) { rc_local = rc_ps; snprintf(first_error, sizeof(first_error), "%s", st3r_last_error()); }
         if (q > 0) RCCL_TRY(api, api->reduce_scatter(grads, grads + r * q, (size_t)q, ncclFloat32, ncclSum, comm, s));
         if (total > tail0) RCCL_TRY(api, api->all_reduce(grads + tail0, grads + tail0, (size_t)(total - tail0), ncclFloat32, ncclSum, comm, s));
         st3r_prof_begin(ctx, s, STG_ADAM);
-        rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
-                            count_dev, count_cap, r * q, (r + 1) * q, 0, -1, pstage, nullptr, nullptr);
-        if (!rc && total > tail0)   // the remainder: every rank holds its sum and updates it itself
-            rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
-                                step, count_dev, count_cap, tail0, total, 0, -1, nullptr, nullptr, nullptr);
-        st3r_prof_end(ctx, s, STG_ADAM);
-        if (rc) return rc;
-        if (q > 0) {
-            RCCL_TRY(api, api->all_gather(pstage + r * q, pstage, (size_t)q, ncclFloat32, comm, s));
-            rc = st3r_params_from_stage_impl(s, N, means, quats, scales, opacities, sh, sh_stride, pstage, r * q, (r + 1) * q,
-                                             tail0, count_dev, count_cap);
+        if (pstage) {
+            rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
+                                guard, count_cap, r * q, (r + 1) * q, 0, -1, pstage, nullptr, nullptr);
+            if (!rc && total > tail0)   // the remainder: every rank holds its sum and updates it itself
+                rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
+                                    step, guard, count_cap, tail0, total, 0, -1, nullptr, nullptr, nullptr);
         }
-        return rc;
+        st3r_prof_end(ctx, s, STG_ADAM);
+        if (q > 0) {
+            // (without a staging buffer -- this rank is failing -- the gradient buffer stands in: the others' pieces are
+            // discarded everywhere, the status word says so)
+            float* ag = pstage ? pstage : grads;
+            RCCL_TRY(api, api->all_gather(ag + r * q, ag, (size_t)q, ncclFloat32, comm, s));
+            if (pstage && !rc)
+                rc = st3r_params_from_stage_impl(s, N, means, quats, scales, opacities, sh, sh_stride, pstage, r * q,
+                                                 (r + 1) * q, tail0, guard, count_cap);
+        }
+    } else {
+        RCCL_TRY(api, api->all_reduce(grads, grads, (size_t)total, ncclFloat32, ncclSum, comm, s));
+        st3r_prof_begin(ctx, s, STG_ADAM);
+        rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
+                            guard, count_cap, -1, -1, 0, -1, nullptr, nullptr, nullptr);
+        st3r_prof_end(ctx, s, STG_ADAM);
     }
-    rc = st3r_grad_allreduce(ctx, stream, grads, total);
-    if (rc) return rc;
-    return st3r_adam_step(ctx, stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2,
-                          eps, step);
+    if (rc_local) { st3r_set_error("%s", first_error); return rc_local; }
+    return rc;
 }

@@ -278,11 +278,13 @@ def run_3dgs_optim(
     gt = _gt_on_device(scene, views)
     losses = torch.zeros(max(iters, 1), device=scene.device)
     fused = world == 1 or getattr(ctx, "native_comm", False)
-    import os
-    if enable_pruning and os.environ.get("ST3R_EXCHANGE") == "rs_ag":
+    restore_exchange = None
+    if enable_pruning and fused and world > 1 and ops.get_exchange(ctx) == "rs_ag":
         # reduce-scatter exchange: a rank maintains the Adam moments of its piece of the buffer only; growing the set
-        # moves the piece boundaries, so the refinement loop stays on an exchange with replicated moments
-        os.environ["ST3R_EXCHANGE"] = "ranges"
+        # moves the piece boundaries, so a refinement run uses the plain all-reduce (replicated moments) for its duration:
+        # the pieces are all-gathered first so that every rank holds the same, complete moments
+        ops.allgather_pieces(ctx, st.m); ops.allgather_pieces(ctx, st.v)
+        restore_exchange = ops.set_exchange(ctx, "allreduce")
     it_range = range(iters)
     if verbose:
         from tqdm import trange
@@ -333,6 +335,8 @@ def run_3dgs_optim(
             if not capacity_error(e):
                 raise
             one_iteration(iters - 1)   # its update was skipped on the device: repeat it
+    if restore_exchange is not None:   # (the moments stay complete on every rank: rs_ag goes on using its own piece)
+        ops.set_exchange(ctx, restore_exchange)
     _dist.all_reduce_sum(losses)
     return losses[:iters].cpu().tolist()   # one device->host copy for the whole call (reference: .item() per step)
 

@@ -368,9 +368,33 @@ def peek(ctx, which, count, dtype=torch.int32):
     return out
 
 
+EXCHANGE_FORMS = ("allreduce", "ranges", "rs_ag")   # ST3R_EXCHANGE_* of include/st3r.h, in order
+
+
+def set_exchange(ctx, form):
+    """The form the gradient exchange inside train_step takes from now on (a setting of the ctx; all ranks must agree):
+    'allreduce' | 'ranges' | 'rs_ag' (csrc/comm.hip).  Returns the previous form."""
+    prev = get_exchange(ctx)
+    _lib.check(_lib.lib().st3r_comm_set_exchange(ctx.handle, EXCHANGE_FORMS.index(form)))
+    return prev
+
+
+def get_exchange(ctx):
+    f = C.c_int(-1)
+    _lib.check(_lib.lib().st3r_comm_get_exchange(ctx.handle, C.byref(f)))
+    return EXCHANGE_FORMS[f.value]
+
+
+def allgather_pieces(ctx, buf):
+    """In-place all-gather of the ranks' pieces of a [23N] buffer (the partition of the 'rs_ag' exchange): replicates
+    Adam moments that were maintained piece-wise.  No-op without a communicator."""
+    _lib.check(_lib.lib().st3r_comm_allgather_pieces(ctx.handle, _stream(), _p(buf), buf.numel()))
+
+
 def settle(ctx):
     """Wait for the record count of the last asynchronous training step; raises St3rError (code -3) if that step outgrew
-    its buffers (its Adam update was skipped on the device)."""
+    its buffers (its Adam update was skipped on the device), code -5 if the last exchanged step failed on another rank
+    (no rank applied it)."""
     _lib.check(_lib.lib().st3r_ctx_settle(ctx.handle))
 
 

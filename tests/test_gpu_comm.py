@@ -51,10 +51,10 @@ def test_native_comm_single_rank_and_fused_step():
     # second stream under the projection backward / Adam of the neighbouring ranges; reduce-scatter -> Adam on the own
     # piece -> parameter all-gather).  One rank: the collectives are copies, the control flow, streams, events, index
     # ranges and the staging buffer are the real ones.
-    import os
     try:
+        assert ops.get_exchange(ctx) == "allreduce"       # the default of a fresh communicator (ST3R_EXCHANGE unset)
         for mode in ("allreduce", "ranges", "rs_ag"):
-            os.environ["ST3R_EXCHANGE"] = mode
+            assert ops.set_exchange(ctx, mode) in ops.EXCHANGE_FORMS and ops.get_exchange(ctx) == mode
             B = {k: v_.clone() for k, v_ in P.items()}
             grads_b = torch.empty(23 * N, device=DEV); mb = torch.zeros_like(grads); vb = torch.zeros_like(grads)
             loss_b = torch.zeros(1, device=DEV)
@@ -67,7 +67,7 @@ def test_native_comm_single_rank_and_fused_step():
             for k in A:
                 assert torch.equal(B[k], A[k]), (mode, k)
     finally:
-        os.environ.pop("ST3R_EXCHANGE", None)
+        ops.set_exchange(ctx, "allreduce")
         sdist.detach_native_comm(ctx)
     assert not ctx.native_comm
 
@@ -109,3 +109,99 @@ def test_sharded_adam_pieces_reassemble_the_replicated_update():
         assert torch.equal(R["v"][tail0:], v_ref[tail0:])
         other = (r + 1) % w
         assert torch.equal(R["m"][other * q:(other + 1) * q], m0[other * q:(other + 1) * q])   # not this rank's piece
+
+
+def _one_step(ctx, P, w2c, Ks, gt, W, H, step=1, grads=None, m=None, v=None):
+    from starst3r_amd import ops
+    N = P["means"].shape[0]
+    grads = torch.empty(23 * N, device=DEV) if grads is None else grads
+    m = torch.zeros_like(grads) if m is None else m
+    v = torch.zeros_like(grads) if v is None else v
+    loss = torch.zeros(1, device=DEV)
+    ops.train_step(ctx, P, w2c, Ks, ops.camera_positions(w2c), gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999,
+                   1e-8, step, loss)
+    torch.cuda.synchronize()
+    return grads, m, v, loss
+
+
+def test_range_exchange_of_a_chunked_call_equals_the_allreduce_result():
+    """ranges + view chunks.  Round 3 staged only the FIRST chunk's gradients range-major, added the later
+    chunks to the caller's buffer and then all-reduced that buffer alone: the first chunk's gradients were lost.  Every
+    chunk now adds to the staged ranges and the rank takes part in the same K range collectives as an unchunked rank."""
+    from starst3r_amd import dist as sdist, ops
+    ctx, P, w2c, Ks, gt, W, H = _problem()
+    sdist.attach_native_comm(ctx)
+    try:
+        A = {k: t.clone() for k, t in P.items()}
+        g_a, m_a, v_a, l_a = _one_step(ctx, A, w2c, Ks, gt, W, H)           # all-reduce, one pass
+        ops.set_exchange(ctx, "ranges")
+        ops.set_debug(ctx, 32)                                              # the training calls walk their views in two chunks
+        B = {k: t.clone() for k, t in P.items()}
+        g_b, m_b, v_b, l_b = _one_step(ctx, B, w2c, Ks, gt, W, H)
+        ops.set_debug(ctx, 0)
+        assert float(l_b) == pytest.approx(float(l_a), rel=1e-6)
+        # chunked sums add the views in another order than the one-pass kernel: equal to rounding, not bit for bit
+        scale = float(g_a.abs().max())
+        assert float((g_b - g_a).abs().max()) <= 2e-6 * scale
+        for k in A:
+            assert torch.allclose(B[k], A[k], rtol=0, atol=2e-6), k          # one Adam step of lr 1e-3 on equal gradients
+        assert torch.allclose(m_b, m_a, rtol=0, atol=2e-7 * scale)
+    finally:
+        ops.set_debug(ctx, 0)
+        ops.set_exchange(ctx, "allreduce")
+        sdist.detach_native_comm(ctx)
+
+
+@pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag"])
+def test_a_failing_rank_still_takes_part_and_nobody_applies_the_step(form):
+    """A step that fails on one rank must not strand the others in the collective: the failing rank issues
+    every collective of the step and returns its error, the max-reduced status word skips the Adam update on the device
+    everywhere, and the NEXT training call reports ST3R_ERR_PEER.  One rank here: it sees both its own error and the
+    status word of the step."""
+    from starst3r_amd import _lib, dist as sdist, ops
+    ctx, P, w2c, Ks, gt, W, H = _problem()
+    sdist.attach_native_comm(ctx)
+    try:
+        ops.set_exchange(ctx, form)
+        A = {k: t.clone() for k, t in P.items()}
+        N = A["means"].shape[0]
+        grads = torch.zeros(23 * N, device=DEV); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+        ops.set_debug(ctx, 2048)                                            # this rank's forward/backward "fails"
+        with pytest.raises(_lib.St3rError) as e1:
+            _one_step(ctx, A, w2c, Ks, gt, W, H, 1, grads, m, v)
+        assert e1.value.code == -4 and "simulated failure" in str(e1.value)
+        ops.set_debug(ctx, 0)
+        torch.cuda.synchronize()                                            # the collectives were issued and completed
+        for k in A:
+            assert torch.equal(A[k], P[k]), k                               # no update was applied
+        assert not m.any() and not v.any()
+        with pytest.raises(_lib.St3rError) as e2:                           # what every OTHER rank sees at its next call
+            _one_step(ctx, A, w2c, Ks, gt, W, H, 1, grads, m, v)
+        assert e2.value.code == -5
+        for k in A:
+            assert torch.equal(A[k], P[k]), k
+        _one_step(ctx, A, w2c, Ks, gt, W, H, 1, grads, m, v)                # and the job continues
+        ops.set_exchange(ctx, "allreduce")
+        B = {k: t.clone() for k, t in P.items()}
+        _one_step(ctx, B, w2c, Ks, gt, W, H, 1)
+        for k in A:
+            assert torch.equal(A[k], B[k]), (form, k)
+        ops.settle(ctx)                                                     # nothing pending, nothing to report
+    finally:
+        ops.set_debug(ctx, 0)
+        ops.set_exchange(ctx, "allreduce")
+        sdist.detach_native_comm(ctx)
+
+
+def test_allgather_pieces_replicates_piecewise_moments():
+    from starst3r_amd import dist as sdist, ops
+    ctx = ops.get_context(DEV)
+    x = torch.arange(23 * 101, device=DEV, dtype=torch.float32); y = x.clone()
+    ops.allgather_pieces(ctx, x)                       # no communicator: a no-op
+    sdist.attach_native_comm(ctx)
+    try:
+        ops.allgather_pieces(ctx, x)                   # one rank: its piece is the whole buffer
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+    finally:
+        sdist.detach_native_comm(ctx)
