@@ -126,9 +126,11 @@ def run(flat, lr1=0.07, niter1=500, lr2=0.014, niter2=200, prev_params=None, los
     core_res = depth_work[-Cn * G:].reshape(Cn, G) if depth_work is not None else core
     depth = cam[:, 15:16] + cam[:, 16:17] * core_res
     res = dict(intrinsics=K, cam2w=cam2w, depthmaps=depth, pts3d=pts, losses=losses[:niter1 + niter2],
-               _cam_rows=cam, _core=core, _base_focals=base_focals,
+               # (dense unprojection reads _core with _cam_rows: both belong to the start of the last iteration, like the
+               # depthmaps the reference unprojects from; the stepped core depths are params["core_depth"])
+               _cam_rows=cam, _core=core_res, _base_focals=base_focals,
                _adam_m=work[:11 * Cn].clone(),  # first moments, order pps|log_focals|quats|trans|log_sizes (tests)
-               _flags=work[22 * Cn + 24 * Cn + 20 * Cn:22 * Cn + 24 * Cn + 20 * Cn + 4].clone())  # loss, NaN stop, barrier abort
+               _flags=work[22 * Cn + 24 * Cn + 20 * Cn:22 * Cn + 24 * Cn + 20 * Cn + 4].clone())  # loss, NaN stop
     if depth_work is not None:   # opt_depth: first moments of the core depths [C, G] (tests)
         n_rows2 = depth_work.numel() - 3 * Cn * G
         res["_adam_m_core"] = depth_work[n_rows2:n_rows2 + Cn * G].reshape(Cn, G).clone()

@@ -184,19 +184,7 @@ __device__ __forceinline__ void flush_camera(const CamGrad& c, float* sw) {
 }
 
 // stage: 1 = loss_3d rows + dust rows, 2 = loss_2d rows + dust rows
-// Words that workgroups of the persistent kernel hand to each other (camera table, partial sums, the NaN flag) are
-// read and written with agent-scope atomics there (COH): they bypass the caches that are not coherent between XCDs, so
-// the kernel needs no cache write-back / invalidation per phase and everything constant stays cached.
-template <bool COH> __device__ __forceinline__ float ldx(const float* p) {
-    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COH> __device__ __forceinline__ void stx(float* p, float v) {
-    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
-
-// (the body is shared by the one-launch-per-iteration kernel k_align_resid and the persistent k_align_persist: `wg` is
-// the index of the workgroup among those of the residual phase)
-template <bool COH>
+// (`wg`: index of the workgroup among those of the residual phase)
 __device__ __forceinline__ void align_resid_body(const AlignProblem& P, const AlignState& S, int stage, float dust_w, int rpt,
                                                  int wg) {
     extern __shared__ float sacc[];  // 4 x [C*ACC_STRIDE + 1] accumulators (one per wave), then the camera table [C*CAM_STRIDE]
@@ -204,9 +192,9 @@ __device__ __forceinline__ void align_resid_body(const AlignProblem& P, const Al
     float* scam = sacc + 4 * nacc;
     float* sw = sacc + (threadIdx.x >> 6) * nacc;
     for (int i = threadIdx.x; i < 4 * nacc; i += blockDim.x) sacc[i] = 0.f;
-    for (int i = threadIdx.x; i < P.C * CAM_STRIDE; i += blockDim.x) scam[i] = ldx<COH>(S.cam + i);   // overlaps the row index loads
+    for (int i = threadIdx.x; i < P.C * CAM_STRIDE; i += blockDim.x) scam[i] = S.cam[i];   // overlaps the row index loads
     __syncthreads();
-    const bool running = ldx<COH>(S.acc + P.C * ACC_STRIDE + 1) == 0.f;   // not stopped by a NaN loss
+    const bool running = *(S.acc + P.C * ACC_STRIDE + 1) == 0.f;   // not stopped by a NaN loss
     for (int rr = 0; rr < rpt; ++rr) {   // rpt consecutive groups of 256 rows per workgroup (bounds the number of partials)
     CamGrad ca, cb;
     cam_clear(ca); cam_clear(cb);
@@ -326,11 +314,11 @@ __device__ __forceinline__ void align_resid_body(const AlignProblem& P, const Al
     // atomics anywhere, so the whole alignment is bit-reproducible
     float* part = S.part + (size_t)wg * nacc;
     for (int i = threadIdx.x; i < nacc; i += blockDim.x)
-        stx<COH>(part + i, (sacc[i] + sacc[nacc + i]) + (sacc[2 * nacc + i] + sacc[3 * nacc + i]));
+        part[i] = (sacc[i] + sacc[nacc + i]) + (sacc[2 * nacc + i] + sacc[3 * nacc + i]);
 }
 
 __global__ __launch_bounds__(256) void k_align_resid(AlignProblem P, AlignState S, int stage, float dust_w, int rpt) {
-    align_resid_body<false>(P, S, stage, dust_w, rpt, blockIdx.x);
+    align_resid_body(P, S, stage, dust_w, rpt, blockIdx.x);
 }
 
 __device__ __forceinline__ void quat_to_rot(const float* q, float* R, float* qn, float* inv_norm) {
@@ -447,7 +435,6 @@ __device__ unsigned long long g_upd_prof[8];
 #define UPD_MARK(k) do { } while (0)
 #endif
 
-template <bool COH>
 __device__ __forceinline__ void align_update_body(const AlignProblem& P, const AlignState& S, const UpdateArgs& U) {
     __shared__ float sRr[MAXC * 9], sRt[MAXC * 9], stt[MAXC * 3];        // relative / chained rotations, chained translation
     __shared__ float svRt[MAXC * 9], svtt[MAXC * 3];                      // their gradients
@@ -463,7 +450,7 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
     for (int k = i; k < 3 * C; k += blockDim.x) strans[k] = S.trans[k];
     for (int k = i; k < 2 * P.n_edges; k += blockDim.x) sedge[k] = P.edges[k];
     float* flags = S.acc + C * ACC_STRIDE;
-    if (U.do_backward && ldx<COH>(flags + 1) != 0.f) return;  // stopped earlier by a NaN loss
+    if (U.do_backward && *(flags + 1) != 0.f) return;  // stopped earlier by a NaN loss
     if (U.do_backward && U.n_part >= 0) {   // gradient sums and loss = the residual workgroups' partials, added in
                                             // workgroup order (n_part < 0: k_align_reduce has done it)
         const int nacc = C * ACC_STRIDE + 1;
@@ -475,7 +462,7 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
             for (int b0 = 0; b0 < U.n_part; b0 += INFL) {
                 float v[INFL];
 #pragma unroll
-                for (int j = 0; j < INFL; ++j) v[j] = b0 + j < U.n_part ? ldx<COH>(part + (size_t)(b0 + j) * nacc + k) : 0.f;
+                for (int j = 0; j < INFL; ++j) v[j] = b0 + j < U.n_part ? *(part + (size_t)(b0 + j) * nacc + k) : 0.f;
 #pragma unroll
                 for (int j = 0; j < INFL; ++j) a += v[j];
             }
@@ -487,7 +474,7 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
     if (U.do_backward && i == 0) {
         const float loss = flags[0];
         S.losses[U.loss_index] = loss;
-        if (loss != loss) stx<COH>(flags + 1, 1.f);          // reference: `if loss != loss: break` (:397-399), before... after the step
+        if (loss != loss) flags[1] = 1.f;          // reference: `if loss != loss: break` (:397-399), before... after the step
     }
     if (U.reset_moments)
         for (int k = i; k < 11 * C; k += blockDim.x) { S.m[k] = 0.f; S.v[k] = 0.f; }
@@ -664,145 +651,18 @@ __device__ __forceinline__ void align_update_body(const AlignProblem& P, const A
         const float to[3] = {zc * (W / f) * (0.5f - ppx), zc * (H / f) * (0.5f - ppy), zc};
         float* c = S.cam + i * CAM_STRIDE;
         const float* Rt = sRt + 9 * i;
-        for (int k = 0; k < 9; ++k) stx<COH>(c + k, Rt[k]);
+        for (int k = 0; k < 9; ++k) c[k] = Rt[k];
         for (int r = 0; r < 3; ++r)
-            stx<COH>(c + 9 + r, gs * (stt[3 * i + r] - (Rt[3 * r] * to[0] + Rt[3 * r + 1] * to[1] + Rt[3 * r + 2] * to[2])));
-        stx<COH>(c + 12, f); stx<COH>(c + 13, ppx * W); stx<COH>(c + 14, ppy * H);
-        stx<COH>(c + 15, gs * (zc - med * s)); stx<COH>(c + 16, gs * med * s); stx<COH>(c + 17, bf);
+            c[9 + r] = gs * (stt[3 * i + r] - (Rt[3 * r] * to[0] + Rt[3 * r + 1] * to[1] + Rt[3 * r + 2] * to[2]));
+        c[12] = f; c[13] = ppx * W; c[14] = ppy * H;
+        c[15] = gs * (zc - med * s); c[16] = gs * med * s; c[17] = bf;
     }
     // clear the accumulators for the next residual launch (keep the NaN flag)
     for (int k = i; k < C * ACC_STRIDE + 1; k += blockDim.x) S.acc[k] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_align_update(AlignProblem P, AlignState S, UpdateArgs U) {
-    align_update_body<false>(P, S, U);
-}
-
-// ---- the whole optimisation as ONE launch (round 3; opt-in, debug flag 1024 -- built to remove the launches, kept as
-// a measured negative result).  The per-iteration kernels above run back to back: at 8 views an iteration is 12.6 us of
-// k_align_resid + 15.7 us of k_align_update.  Here `n_wg` workgroups stay resident for all niter1 + niter2 iterations:
-//   residual phase   every workgroup with rows runs align_resid_body -> its partial sums
-//   grid barrier
-//   update phase     workgroup 0 runs align_update_body (adds the partials in workgroup order, Adam, new camera table)
-//   grid barrier
-// The grid barrier is an agent-scope counter in device memory: one thread per workgroup adds one and polls until all
-// n_wg have arrived.  A first version released / acquired at agent scope around it (the L2 of an XCD is not coherent with
-// the others': write-back + invalidation) and ran no faster than the launches it replaced -- a cache flush per phase IS a
-// kernel boundary; the words that cross workgroups now travel with agent-scope atomics instead (ldx / stx above) and the
-// barrier touches no cache.  The poll is bounded -- a workgroup that gives up sets flags[2] and every workgroup leaves (the
-// launch uses at most 64 workgroups of 256 threads, far below what is resident at once, so this only guards against
-// a device that is shared with a kernel that never ends).  Same arithmetic in the same order as the multi-launch path:
-// bit-identical results whenever both group the rows into the same workgroups (up to 16384 rows per stage).
-// Measured (tools/align_profile.py, -DALIGN_PROFILE: shader-clock timestamps of workgroup 0; 8 views, 7496 rows, 30
-// workgroups): residual phase 5.6 us + 6.7 us waiting for the slowest workgroup (thirty workgroups on eight XCDs fetch
-// the same 768 bytes of camera table from the memory side) + update phase 16.9 us (a single workgroup walking dependent
-// chains: ~8 us fixed + 1.4 us per view -- three sequential passes over the MST) + 1.5 us for the second barrier =
-// 30.6 us per iteration against 28.3 us for the two launches.  The launches were never the cost; the update phase is,
-// and what would shorten it (per-view state in registers across iterations, one fused pass over the MST) applies to
-// both forms.
-struct PersistArgs {
-    int niter1, niter2, n_part1, n_part2, rpt, n_wg, opt_pp, n_anchors;
-    float dust_w;
-    const float* lr;       // [3][niter1 + niter2]: learning rate, Adam step size, sqrt of the second bias correction
-    unsigned* barrier;     // zeroed before the launch
-    float* cam_out; float* pts_out;
-};
-
-__device__ __forceinline__ bool align_grid_sync(unsigned* bar, unsigned target, float* flags) {
-    // every thread's written-through stores must have been acknowledged before its workgroup arrives (the barrier
-    // instruction alone does not wait for global stores)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        // (the words other workgroups read were stored with agent-scope atomics, i.e. written through, and have been
-        // acknowledged: no cache write-back here, no invalidation behind the poll)
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
-            __builtin_amdgcn_s_sleep(2);
-            if (spins > (1u << 24) || __hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.f) {
-                __hip_atomic_store(flags + 2, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        s_ok = ok;
-    }
-    __syncthreads();
-    return s_ok != 0;
-}
-
-__global__ __launch_bounds__(256) void k_align_persist(AlignProblem P, AlignState S, PersistArgs A) {
-    const int wg = blockIdx.x;
-    float* flags = S.acc + P.C * ACC_STRIDE;
-    unsigned epoch = 0;
-    if (wg == 0) {
-        UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0, 1, 0.f, 1.f};
-        align_update_body<true>(P, S, U0);
-    }
-    if (!align_grid_sync(A.barrier, (++epoch) * A.n_wg, flags)) return;
-    const int last_stage = A.niter2 > 0 ? 2 : 1;
-    int li = 0;
-#ifdef ALIGN_PROFILE   // shader-clock ticks of workgroup 0 per phase, summed over the iterations -> ctl words 4..11
-    long long pf[4] = {0, 0, 0, 0};
-#define PF_T() ((long long)__builtin_readcyclecounter())
-#endif
-    for (int stage = 1; stage <= 2; ++stage) {
-        const int niter = stage == 1 ? A.niter1 : A.niter2;
-        const int n_part = stage == 1 ? A.n_part1 : A.n_part2;
-        for (int it = 0; it < niter; ++it, ++li) {
-#ifdef ALIGN_PROFILE
-            const long long p0 = PF_T();
-#endif
-            if (stage == last_stage && it == niter - 1) {
-                // the results belong to the START of the last iteration (see export_results on the host side)
-                extern __shared__ float sdyn[];
-                float* scam = sdyn + 4 * (P.C * ACC_STRIDE + 1);      // where the residual phase keeps its copy, too
-                __syncthreads();
-                for (int k = threadIdx.x; k < P.C * CAM_STRIDE; k += blockDim.x) {
-                    scam[k] = ldx<true>(S.cam + k);
-                    if (wg == 0) A.cam_out[k] = scam[k];
-                }
-                __syncthreads();
-                if (A.pts_out)
-                    for (int a = wg * blockDim.x + threadIdx.x; a < A.n_anchors; a += A.n_wg * blockDim.x) {
-                        const Pt r = anchor_point(P, scam, a);
-                        A.pts_out[3 * a] = r.pw[0]; A.pts_out[3 * a + 1] = r.pw[1]; A.pts_out[3 * a + 2] = r.pw[2];
-                    }
-                __syncthreads();
-            }
-            if (wg < n_part) align_resid_body<true>(P, S, stage, A.dust_w, A.rpt, wg);
-#ifdef ALIGN_PROFILE
-            const long long p1 = PF_T();
-#endif
-            if (!align_grid_sync(A.barrier, (++epoch) * A.n_wg, flags)) return;
-#ifdef ALIGN_PROFILE
-            const long long p2 = PF_T();
-#endif
-            if (wg == 0) {
-                UpdateArgs U;
-                const int nit = A.niter1 + A.niter2;
-                U.n_part = n_part; U.do_backward = 1; U.stage = stage; U.lr = A.lr[li]; U.step = it + 1; U.loss_index = li;
-                U.reset_moments = (it == 0); U.opt_pp = A.opt_pp; U.step_size = A.lr[nit + li]; U.bc2_sqrt = A.lr[2 * nit + li];
-                align_update_body<true>(P, S, U);
-            }
-#ifdef ALIGN_PROFILE
-            const long long p3 = PF_T();
-#endif
-            if (!align_grid_sync(A.barrier, (++epoch) * A.n_wg, flags)) return;
-#ifdef ALIGN_PROFILE
-            const long long p4 = PF_T();
-            pf[0] += p1 - p0; pf[1] += p2 - p1; pf[2] += p3 - p2; pf[3] += p4 - p3;
-#endif
-        }
-    }
-#ifdef ALIGN_PROFILE
-    if (wg == 0 && threadIdx.x == 0) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(A.barrier + 4);
-        for (int k = 0; k < 4; ++k) out[k] = (unsigned long long)pf[k];
-    }
-#endif
+    align_update_body(P, S, U);
 }
 
 // opt_depth (reconstruct.py:437): the core depths are parameters of the second stage as well.  One thread per core
@@ -838,9 +698,6 @@ __global__ void k_align_points(AlignProblem P, AlignState S, int n_anchors, floa
 }
 
 #ifdef ALIGN_PROFILE
-ST3R_EXPORT int st3r_debug_align_profile(st3r_ctx* ctx, unsigned long long* out4_host) {
-    return hipMemcpy(out4_host, (const char*)ctx->slot_ptr[SLOT_ALIGN_CTL] + 16, 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
 ST3R_EXPORT int st3r_debug_update_profile(unsigned long long* out8_host, int reset) {
     if (out8_host) (void)hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_upd_prof), sizeof(unsigned long long) * 8);
     if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_upd_prof), z, sizeof(z)); }
@@ -896,17 +753,12 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
     S.pps = pps; S.log_focals = log_focals; S.quats = quats; S.trans = trans; S.log_sizes = log_sizes;
     S.m = work; S.v = work + 11 * C; S.cam = work + 22 * C; S.acc = S.cam + (int64_t)C * CAM_STRIDE;
     S.losses = losses_out;
-    // control words: [0..15] grid-barrier counter (+ profile words) | [16 .. 16+12C) the chain cache of k_align_update |
-    // three per-iteration tables of the persistent kernel
-    const int n_iter_total = niter1 + niter2;
-    float* ctl;
-    {
+    {   // the chain cache of k_align_update: 12 floats per view
         void* pc;
-        int rc = st3r_arena_get(ctx, SLOT_ALIGN_CTL, sizeof(float) * (size_t)(16 + 12 * C + 3 * n_iter_total), &pc);
+        int rc = st3r_arena_get(ctx, SLOT_ALIGN_CTL, sizeof(float) * (size_t)(12 * C), &pc);
         if (rc) return rc;
-        ctl = (float*)pc;
+        S.chain = (float*)pc;
     }
-    S.chain = ctl + 16;
     auto lr_of = [&](int stage, int it, int li) -> float {
         const int niter = stage == 1 ? niter1 : niter2;
         const float lr_base = stage == 1 ? lr1 : lr2;
@@ -939,37 +791,6 @@ ST3R_EXPORT int st3r_align_run_opts(st3r_ctx* ctx, void* stream, int C, int G, i
         if (n_anchors > 0)
             hipLaunchKernelGGL(k_align_pack_anchors, dim3(ceil_div(n_anchors, 256)), dim3(256), 0, s, n_anchors, anchor_pix,
                                anchor_idx, anchor_off, anchor_img, core, G, (float4*)pk);
-    }
-    // ---- one persistent launch for the whole optimisation: opt-in (debug flag 1024).  Measured on the box it is no
-    // faster than the launch-per-iteration loop below (8 views: 21.4 vs 19.8 ms for 500 + 200 iterations; see the
-    // comment at k_align_persist), so the loop stays the default.
-    if ((ctx->debug_flags & 1024) && !opt_depth && niter1 + niter2 > 0) {
-        PersistArgs A;
-        const int groups = max_rows > 0 ? ceil_div(max_rows, 256) : 1;
-        A.n_wg = groups < 64 ? groups : 64;
-        A.rpt = ceil_div(groups, A.n_wg);
-        const int rows1 = n_corr + n_dust, rows2 = n_c2d + n_dust;
-        A.n_part1 = rows1 > 0 ? ceil_div(rows1, 256 * A.rpt) : 0;
-        A.n_part2 = rows2 > 0 ? ceil_div(rows2, 256 * A.rpt) : 0;
-        A.niter1 = niter1; A.niter2 = niter2; A.opt_pp = opt_pp; A.n_anchors = n_anchors; A.dust_w = dust_weight;
-        A.cam_out = cam_out; A.pts_out = n_anchors > 0 ? pts_out : nullptr;
-        A.barrier = (unsigned*)ctl;
-        float* tab_dev = ctl + 16 + 12 * C;
-        A.lr = tab_dev;
-        std::vector<float> tab(3 * (size_t)n_iter_total);
-        for (int st = 1, li = 0; st <= 2; ++st)
-            for (int it = 0; it < (st == 1 ? niter1 : niter2); ++it, ++li) {
-                tab[li] = lr_of(st, it, li);
-                adam_factors(tab[li], it + 1, &tab[n_iter_total + li], &tab[2 * (size_t)n_iter_total + li]);
-            }
-        HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(float) * 16, s));
-        // (pageable source: the runtime has taken its copy of `tab` when the call returns)
-        HIP_TRY(hipMemcpyAsync(tab_dev, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice, s));
-        if (sh > 24 * 1024)   // 40 KB of static LDS (the update's tables) + the residual's dynamic part
-            HIP_TRY(hipFuncSetAttribute((const void*)k_align_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(k_align_persist, dim3(A.n_wg), dim3(256), sh, s, P, S, A);
-        LAUNCH_CHECK();
-        return ST3R_OK;
     }
     UpdateArgs U0 = {0, 0, 1, 0.f, 0, 0, 0, 1, 0.f, 1.f};
     hipLaunchKernelGGL(k_align_update, dim3(1), dim3(256), 0, s, P, S, U0);

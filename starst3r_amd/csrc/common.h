@@ -71,7 +71,7 @@ enum ArenaSlot {
     SLOT_COUNTS,
     SLOT_PSTAGE,
     SLOT_GSTAGE,
-    SLOT_ALIGN_CTL,   // persistent alignment kernel: grid-barrier counter + one learning rate per iteration
+    SLOT_ALIGN_CTL,   // alignment: the chain cache of k_align_update
     SLOT_SCAN_CHAIN,  // single-pass scans (gs_isect.hip): ticket, totals, one status word per tile
     SLOT_COUNT
 };
@@ -105,8 +105,8 @@ struct st3r_ctx {
     int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test; 1: backward
                       // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks;
                       // 6: backward gathers rectangle and slot base separately; 7 (128): training forward on the quadrant
-                      // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 10 (1024): alignment as one persistent
-                      // kernel instead of two launches per iteration (measured: not faster)
+                      // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 11 (2048): under a communicator
+                      // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip)
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     uint32_t scan_gen, scan_ticket[2];   // chained kernels (gs_isect.hip): generation of the status words; tickets handed
                                          // out so far from queue 0 and from each of the queues 1..7

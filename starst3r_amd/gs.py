@@ -316,8 +316,13 @@ def run_3dgs_optim(
         except _lib_mod.St3rError as e:
             # ST3R_ERR_CAPACITY is reported by the call AFTER the asynchronous step that outgrew its buffers (> 25 % more
             # tile intersections than the step before it).  That step's records past the capacity were dropped and its
-            # Adam update was skipped on the device (k_adam's guard), so nothing has to be undone: the lost iteration is
-            # repeated -- the context is back on the exactly sized path -- and then this one runs.
+            # Adam update was skipped on the device (k_adam's guard), so no parameter update has to be undone: the lost
+            # iteration is repeated -- the context is back on the exactly sized path -- and then this one runs.  With
+            # enable_pruning the strategy hooks of the lost iteration have already run on the un-updated parameters
+            # (its position noise, and on a refinement step its relocation / growth): they are NOT run again, i.e. the
+            # noise of that one iteration is drawn before its update instead of after it.  A deviation of one step's
+            # noise (tests/test_gpu_api.py::test_run_3dgs_optim_repeats_...); overflows need > 25 % more tile
+            # intersections than the step before.
             if not capacity_error(e):
                 raise
             if step > 0:

@@ -193,10 +193,15 @@ def _gamma_of(loss, default):
         if "gamma" in fv:
             g = float(fv["gamma"])
             off = fv.get("offset")
+            # the offset gamma_loss itself derives: (1/g)^(1/(g-1)); gamma = 1 is the plain distance (no offset)
+            want = 0.0 if g == 1 else ((1 / g) ** (1 / (g - 1)) if g > 0 else None)
             if fv.get("mul", 1) != 1 or fv.get("clip", float("inf")) != float("inf") or \
-                    (off is not None and abs(off - (1 / g) ** (1 / (g - 1))) > 1e-6 * abs(off)):
+                    (off is not None and (want is None or abs(off - want) > 1e-6 * max(abs(off), 1e-30))):
                 raise NotImplementedError("gamma_loss with mul / clip / a custom offset is not implemented on the HIP path")
-    if g is None or "meta" in repr(loss):
+    # Mast3r's meta_gamma_loss (a loss factory the optimiser calls with the progress alpha, reconstruct.py:375,387) is
+    # recognised by its name, not by a substring of repr(): module paths or closures may well contain "meta"
+    name = getattr(loss, "__qualname__", getattr(loss, "__name__", type(loss).__name__))
+    if g is None or "meta_gamma_loss" in name or type(loss).__name__ == "meta_gamma_loss":
         raise NotImplementedError("only gamma_loss(g) / l1_loss objects can be evaluated on the HIP path")
     if not g > 0:
         raise ValueError("gamma_loss: gamma must be positive")

@@ -217,37 +217,6 @@ def test_opt_depth_gradient_and_schedule_vs_reference_golden():
     assert np.array_equal(par["core_depth"], par2["core_depth"]) and np.array_equal(par["quats"], par2["quats"])
 
 
-@pytest.mark.parametrize("views,n_corr", [(2, 300), (8, 250), (12, 900)])
-def test_persistent_kernel_equals_one_launch_per_iteration(views, n_corr):
-    """Debug flag 1024 runs the whole schedule of st3r_align_run* as ONE persistent launch (grid barriers between the
-    residual and the update phase) instead of two launches per iteration.  Same arithmetic in the same order:
-    bit-identical parameters, results and loss curves while both group the rows into the same workgroups (up to 16384
-    rows per stage), float-accurate beyond."""
-    from starst3r_amd import ops
-    from st3r_synth import synth_align
-    flat = synth_align.flatten(synth_align.make_problem(n_views=views, n_corr=n_corr, seed=21, bad_pair=views > 2))
-    ctx = ops.get_context("cuda:0")
-    rows = max(len(flat["corr_a1"]), len(flat["c2d_a2"])) + len(flat["dust_a1"])
-    # (beyond 16384 rows the partial sums are grouped differently: rounding-level differences, which the optimiser
-    # amplifies along the loosely constrained directions like any float32 trajectory -- compared after 10 + 5 iterations)
-    n1, n2 = (120, 60) if rows <= 16384 else (10, 5)
-    res_l, par_l = run_hip(flat, niter1=n1, niter2=n2)
-    ops.set_debug(ctx, 1024)
-    try:
-        res_p, par_p = run_hip(flat, niter1=n1, niter2=n2)
-    finally:
-        ops.set_debug(ctx, 0)
-    assert res_p["_flags"][2] == 0          # no grid barrier gave up
-    if rows <= 16384:
-        for k in ("pps", "log_focals", "quats", "trans", "log_sizes"):
-            assert np.array_equal(par_p[k], par_l[k]), k
-        for k in ("intrinsics", "cam2w", "depthmaps", "pts3d", "losses"):
-            assert np.array_equal(res_p[k], res_l[k]), k
-    else:
-        compare(res_p, par_p, res_l, par_l, 1e-4, "persistent vs launches")
-    print(views, "views,", rows, "rows: identical" if rows <= 16384 else "rows: float-accurate")
-
-
 def test_warm_start_splices_previous_params():
     """prev_params of a 2-view solve seed the first 2 views of a 3-view problem (reconstruct.py:408-415)."""
     from st3r_synth import synth_align

@@ -204,3 +204,52 @@ def test_view_chunks_give_the_gradients_of_the_whole_call():
     g3 = torch.empty_like(g1)
     ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, g3, l2, want_stats=False)
     assert torch.equal(g2, g3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pruning", [False, True])
+def test_run_3dgs_optim_repeats_an_iteration_whose_update_was_dropped(monkeypatch, pruning):
+    """the ST3R_ERR_CAPACITY recovery of run_3dgs_optim itself (re-run iteration k-1, then k; the final
+    ops.settle retry).  An asynchronous step is made to outgrow its buffers (debug flag 8 halves its capacity): its Adam
+    update is skipped on the device, the next call reports it, the loop repeats the lost iteration.  Without the MCMC
+    hooks the run equals an undisturbed one bit for bit; with them the position noise of the lost iteration was drawn before
+    its (repeated) update instead of after it -- a documented deviation: same Gaussian count, finite losses, close parameters."""
+    import starst3r_amd as st
+    from starst3r_amd import gs as gs_mod, ops
+    from st3r_synth.synth_model import SyntheticPairwiseModel
+
+    def make_scene():
+        scene = st.Scene(device="cuda:0")
+        scene.add_images(SyntheticPairwiseModel(width=128, height=96, n_corr=300, seed=2), [torch.zeros(3, 96, 128)] * 2)
+        scene.init_3dgs()
+        return scene
+    iters = 7
+    ref = make_scene()
+    ref_losses = ref.run_3dgs_optim(iters, enable_pruning=pruning)
+    real = ops.train_step
+    calls = {"n": 0, "overflowed": []}
+
+    def hooked(ctx, *a, **kw):
+        k = calls["n"]; calls["n"] += 1
+        if k in (3, iters):           # the 4th iteration, and -- counting the two repeats -- the LAST one (settle path)
+            ops.set_debug(ctx, 8); calls["overflowed"].append(k)
+        try:
+            return real(ctx, *a, **kw)
+        finally:
+            ops.set_debug(ctx, 0)
+    monkeypatch.setattr(gs_mod.ops, "train_step", hooked)
+    sc = make_scene()
+    losses = sc.run_3dgs_optim(iters, enable_pruning=pruning)
+    # 7 iterations + the repeat of the 4th (two extra calls: k-1 and k again... k is the call that raised) + the final repeat
+    assert calls["overflowed"] == [3, iters] and calls["n"] >= iters + 2
+    assert len(losses) == iters and np.all(np.isfinite(losses))
+    assert sc._gs_optim.step == ref._gs_optim.step == iters
+    assert sc.gaussians["means"].shape == ref.gaussians["means"].shape
+    if not pruning:
+        for k in ("means", "quats", "scales", "opacities", "shN"):
+            assert torch.equal(sc.gaussians[k].data, ref.gaussians[k].data), k
+        assert losses == ref_losses
+    else:
+        for k in ("means", "scales", "opacities"):
+            assert torch.allclose(sc.gaussians[k].data, ref.gaussians[k].data, atol=5e-3), k
+        assert abs(losses[-1] - ref_losses[-1]) < 0.05 * abs(ref_losses[-1])

@@ -55,3 +55,35 @@ def test_unsupported_configurations_are_refused():
     assert rc._gamma_of(rc.gamma_loss(1), 1.1) == 1.0 and rc._gamma_of(rc.l1_loss, 0.4) == 1.0
     assert rc.cosine_schedule(0.0, 0.07) == pytest.approx(0.07) and rc.cosine_schedule(1.0, 0.07) == pytest.approx(0.0)
     assert rc.linear_schedule(0.25, 0.08) == pytest.approx(0.06)
+
+
+def test_gamma_of_mast3r_style_closures():
+    """Mast3r's own gamma_loss closures -- free variables gamma / mul / offset / clip [U] -- incl. gamma = 1
+    with an explicit zero offset (used to divide by zero) and callables whose repr merely contains "meta"."""
+    def mast3r_gamma_loss(gamma, mul=1, offset=None, clip=float("inf")):
+        if offset is None:
+            offset = 0.0 if gamma == 1 else (1 / gamma) ** (1 / (gamma - 1))
+
+        def loss_func(x, y):
+            return (mul * rc.l1_loss(x, y).clip(max=clip) + offset) ** gamma - offset ** gamma
+        return loss_func
+    assert rc._gamma_of(mast3r_gamma_loss(1.1), 0.4) == pytest.approx(1.1)
+    assert rc._gamma_of(mast3r_gamma_loss(1, offset=0.0), 0.4) == 1.0
+    with pytest.raises(NotImplementedError):
+        rc._gamma_of(mast3r_gamma_loss(1, offset=0.5), 0.4)
+    with pytest.raises(NotImplementedError):
+        rc._gamma_of(mast3r_gamma_loss(0.5, mul=2), 0.4)
+
+    class metadata_loss:            # "meta" in the name, but an ordinary gamma loss object
+        gamma = 0.7
+
+        def __call__(self, x, y):
+            return x
+    assert rc._gamma_of(metadata_loss(), 1.1) == 0.7
+
+    def meta_gamma_loss():          # the factory form the kernels cannot take
+        return lambda alpha: rc.gamma_loss(1.1)
+    f = meta_gamma_loss
+    f.gamma = 1.1
+    with pytest.raises(NotImplementedError):
+        rc._gamma_of(f, 1.1)
