@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-drift", action="store_true",
                     help="skip the untimed continuation to 200 steps that shows how the step time drifts as training "
                          "changes the scene (windows.drift; one GPU, only when --steps < 200)")
+    ap.add_argument("--no-scaling-model", action="store_true",
+                    help="skip the single-GPU model of the 1 -> 8 GPU curve (scaling_model: this rank's step at 8 / 4 / 2 / 1 "
+                         "views + the one-rank exchange), ~1 s")
     ap.add_argument("--train-only", action="store_true",
                     help="skip the alignment / matching / condensation benches behind the headline (profiling runs)")
     ap.add_argument("--multi-gpu", choices=("replicated", "gaussian-sharded"), default="replicated",
@@ -253,6 +256,131 @@ def pmc_traffic(stage, N, views, W, H, world):
     return v, f"profiles/pmc_traffic.json (commit {rec.get('commit')}, {rec.get('source')})"
 
 
+CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md)
+
+
+def valu_issue(per_stage_ms, N, views, W, H, world):
+    """The roofline the blend kernels actually hit: VALU issue.  SQ_INSTS_VALU per launch (PMC pass of
+    tools/profile_round4.sh, kept in profiles/pmc_traffic.json next to the traffic) x 2 cycles -- the guide's issue rate of
+    a wave64 VALU instruction -- over 1024 SIMDs x clock x the kernel's time, and the same instruction count priced with
+    the measured per-opcode issue costs of tools/probe/valu_cost.hip instead of a flat 2 cycles (adds / multiplies /
+    fmac 1.0-1.1 ns, 3-source fma 1.47, compares / selects / min / max / DPP 1.7-1.8, exp / rcp 3.4 ns per instruction
+    and SIMD: DESIGN.md section 4 derives 1.17 ns per instruction for the backward's mix, 1.30 ns for the forward's)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    wl = rec.get("workload", {})
+    if [wl.get(k) for k in ("gaussians", "views", "width", "height", "n_gpus")] != [N, views, W, H, world]:
+        return None
+    insts = rec.get("valu_insts_per_launch")
+    if not insts or rec.get("csrc_fingerprint") != csrc_fingerprint():
+        return None
+    mix_ns = {"blend_bwd": 1.17, "blend_fwd": 1.30}
+    out = {"source": f"profiles/pmc_traffic.json (commit {rec.get('commit')}): SQ_INSTS_VALU per launch; kernel time: this "
+                     "run's HIP events; 1024 SIMDs at 2.4 GHz",
+           "opcode_mix_source": "tools/probe/valu_cost.hip issue costs x the instruction budgets of DESIGN.md section 4"}
+    for st in ("blend_fwd", "blend_bwd"):
+        if st in insts and per_stage_ms.get(st):
+            t = per_stage_ms[st] * 1e-3
+            per_simd = insts[st] / 1024.0
+            out[st] = {"valu_insts_per_launch": insts[st],
+                       "frac_at_2_cycles": per_simd * 2.0 / (CLOCK_GHZ * 1e9) / t,
+                       "frac_opcode_mix_weighted": per_simd * mix_ns[st] * 1e-9 / t}
+    return out
+
+
+def scaling_model(ctx, ops, g_np, w2c_np, Ks_np, N, V, W, H, device):
+    """What ONE GPU can say about the 1 -> 8 GPU curve of the north_star partition (views sharded, Gaussians replicated):
+    this rank's whole step at C_local = V, V/2, V/4, V/8 views -- the compute a rank of a 1-, 2-, 4-, 8-GPU job does
+    (projection, its backward and Adam stay O(N); blending, loss and the level-2 sort scale with the views) --, the
+    library's own exchange on a one-rank communicator (what the collective's launch and the exact per-step sizing cost
+    without any link traffic), and the link time of the 92 MB gradient buffer under SURVEY.md section 5's xGMI model
+    (7 point-to-point links x 153.6 GB/s per GPU): ring all-reduce 2 (w-1)/w B / link, direct reduce-scatter +
+    all-gather 2 B / (w link).  A MODEL, not a measurement: no multi-GPU node was available to the builder."""
+    from starst3r_amd import dist as sdist
+    LINK = 153.6e9
+    grad_bytes = 23 * N * 4
+    P0 = {k: torch.tensor(v, device=device) for k, v in g_np.items()}
+    out = {"note": "single-GPU model of the view-sharded job (DESIGN.md section 5); predicted, NOT measured on >1 GPU",
+           "link_model": "xGMI 7 links x 153.6 GB/s per GPU (SURVEY.md section 5)", "gradient_buffer_bytes": grad_bytes,
+           "per_rank": {}}
+
+    def time_steps(P, w2c, Ks, gt, n=10, warm=3):
+        campos = ops.camera_positions(w2c)
+        grads = torch.empty(23 * N, device=device); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+        loss = torch.zeros(1, device=device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(warm + n):
+            if it == warm:
+                e0.record()
+            ops.train_step(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1,
+                           loss, want_stats=(it == 0))
+        e1.record(); torch.cuda.synchronize()
+        try:
+            ops.settle(ctx)
+        except Exception:  # noqa: BLE001 -- a late capacity report of the last untimed step is of no interest here
+            pass
+        return e0.elapsed_time(e1) / n
+    worlds = [w for w in (1, 2, 4, 8) if V % w == 0]
+    setups = {}
+    for w in worlds:
+        views = list(range(0, V, w))                      # rank 0's shard of a w-GPU job (bench.py: range(rank, V, world))
+        w2c = torch.tensor(w2c_np[views], device=device); Ks = torch.tensor(Ks_np[views], device=device)
+        gt = make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device)
+        setups[w] = (w2c, Ks, gt)
+        ms = time_steps({k: t.clone() for k, t in P0.items()}, w2c, Ks, gt)
+        out["per_rank"][str(w)] = {"views_per_gpu": len(views), "step_ms_no_exchange": ms}
+    # the exchange machinery with one rank: collective launch + exact sizing (one host round trip per step), no link traffic
+    try:
+        sdist.attach_native_comm(ctx)
+        buf = torch.zeros(23 * N, device=device)
+        from starst3r_amd import _lib
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for r_ in range(6):
+            if r_ == 1:
+                e0.record()
+            _lib.check(_lib.lib().st3r_grad_allreduce(ctx.handle, ops._stream(), ops._p(buf), buf.numel()))
+        e1.record(); torch.cuda.synchronize()
+        out["one_rank_allreduce_ms"] = e0.elapsed_time(e1) / 5
+        for w in worlds:
+            w2c, Ks, gt = setups[w]
+            forms = {}
+            for form in ops.EXCHANGE_FORMS:
+                ops.set_exchange(ctx, form)
+                forms[form] = time_steps({k: t.clone() for k, t in P0.items()}, w2c, Ks, gt, n=6, warm=2)
+            out["per_rank"][str(w)]["step_ms_one_rank_communicator"] = forms
+        ops.set_exchange(ctx, "allreduce")
+        sdist.detach_native_comm(ctx)
+    except Exception as e:  # noqa: BLE001 -- no RCCL the library can bind: the compute part of the model stands
+        out["one_rank_allreduce_ms"] = None
+        out["communicator_error"] = str(e)
+    adam_ms = 644.0 * N / 4.4e12 * 1e3    # k_adam streams 644 B per Gaussian at ~4.4 TB/s (stage_ms.adam)
+    pred = {}
+    for w in worlds:
+        base = out["per_rank"][str(w)]
+        comm_ms = (base.get("step_ms_one_rank_communicator") or {}).get("allreduce")
+        # compute of a rank incl. the communicator's fixed costs when they could be measured
+        local = comm_ms if comm_ms is not None else base["step_ms_no_exchange"]
+        ring = 2.0 * (w - 1) / w * grad_bytes / LINK * 1e3 if w > 1 else 0.0
+        direct = 2.0 * grad_bytes / (w * LINK) * 1e3 if w > 1 else 0.0
+        pred[str(w)] = {
+            "link_ms_ring_allreduce": ring, "link_ms_direct_rs_ag": direct,
+            "iters_per_sec_allreduce_form_ring": 1e3 / (local + ring),
+            "iters_per_sec_rs_ag_form_direct": 1e3 / (local + direct - adam_ms * (1.0 - 1.0 / w)),
+            # layout 2 (Gaussians and views sharded): same blending / loss / sorts per rank, Adam on 1/w of the Gaussians,
+            # two all-to-alls of 48-byte records over direct links instead of the gradient exchange
+            "iters_per_sec_gaussian_sharded_direct": 1e3 / (local - adam_ms * (1.0 - 1.0 / w) +
+                                                            (2.0 * 48 * (V // w) * N / w / LINK * 1e3 if w > 1 else 0.0)),
+        }
+    out["predicted"] = pred
+    out["assumptions"] = ("exchange not overlapped with compute (the all-reduce follows the last kernels of the iteration); "
+                          "ring = what RCCL's default all-reduce is bound by on a point-to-point mesh, direct = every "
+                          "rank sends 1/w of the buffer to each peer over its own link (rs_ag form); the rs_ag / sharded "
+                          "rows subtract the replicated Adam's share that those forms do not run")
+    return out
+
+
 def matching_bench(device, with_cpu=True):
     """Path A: seeded nearest-neighbour query of fast_reciprocal_NNs (starster/reconstruct.py:97) at the
     reference's size: 3072 seeds against the 512x384 descriptors (D = 24) of the other image -- the only dense
@@ -301,6 +429,12 @@ def matching_bench(device, with_cpu=True):
 
 def main():
     args = parse()
+    # The ONE JSON line is the only thing that may reach stdout: libraries print there too (RCCL's version banner at
+    # communicator creation, from C, buffered until exit) -- so file descriptor 1 points at stderr for the whole run and
+    # the line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -568,6 +702,9 @@ def main():
                                    "others in turn); a stage without a sample there: warm-up steps",
             },
         }
+        out["roofline"]["valu_issue"] = valu_issue(per_stage, N, args.views, W, H, world)
+        if world == 1 and not FREEZE and not args.no_scaling_model and mode != "gaussian-sharded":
+            out["scaling_model"] = scaling_model(ctx, ops, g_np, w2c_np, Ks_np, N, args.views, W, H, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         else:
@@ -580,7 +717,7 @@ def main():
             out["align"]["hip_seconds_by_views"]["8"] = out["align"]["hip_seconds"]
             out["matching"] = matching_bench(device, with_cpu=not args.no_cpu_baseline)
             out["condense"] = condense_bench(device, with_cpu=not args.no_cpu_baseline)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     # ---- after the line: the whole step under each exchange form of st3r_gs_train_step (a few extra steps each; rs_ag
     # leaves the Adam moments sharded, which no longer matters here).  Every rank arms a watchdog first: the forms other
     # than the plain all-reduce have only ever run with one rank, and a hung collective cannot be interrupted in-process.

@@ -246,7 +246,14 @@ def test_l1_ssim_vs_oracle(ctx, shape):
         l1, ss, vr = go.l1_ssim(x[c], y[c], 0.8, 0.2)
         assert abs(sums[c, 0] / (H * W * 3) - l1) < 1e-6
         assert abs(sums[c, 1] / ((H - 10) * (W - 10) * 3) - ss) < 1e-5
-        np.testing.assert_allclose(v[c], vr, rtol=2e-3, atol=2e-8)
+        # v_render (round 3: one rtol = 2e-3 over everything): the error against the tensor's maximum, and element-wise
+        # over the elements that are not cancellation residue (above 1e-3 of the maximum).  Measured: 6e-7 / 1.5e-6
+        # (v_rcp_f32 instead of IEEE divisions is the largest contribution); bounds 2e-6 / 1e-5
+        scale = np.abs(vr).max()
+        err = np.abs(v[c] - vr)
+        big = np.abs(vr) > 1e-3 * scale
+        assert err.max() <= 2e-6 * scale
+        assert (err[big] / np.abs(vr[big])).max() <= 1e-5
 
 
 def test_adam_vs_oracle_and_torch(ctx):
