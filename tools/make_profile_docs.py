@@ -17,9 +17,9 @@ body = subprocess.run([sys.executable, "tools/rocprof_summary.py", glob.glob(f"{
 with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
     f.write(f"# {ROUND} ({note}; commit {commit}) -- rocprofv3 --kernel-trace --stats of the driver's bench command\n\n"
             "SYNTH-1M (1 M Gaussians, 8 x 1920x1080), 1 MI355X; the run also executes the alignment, matching and condensation benches.\n"
-            f"Command: `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_{tag}/trace -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline` (tools/profile_round3.sh; round 2: profile_round2.sh).\n"
+            f"Command: `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_{tag}/trace -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline` (tools/profile_round.sh <tag>).\n"
             f"bench.py's own line in the same (profiled) run: {line['value']:.2f} iters/s; stage_ms (HIP events inside bench.py): {stage}\n"
-            "(blend_bwd stage = k_blend_bwd + k_gather_vtile; loss = k_ssim_fused; sort / sort_depth = k_rs_hist + k_rs_scan_hist + k_rs_pass of radix_sort.hip; scan = k_scan_*.)\n"
+            "(blend_bwd stage = k_blend_bwd + k_gather_vtile; loss = k_ssim_fused; sort / sort_depth = k_rs_hist + k_rs_scan_hist + k_rs_pass of radix_sort.hip; scan = k_scan_chained; emit = k_isect_gather + k_isect_emit_d.)\n"
             f"(the bench line of the same build without the profiler is {tag}_bench_default.json.)\n\n")
     f.write("\n".join(body[2:44]) + "\n")
 shutil.copy(glob.glob(f"{T}/trace/runc/*_kernel_stats.csv")[0], f"profiles/{tag}_rocprof_kernel_stats.csv")
@@ -44,7 +44,7 @@ pmc = subprocess.run([sys.executable, "tools/pmc_summary.py"] + glob.glob(f"{T}/
                      capture_output=True, text=True).stdout
 with open(f"profiles/{tag}_pmc.md", "w") as f:
     f.write(f"# {ROUND} ({note}; commit {commit}) -- PMC counters per kernel launch (rocprofv3 --pmc, one counter set per run, --kernel-trace only)\n\n"
-            "Passes (tools/profile_round3.sh; round 2: profile_round2.sh): FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU | SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY,\n"
+            "Passes (tools/profile_round.sh <tag>): FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU | SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY,\n"
             "each around `python bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline` (SYNTH-1M, 1 MI355X).  FETCH_SIZE / WRITE_SIZE are KiB as reported.\n\n"
             "HBM traffic per launch as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 for 16 B/lane reads on gfx950, WRITE_SIZE as is):\n\n"
             "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic = (2 FETCH + WRITE) x 1024 B |\n|---|---|---|---|\n")
@@ -57,4 +57,5 @@ with open(f"profiles/{tag}_pmc.md", "w") as f:
 for t, k in rows[:12]:
     print(f"{k:28s} {t / 1e9:6.2f} GB")
 subprocess.run([sys.executable, "tools/pmc_summary.py", "--traffic-json", "profiles/pmc_traffic.json", commit] +
-               glob.glob(f"{T}/pmc_FETCH_SIZE/runc/*_counter_collection.csv") + glob.glob(f"{T}/pmc_WRITE_SIZE/runc/*_counter_collection.csv"))
+               glob.glob(f"{T}/pmc_FETCH_SIZE/runc/*_counter_collection.csv") + glob.glob(f"{T}/pmc_WRITE_SIZE/runc/*_counter_collection.csv") +
+               glob.glob(f"{T}/pmc_SQ1/runc/*_counter_collection.csv"))

@@ -40,7 +40,7 @@ def main(paths):
 STAGE_KERNELS = {
     "blend_bwd": ("k_blend_bwd", "k_gather_vtile"), "blend_fwd": ("k_blend_fwd",), "loss": ("k_ssim_wave", "k_ssim_fused"),
     "project": ("k_project_sh_fwd", "k_reg_reduce"), "project_bwd": ("k_project_sh_bwd",), "adam": ("k_adam",),
-    "emit": ("k_isect_emit_rects",), "offsets": ("k_isect_offsets32",), "scan": ("k_scan_reduce", "k_scan_blocksums", "k_scan_down"),
+    "emit": ("k_isect_gather", "k_isect_emit_d"), "offsets": ("k_isect_offsets32",), "scan": ("k_scan_chained",),
 }
 
 
@@ -67,9 +67,15 @@ def traffic_json(paths, out_path, commit, workload):
         b = sum(per_kernel[k]["bytes"] for k in ks if k in per_kernel)
         if b:
             stages[st] = b
+    # SQ_INSTS_VALU per launch and stage (its own pass): bench.py's roofline.valu_issue
+    valu = {}
+    for st, ks in STAGE_KERNELS.items():
+        v = sum(vals[k]["SQ_INSTS_VALU"] / len(calls[k]["SQ_INSTS_VALU"]) for k in ks if "SQ_INSTS_VALU" in vals.get(k, {}))
+        if v:
+            valu[st] = v
     rec = dict(commit=commit, csrc_fingerprint=bench.csrc_fingerprint(), workload=workload,
                source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2 x FETCH + WRITE) x 1024 per launch",
-               traffic_bytes_per_launch=stages, kernels=per_kernel)
+               traffic_bytes_per_launch=stages, valu_insts_per_launch=valu, kernels=per_kernel)
     json.dump(rec, open(out_path, "w"), indent=1)
     print("wrote", out_path, {k: round(v / 1e9, 3) for k, v in stages.items()})
 
