@@ -276,17 +276,24 @@ def valu_issue(per_stage_ms, N, views, W, H, world):
     insts = rec.get("valu_insts_per_launch")
     if not insts or rec.get("csrc_fingerprint") != csrc_fingerprint():
         return None
-    mix_ns = {"blend_bwd": 1.17, "blend_fwd": 1.30}
-    out = {"source": f"profiles/pmc_traffic.json (commit {rec.get('commit')}): SQ_INSTS_VALU per launch; kernel time: this "
-                     "run's HIP events; 1024 SIMDs at 2.4 GHz",
-           "opcode_mix_source": "tools/probe/valu_cost.hip issue costs x the instruction budgets of DESIGN.md section 4"}
+    share = rec.get("kernel_share_of_stage_time", {})
+    # opcode-mix-weighted: only where DESIGN.md section 4 derives the kernel's budget -- the backward: 1.17 ns per VALU
+    # instruction of its mix (phase 1: 23 VALU + exp + rcp per trip; phase 2: 34 plain + 20 DPP + 6 per four records)
+    mix_ns = {"blend_bwd": 1.17}
+    out = {"source": f"profiles/pmc_traffic.json (commit {rec.get('commit')}): SQ_INSTS_VALU per launch of k_blend_fwd_cells / "
+                     "k_blend_bwd; kernel time = this run's stage time (HIP events) x the kernel's share of the stage in the "
+                     "same profile (the backward stage also holds k_gather_vtile); 1024 SIMDs at 2.4 GHz",
+           "opcode_mix_source": "tools/probe/valu_cost.hip issue costs (add / mul / fmac 1.0-1.1 ns, 3-source fma 1.47, compares / "
+                                "selects / min / max / DPP 1.7-1.8, exp / rcp 3.4 ns per instruction and SIMD) x the "
+                                "instruction budget of DESIGN.md section 4"}
     for st in ("blend_fwd", "blend_bwd"):
         if st in insts and per_stage_ms.get(st):
-            t = per_stage_ms[st] * 1e-3
+            t = per_stage_ms[st] * 1e-3 * share.get(st, 1.0)
             per_simd = insts[st] / 1024.0
-            out[st] = {"valu_insts_per_launch": insts[st],
-                       "frac_at_2_cycles": per_simd * 2.0 / (CLOCK_GHZ * 1e9) / t,
-                       "frac_opcode_mix_weighted": per_simd * mix_ns[st] * 1e-9 / t}
+            out[st] = {"valu_insts_per_launch": insts[st], "kernel_ms": t * 1e3,
+                       "frac_at_2_cycles": per_simd * 2.0 / (CLOCK_GHZ * 1e9) / t}
+            if st in mix_ns:
+                out[st]["frac_opcode_mix_weighted"] = per_simd * mix_ns[st] * 1e-9 / t
     return out
 
 

@@ -38,7 +38,7 @@ def main(paths):
 
 # kernels of each stage of the fused train step (the stages bench.py times)
 STAGE_KERNELS = {
-    "blend_bwd": ("k_blend_bwd", "k_gather_vtile"), "blend_fwd": ("k_blend_fwd",), "loss": ("k_ssim_wave", "k_ssim_fused"),
+    "blend_bwd": ("k_blend_bwd", "k_gather_vtile"), "blend_fwd": ("k_blend_fwd_cells",), "loss": ("k_ssim_fused",),
     "project": ("k_project_sh_fwd", "k_reg_reduce"), "project_bwd": ("k_project_sh_bwd",), "adam": ("k_adam",),
     "emit": ("k_isect_gather", "k_isect_emit_d"), "offsets": ("k_isect_offsets32",), "scan": ("k_scan_chained",),
 }
@@ -53,10 +53,17 @@ def traffic_json(paths, out_path, commit, workload):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     vals = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(set))
+    dsum, dn = defaultdict(float), defaultdict(int)
     for p in paths:
         for r in csv.DictReader(open(p)):
             k = short(r["Kernel_Name"]).split("<")[0].strip()
             vals[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+        kt = p.replace("counter_collection.csv", "kernel_trace.csv")   # mean kernel durations of the same pass
+        if os.path.exists(kt):
+            for r in csv.DictReader(open(kt)):
+                k = short(r["Kernel_Name"]).split("<")[0].strip()
+                dsum[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); dn[k] += 1
+    dur = {k: dsum[k] / dn[k] for k in dsum}
     per_kernel = {}
     for k in vals:
         if "FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k]:
@@ -67,15 +74,19 @@ def traffic_json(paths, out_path, commit, workload):
         b = sum(per_kernel[k]["bytes"] for k in ks if k in per_kernel)
         if b:
             stages[st] = b
-    # SQ_INSTS_VALU per launch and stage (its own pass): bench.py's roofline.valu_issue
-    valu = {}
-    for st, ks in STAGE_KERNELS.items():
-        v = sum(vals[k]["SQ_INSTS_VALU"] / len(calls[k]["SQ_INSTS_VALU"]) for k in ks if "SQ_INSTS_VALU" in vals.get(k, {}))
-        if v:
-            valu[st] = v
+    # SQ_INSTS_VALU per launch of the blend kernels themselves (its own pass) and the kernel's share of its stage's time
+    # (kernel-trace durations of the same passes): bench.py's roofline.valu_issue
+    valu, share = {}, {}
+    for st, main in (("blend_fwd", "k_blend_fwd_cells"), ("blend_bwd", "k_blend_bwd")):
+        if "SQ_INSTS_VALU" in vals.get(main, {}):
+            valu[st] = vals[main]["SQ_INSTS_VALU"] / len(calls[main]["SQ_INSTS_VALU"])
+        tot = sum(dur.get(k, 0.0) for k in STAGE_KERNELS[st])
+        if tot > 0 and main in dur:
+            share[st] = dur[main] / tot
     rec = dict(commit=commit, csrc_fingerprint=bench.csrc_fingerprint(), workload=workload,
                source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2 x FETCH + WRITE) x 1024 per launch",
-               traffic_bytes_per_launch=stages, valu_insts_per_launch=valu, kernels=per_kernel)
+               traffic_bytes_per_launch=stages, valu_insts_per_launch=valu, kernel_share_of_stage_time=share,
+               kernels=per_kernel)
     json.dump(rec, open(out_path, "w"), indent=1)
     print("wrote", out_path, {k: round(v / 1e9, 3) for k, v in stages.items()})
 
