@@ -142,7 +142,7 @@ def cpu_baseline(args):
     }
 
 
-def align_bench(device, with_cpu=True, views=8):
+def align_bench(device, with_cpu=True, views=8, cpu_iters=(100, 40)):
     """Secondary metric "align sec": wall time of the reference's 500+200-iteration global alignment
     (starster/reconstruct.py:427,440) on a synthetic condensed problem -- HIP path vs the torch-CPU oracle
     (a port of the reference loop, validated against reference-generated goldens) on the host cores."""
@@ -169,14 +169,15 @@ def align_bench(device, with_cpu=True, views=8):
         cores = min(8, os.cpu_count() or 1)
         prev_threads = torch.get_num_threads()
         torch.set_num_threads(cores)
+        n1, n2 = cpu_iters
         t0 = time.perf_counter()
-        align_oracle.run(flat, niter1=100, niter2=40)
+        align_oracle.run(flat, niter1=n1, niter2=n2)
         cpu_sample = time.perf_counter() - t0
         torch.set_num_threads(prev_threads)
-        cpu_s = cpu_sample * 5.0
+        cpu_s = cpu_sample * (500.0 / n1)
         out.update(cpu_port_seconds=cpu_s, cpu_cores=cores, cpu_kind="port", cpu_sample_seconds=cpu_sample,
                    cpu_note="oracle/align_oracle.py (torch CPU autograd restatement of reconstruct.py:116-457), "
-                            f"{cores} intra-op threads, 100+40 iterations timed and scaled x5 to 500+200",
+                            f"{cores} intra-op threads, {n1}+{n2} iterations timed and scaled x{500 // n1} to 500+200",
                    speedup=cpu_s / hip_s)
     return out
 
@@ -719,9 +720,14 @@ def main():
         if world == 1 and not args.train_only:
             out["align"] = align_bench(device, with_cpu=not args.no_cpu_baseline)
             # the synthetic condensed problems at 2 / 8 / 32 views (HIP seconds for 500+200 iterations)
-            out["align"]["hip_seconds_by_views"] = {str(c): align_bench(device, with_cpu=False, views=c)["hip_seconds"]
-                                                    for c in (2, 32)}
+            # (the CPU port beside it at all three sizes; 2 and 32 views on a shorter sample, 50+20 iterations x 10)
+            with_cpu = not args.no_cpu_baseline
+            others = {c: align_bench(device, with_cpu=with_cpu, views=c, cpu_iters=(50, 20)) for c in (2, 32)}
+            out["align"]["hip_seconds_by_views"] = {str(c): r["hip_seconds"] for c, r in others.items()}
             out["align"]["hip_seconds_by_views"]["8"] = out["align"]["hip_seconds"]
+            if with_cpu:
+                out["align"]["cpu_port_seconds_by_views"] = {str(c): r["cpu_port_seconds"] for c, r in others.items()}
+                out["align"]["cpu_port_seconds_by_views"]["8"] = out["align"]["cpu_port_seconds"]
             out["matching"] = matching_bench(device, with_cpu=not args.no_cpu_baseline)
             out["condense"] = condense_bench(device, with_cpu=not args.no_cpu_baseline)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
