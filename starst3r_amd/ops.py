@@ -106,6 +106,15 @@ def project_sh(ctx, means, quats, scales, opacities, sh, viewmats, Ks, campos, W
     return splats, tiles
 
 
+def isect_scan(ctx, tiles):
+    """st3r_gs_isect_scan on its own: inclusive prefix sum of int32 counts -> (cum, total on the host)."""
+    cum = torch.empty_like(tiles)
+    n = C.c_int64(0)
+    _lib.check(_lib.lib().st3r_gs_isect_scan(ctx.handle, _stream(), tiles.numel(), _p(tiles, torch.int32),
+                                             _p(cum, torch.int32), C.byref(n)))
+    return cum, n.value
+
+
 def isect(ctx, splats, tiles, N, Cn, W, H):
     tw, th = tile_grid(W, H)
     cum = torch.empty_like(tiles)

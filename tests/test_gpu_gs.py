@@ -454,3 +454,65 @@ def test_train_gradients_are_bit_reproducible(ctx):
         out.append(grads)
     torch.cuda.synchronize()
     assert torch.equal(out[0].view(torch.int32), out[1].view(torch.int32))
+
+
+@pytest.mark.parametrize("case", ["wide", "flag64", "views16"])
+def test_fused_front_end_variants_equal_the_stage_path(ctx, case):
+    """The three shapes of the round-4 front end that SYNTH-1M does not reach: (wide) a tile grid of more than 255 tiles
+    a side -- 64-bit packed rectangles instead of 32-bit --; (flag64) the same 64-bit form forced on a small image together
+    with the backward's separate rectangle / slot-base gathers; (views16) sixteen views -- 64-bit level-1 keys and two
+    cameras per XCD queue of the emission kernels.  Fused gradients against the reference-exact stage path."""
+    from starst3r_amd import ops
+    from st3r_synth import synth
+    if case == "wide":
+        N, V, W, H = 3000, 2, 4112, 48          # 257 x 3 tiles
+    elif case == "views16":
+        N, V, W, H = 1500, 16, 96, 64
+    else:
+        N, V, W, H = 3000, 2, 160, 96
+    g, w2c, Ks = synth.make_scene(N, V, W, H, seed=21, scale_lo=0.01, scale_hi=0.06)
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    rgb, alpha, info = ops.rasterization(ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], vm, K, W, H)
+    assert info["isect_ids"].numel() > 1000
+    torch.manual_seed(3)
+    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
+    sums, v_rgb = ops.loss_l1_ssim(ctx, rgb, gt, 0.8, 0.2)
+    v_splats = ops.blend_bwd(ctx, info["_splats"], info["isect_offsets"], info["_flatten_ids_dense"], alpha,
+                             info["_last_ids"], v_rgb, None, info["_cum_tiles"], V, W, H)
+    ref = ops.project_sh_bwd(ctx, P["means"], P["quats"], P["scales"], P["opacities"], P["shN"], vm, K, campos, W, H,
+                             info["_splats"], v_splats, float(V), 0.01, 0.01)
+    grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+    if case == "flag64":
+        ops.set_debug(ctx, 64)
+    try:
+        st = ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_debug(ctx, 0)
+    assert st["n_isects_ref"] == info["isect_ids"].numel() and 0 < st["n_isects"] <= st["n_isects_ref"]
+    for which, full in ((8, rgb), (9, alpha)):
+        got = ops.peek(ctx, which, full.numel(), torch.float32)
+        assert torch.equal(got.view(torch.int32), full.reshape(-1).view(torch.int32))
+    assert float((grads - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_scan_status_generation_wraps_cleanly(ctx):
+    """The single-pass scan never clears its status words between launches: they carry a 14-bit launch generation, and
+    the host clears the block when the generation is about to repeat.  More launches than generations (a training run
+    of > 16 000 steps gets there), checked against numpy on both sides of the wrap, with sizes that make the tile count
+    -- and so the set of stale words -- vary."""
+    from starst3r_amd import ops
+    rng = np.random.default_rng(0)
+    sizes = [5, 4096, 4097, 30000, 123457]
+    data = {n: rng.integers(0, 7, n).astype(np.int32) for n in sizes}
+    dv = {n: torch.tensor(a, device="cuda:0") for n, a in data.items()}
+    want = {n: np.cumsum(a, dtype=np.int64) for n, a in data.items()}
+    for it in range(16500):
+        n = sizes[it % len(sizes)]
+        check_now = it < 10 or it % 997 == 0 or 16370 <= it <= 16400
+        cum, total = ops.isect_scan(ctx, dv[n])
+        if check_now:
+            assert total == int(want[n][-1]), (it, n)
+            assert np.array_equal(cum.cpu().numpy().astype(np.int64), want[n]), (it, n)
