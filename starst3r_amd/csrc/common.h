@@ -108,8 +108,7 @@ struct st3r_ctx {
                       // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 11 (2048): under a communicator
                       // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip)
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
-    uint32_t scan_gen, scan_ticket[2];   // chained kernels (gs_isect.hip): generation of the status words; tickets handed
-                                         // out so far from queue 0 and from each of the queues 1..7
+    uint32_t scan_gen;   // single-pass scan (gs_isect.hip): generation of its status words
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back
     // still in flight (event), and the capacity the in-flight step was given
     int64_t isect_hint, count_cap;

@@ -46,8 +46,9 @@ __device__ __forceinline__ int block_incl_scan(int v, int* total) {
 //   status word = flag (2 bits: 1 = tile sum, 2 = inclusive prefix) | launch generation (14 bits) | value (48 bits)
 // in ONE 64-bit word published and polled with relaxed agent-scope atomics: no fences, independent of XCD placement.
 // The generation makes words of earlier launches invisible, so the status array is never cleared between launches
-// (the host clears it when the generation wraps); tiles are handed out by a ticket counter that only ever grows
-// (the host passes the value it had before this launch), so every predecessor of a running tile is itself running.
+// (the host clears it when the generation wraps); tiles are handed out by a ticket counter, so every predecessor of a
+// running tile is itself running.  Two counters take turns (launch parity = generation & 1): a launch draws from one and
+// its first tile zeroes the other for the launch behind it -- no host-side mirror of device state, no clearing launch.
 //   RECTS  the input is the packed tile rectangle of every element (x0 | y0 << 16 | w << 32 | h << 48), its count w * h
 //   PACK   also leave, per element, exclusive prefix << 32 | x0 | y0 << 10 | w << 20 -- the one word the blend backward
 //          gathers per staged record (slot base + rectangle)
@@ -103,11 +104,15 @@ template <bool RECTS, bool PACK>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const int32_t* in, const void* __restrict__ rects,
                                                                int rect32, int64_t n, int32_t* out,
                                                                uint64_t* __restrict__ pack_out, u64* status,
-                                                               uint32_t* ticket, uint32_t ticket_base, uint32_t gen,
+                                                               uint32_t* ticket, uint32_t gen,
                                                                int32_t* __restrict__ total_out) {
     __shared__ int tile[SCAN_PAD(SCAN_TILE) + 1];
     __shared__ uint32_t s_tile;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    if (threadIdx.x == 0) {
+        s_tile = atomicAdd(ticket + (gen & 1u), 1u);
+        // (the other counter belongs to the previous launch -- finished -- and to the next one -- not started)
+        if (s_tile == 0) __hip_atomic_store(ticket + ((gen & 1u) ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const uint32_t tl = s_tile;
     const int64_t base0 = (int64_t)tl * SCAN_TILE;
@@ -176,9 +181,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const int32_t* in
     }
 }
 
-// Control block of the chained kernels (scan, emit) in one arena slot: eight ticket counters, four rotating totals,
-// then one status word per tile.  Nothing is cleared between launches (generation-stamped words, tickets that only
-// grow); the host clears the block when it is (re)allocated and when the 14-bit generation is about to repeat.
+// Control block of the single-pass scan in one arena slot: two ticket counters, four rotating totals, then one status
+// word per tile.  Nothing is cleared between launches (generation-stamped words, the ticket counters take turns); the host clears the block when it is (re)allocated and when the 14-bit generation is about
+// to repeat.
 struct ChainCtl { uint32_t* tickets; int32_t* total; u64* status; uint32_t gen; };
 static int chain_ctl(st3r_ctx* ctx, hipStream_t s, int64_t nwords, ChainCtl* c) {
     void* p; int grown = 0;
@@ -187,7 +192,6 @@ static int chain_ctl(st3r_ctx* ctx, hipStream_t s, int64_t nwords, ChainCtl* c) 
     if (grown || ctx->scan_gen >= 0x3FFF) {
         HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_SCAN_CHAIN], s));
         ctx->scan_gen = 0;
-        memset(ctx->scan_ticket, 0, sizeof(ctx->scan_ticket));
     }
     u64* ctl = (u64*)p;
     c->gen = ++ctx->scan_gen;
@@ -207,13 +211,12 @@ int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, con
     if (rc) return rc;
 #define SCAN_LAUNCH(R, P)                                                                                                \
     hipLaunchKernelGGL((k_scan_chained<R, P>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, in, rects, rect32, n, out, pack_out, \
-                       c.status, c.tickets, ctx->scan_ticket[0], c.gen, c.total)
+                       c.status, c.tickets, c.gen, c.total)
     if (rects && pack_out) SCAN_LAUNCH(true, true);
     else if (rects) SCAN_LAUNCH(true, false);
     else SCAN_LAUNCH(false, false);
 #undef SCAN_LAUNCH
     LAUNCH_CHECK();
-    ctx->scan_ticket[0] += (uint32_t)ntiles;   // every launched workgroup takes exactly one ticket
     if (total_dev) *total_dev = c.total;
     return ST3R_OK;
 }

@@ -129,7 +129,8 @@ def test_range_exchange_of_a_chunked_call_equals_the_allreduce_result():
     chunks to the caller's buffer and then all-reduced that buffer alone: the first chunk's gradients were lost.  Every
     chunk now adds to the staged ranges and the rank takes part in the same K range collectives as an unchunked rank."""
     from starst3r_amd import dist as sdist, ops
-    ctx, P, w2c, Ks, gt, W, H = _problem()
+    _, P, w2c, Ks, gt, W, H = _problem()
+    ctx = ops.Context("cuda:0")          # a private context: the chunk count of a chunked call sticks to its context
     sdist.attach_native_comm(ctx)
     try:
         A = {k: t.clone() for k, t in P.items()}
@@ -147,9 +148,8 @@ def test_range_exchange_of_a_chunked_call_equals_the_allreduce_result():
             assert torch.allclose(B[k], A[k], rtol=0, atol=2e-6), k          # one Adam step of lr 1e-3 on equal gradients
         assert torch.allclose(m_b, m_a, rtol=0, atol=2e-7 * scale)
     finally:
-        ops.set_debug(ctx, 0)
-        ops.set_exchange(ctx, "allreduce")
         sdist.detach_native_comm(ctx)
+        ctx.close()
 
 
 @pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag"])
