@@ -176,6 +176,17 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
 #ifndef FLW
 #define FLW 64                        // output columns of a fused strip
 #endif
+// Row loop of the fused kernel: unrolled by SSIM_U = 12 with 12-slot rings (one slot more than the 11 rows a window
+// needs), so that both the ring slot of a row and the slot of the SSIM_PD-deep load queue (SSIM_PD divides 12) are
+// compile-time constants; the loads of a row are unconditional (clamped addresses).  Round 4, measured: the row loop
+// without any arithmetic takes 0.34 ms WITH its global loads and 0.12 ms without them -- but the whole kernel takes 0.51 ms
+// without them and 0.52 with: the arithmetic hides the loads, one row of slack is enough (SSIM_PD = 1; deeper queues only
+// cost registers -- and hipcc waits for every load in flight at the commit anyway: 0.59 / 0.60 ms at depth 2 / 3).
+// What the restructuring did buy is the branch-free addressing: 0.58 -> 0.52 ms.
+#ifndef SSIM_PD
+#define SSIM_PD 1
+#endif
+#define SSIM_U 12
 #define HALO2 (2 * HALO)
 #define DCOLS (FLW + 2 * HALO)        // columns of D a workgroup computes (74)
 #define FT1 ((DCOLS * 3 + 63) / 64 * 64)   // forward threads, whole waves (256)
@@ -206,47 +217,52 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
         const bool active = t < DCOLS * 3;
         const int jd = j0 - HALO + col;
         const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
-        float pfx[NPF2], pfy[NPF2];
-        auto prefetch = [&](int r) {
-            const int i = i0 - HALO2 + r;
+        float qx[SSIM_PD][NPF2], qy[SSIM_PD][NPF2];   // rows r+1 .. r+SSIM_PD at the top of iteration r; row q in slot q % SSIM_PD
+        // The loads are UNCONDITIONAL (row and column clamped into the image): a load behind a branch makes the compiler
+        // wait for every load in flight at the next join, which undoes the queue.  What a clamped address delivers outside
+        // the image is never used: windows of interior pixels lie inside the image, everything else is forced to zero.
+        int eoff[NPF2];   // element offset inside an image row (column clamped), constant over the rows
+#pragma unroll
+        for (int n = 0; n < NPF2; ++n) {
+            const int e = min(t + n * FT1, SEG2 - 1);
+            const int jj = min(max(j0 - HALO2 + e / 3, 0), W - 1);
+            eoff[n] = jj * 3 + (e - (e / 3) * 3);
+        }
+        auto fetch_row = [&](int r, float (&vxs)[NPF2], float (&vys)[NPF2]) {
+            const int i = min(max(i0 - HALO2 + r, 0), H - 1);
+#pragma unroll
+            for (int n = 0; n < NPF2; ++n) {
+                const int64_t q = (int64_t)i * W * 3 + eoff[n];
+                vxs[n] = xr[q]; vys[n] = yr[q];
+            }
+        };
+        auto commit_from = [&](int b, const float (&vxs)[NPF2], const float (&vys)[NPF2]) {
 #pragma unroll
             for (int n = 0; n < NPF2; ++n) {
                 const int e = t + n * FT1;
-                const int jj = j0 - HALO2 + e / 3;
-                float vx = 0.f, vy = 0.f;
-                if (r < nrows && i >= 0 && i < H && e < SEG2 && jj >= 0 && jj < W) {
-                    const int64_t q = ((int64_t)i * W + j0 - HALO2) * 3 + e;
-                    vx = xr[q]; vy = yr[q];
-                }
-                pfx[n] = vx; pfy[n] = vy;
+                if (e < SEG2) { sx[b][e] = vxs[n]; sy[b][e] = vys[n]; }
             }
         };
-        auto commit = [&](int b) {
+        float ring[SSIM_U][5];
 #pragma unroll
-            for (int n = 0; n < NPF2; ++n) {
-                const int e = t + n * FT1;
-                if (e < SEG2) { sx[b][e] = pfx[n]; sy[b][e] = pfy[n]; }
-            }
-        };
-        float ring[KS][5];
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < SSIM_U; ++s)
 #pragma unroll
             for (int m = 0; m < 5; ++m) ring[s][m] = 0.f;
         const bool own_col = (col >= HALO) && (col < HALO + FLW) && (jd < W);
-        prefetch(0);
-        commit(0);
-        prefetch(1);
-        __syncthreads();
-        for (int rb = 0; rb <= nrows; rb += KS) {
+        fetch_row(0, qx[0], qy[0]);
+        commit_from(0, qx[0], qy[0]);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+        for (int d = 1; d <= SSIM_PD; ++d) fetch_row(d, qx[d % SSIM_PD], qy[d % SSIM_PD]);   // rows 1 .. SSIM_PD are under way
+        __syncthreads();
+        for (int rb = 0; rb <= nrows; rb += SSIM_U) {
+#pragma unroll
+            for (int s = 0; s < SSIM_U; ++s) {
                 const int r = rb + s;
                 if (r <= nrows) {
                     if (r < nrows) {
                         const int b = r & 1;
-                        commit(b ^ 1);     // row r+1 (prefetched one iteration ago)
-                        prefetch(r + 2);
+                        commit_from(b ^ 1, qx[(s + 1) % SSIM_PD], qy[(s + 1) % SSIM_PD]);   // row r+1, requested SSIM_PD iterations ago
+                        fetch_row(r + 1 + SSIM_PD, qx[(s + 1) % SSIM_PD], qy[(s + 1) % SSIM_PD]);
                         if (active) {
                             const float* px = &sx[b][col * 3 + ch];
                             const float* py = &sy[b][col * 3 + ch];
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                                     float mx = 0, my = 0, exx = 0, eyy = 0, exy = 0;
 #pragma unroll
                                     for (int k = 0; k < KS; ++k) {
-                                        const int slot = (s + 1 + k) % KS;  // input row r-10+k
+                                        const int slot = (s + SSIM_U - 10 + k) % SSIM_U;  // input row r-10+k
                                         const float w = win.w[k];
                                         mx += w * ring[slot][0]; my += w * ring[slot][1]; exx += w * ring[slot][2];
                                         eyy += w * ring[slot][3]; exy += w * ring[slot][4];
@@ -303,27 +319,30 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
         const int t = threadIdx.x - FT1;
         const int col = t / 3, ch = t - col * 3;
         const int j = t < FLW * 3 ? j0 + col : W;   // threads past the strip (whole-wave padding) only keep the barriers
-        float ring[KS][3];
+        float ring[SSIM_U][3];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
-        float xn = 0.f, yn = 0.f;
+        for (int s = 0; s < SSIM_U; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
+        // x, y of this thread's output pixel: iteration r writes image row i0 + r - 21; requested SSIM_PD iterations ahead
+        // (slot r % SSIM_PD), like the forward waves' rows
+        float bx[SSIM_PD], by[SSIM_PD];
+        const int jc = min(j, W - 1) * 3 + ch;   // (unconditional, clamped loads: see the forward waves)
+        auto fetch_px = [&](int r_use, float& vx, float& vy) {
+            const int ion = min(max(i0 + r_use - 1 - 2 * HALO2, 0), H - 1);
+            const int64_t qn = (int64_t)ion * W * 3 + jc;
+            vx = xr[qn]; vy = yr[qn];
+        };
+#pragma unroll
+        for (int d = 0; d < SSIM_PD; ++d) fetch_px(d, bx[d], by[d]);
         __syncthreads();
-        for (int rb = 0; rb <= nrows; rb += KS) {
+        for (int rb = 0; rb <= nrows; rb += SSIM_U) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < SSIM_U; ++s) {
                 const int r = rb + s;
                 if (r <= nrows) {
                     const int rp = r - 1;                 // the forward iteration whose D row is consumed now
-                    const int sp = (s + KS - 1) % KS;     // its ring slot (compile time)
-                    // x, y of the output pixel of this iteration were requested one iteration ago
-                    const float x = xn, y = yn;
-                    {
-                        const int ion = i0 + rp + 1 - 2 * HALO2;  // next iteration's output row
-                        if (ion >= i0 && ion < H && j < W) {
-                            const int64_t qn = ((int64_t)ion * W + j) * 3 + ch;
-                            xn = xr[qn]; yn = yr[qn];
-                        }
-                    }
+                    const int sp = (s + SSIM_U - 1) % SSIM_U;     // its ring slot (compile time)
+                    const float x = bx[s % SSIM_PD], y = by[s % SSIM_PD];
+                    fetch_px(r + SSIM_PD, bx[s % SSIM_PD], by[s % SSIM_PD]);
                     if (rp >= 2 * HALO && j < W) {
                         const float* pd = &sd[rp & 1][col * 9 + ch * 3];
                         float h0 = 0, h1 = 0, h2 = 0;
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                                 float a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
                                 for (int k = 0; k < KS; ++k) {
-                                    const int slot = (sp + 1 + k) % KS;
+                                    const int slot = (sp + SSIM_U - 10 + k) % SSIM_U;
                                     const float w = win.w[k];
                                     a0 += w * ring[slot][0]; a1 += w * ring[slot][1]; a2 += w * ring[slot][2];
                                 }
