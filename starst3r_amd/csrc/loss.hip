@@ -195,7 +195,8 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
 #define SEG2 ((FLW + 2 * HALO2) * 3)  // floats per staged row segment of an image (252)
 #define NPF2 ((SEG2 + FT1 - 1) / FT1) // staged elements per forward thread and row
 
-__global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const float* __restrict__ render,
+// (five waves per SIMD = two workgroups of 7 waves per CU: at most 96 VGPRs; the forward threads' five 12-row rings are 60)
+__global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k_ssim_fused(int LH, int H, int W, const float* __restrict__ render,
                                                     const float* __restrict__ gt, Win win, float k_l1, float k_ss,
                                                     double* __restrict__ sums, float* __restrict__ v_render) {
     __shared__ float sx[2][SEG2];
@@ -221,20 +222,21 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
         // The loads are UNCONDITIONAL (row and column clamped into the image): a load behind a branch makes the compiler
         // wait for every load in flight at the next join, which undoes the queue.  What a clamped address delivers outside
         // the image is never used: windows of interior pixels lie inside the image, everything else is forced to zero.
-        int eoff[NPF2];   // element offset inside an image row (column clamped), constant over the rows
+        unsigned eoff[NPF2];   // element offset inside an image row (column clamped), constant over the rows
 #pragma unroll
         for (int n = 0; n < NPF2; ++n) {
             const int e = min(t + n * FT1, SEG2 - 1);
             const int jj = min(max(j0 - HALO2 + e / 3, 0), W - 1);
-            eoff[n] = jj * 3 + (e - (e / 3) * 3);
+            eoff[n] = (unsigned)(jj * 3 + (e - (e / 3) * 3));
         }
         auto fetch_row = [&](int r, float (&vxs)[NPF2], float (&vys)[NPF2]) {
+            // (the row is uniform over the workgroup: a scalar base pointer per row + one 32-bit offset per thread -- no
+            // 64-bit address arithmetic on the vector unit)
             const int i = min(max(i0 - HALO2 + r, 0), H - 1);
+            const float* xrow = xr + (int64_t)i * (W * 3);
+            const float* yrow = yr + (int64_t)i * (W * 3);
 #pragma unroll
-            for (int n = 0; n < NPF2; ++n) {
-                const int64_t q = (int64_t)i * W * 3 + eoff[n];
-                vxs[n] = xr[q]; vys[n] = yr[q];
-            }
+            for (int n = 0; n < NPF2; ++n) { vxs[n] = xrow[eoff[n]]; vys[n] = yrow[eoff[n]]; }
         };
         auto commit_from = [&](int b, const float (&vxs)[NPF2], const float (&vys)[NPF2]) {
 #pragma unroll
@@ -266,9 +268,15 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                         if (active) {
                             const float* px = &sx[b][col * 3 + ch];
                             const float* py = &sy[b][col * 3 + ch];
-                            float h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+                            // (the first tap initialises the sums: "0 + w x" would cost a move and a multiply-add where a
+                            // multiply does -- sixteen instructions per image row over the four convolutions of this kernel)
+                            float h0, h1, h2, h3, h4;
+                            {
+                                const float xx = px[0], yy = py[0], w = win.w[0];
+                                h0 = w * xx; h1 = w * yy; h2 = h0 * xx; h3 = h1 * yy; h4 = h0 * yy;
+                            }
 #pragma unroll
-                            for (int k = 0; k < KS; ++k) {
+                            for (int k = 1; k < KS; ++k) {
                                 const float xx = px[k * 3], yy = py[k * 3], w = win.w[k];
                                 const float wx = w * xx, wy = w * yy;
                                 h0 += wx; h1 += wy; h2 += wx * xx; h3 += wy * yy; h4 += wx * yy;
@@ -281,9 +289,15 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                                 float d0 = 0.f, d1 = 0.f, d2 = 0.f;
                                 const bool interior = (id >= HALO) && (id < H - HALO) && (jd >= HALO) && (jd < W - HALO);
                                 if (interior) {
-                                    float mx = 0, my = 0, exx = 0, eyy = 0, exy = 0;
+                                    float mx, my, exx, eyy, exy;
+                                    {
+                                        const int slot = (s + SSIM_U - 10) % SSIM_U;
+                                        const float w = win.w[0];
+                                        mx = w * ring[slot][0]; my = w * ring[slot][1]; exx = w * ring[slot][2];
+                                        eyy = w * ring[slot][3]; exy = w * ring[slot][4];
+                                    }
 #pragma unroll
-                                    for (int k = 0; k < KS; ++k) {
+                                    for (int k = 1; k < KS; ++k) {
                                         const int slot = (s + SSIM_U - 10 + k) % SSIM_U;  // input row r-10+k
                                         const float w = win.w[k];
                                         mx += w * ring[slot][0]; my += w * ring[slot][1]; exx += w * ring[slot][2];
@@ -325,11 +339,10 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
         // x, y of this thread's output pixel: iteration r writes image row i0 + r - 21; requested SSIM_PD iterations ahead
         // (slot r % SSIM_PD), like the forward waves' rows
         float bx[SSIM_PD], by[SSIM_PD];
-        const int jc = min(j, W - 1) * 3 + ch;   // (unconditional, clamped loads: see the forward waves)
+        const unsigned jc = (unsigned)(min(j, W - 1) * 3 + ch);   // (unconditional, clamped loads: see the forward waves)
         auto fetch_px = [&](int r_use, float& vx, float& vy) {
             const int ion = min(max(i0 + r_use - 1 - 2 * HALO2, 0), H - 1);
-            const int64_t qn = (int64_t)ion * W * 3 + jc;
-            vx = xr[qn]; vy = yr[qn];
+            vx = (xr + (int64_t)ion * (W * 3))[jc]; vy = (yr + (int64_t)ion * (W * 3))[jc];
         };
 #pragma unroll
         for (int d = 0; d < SSIM_PD; ++d) fetch_px(d, bx[d], by[d]);
@@ -345,9 +358,9 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                     fetch_px(r + SSIM_PD, bx[s % SSIM_PD], by[s % SSIM_PD]);
                     if (rp >= 2 * HALO && j < W) {
                         const float* pd = &sd[rp & 1][col * 9 + ch * 3];
-                        float h0 = 0, h1 = 0, h2 = 0;
+                        float h0 = win.w[0] * pd[0], h1 = win.w[0] * pd[1], h2 = win.w[0] * pd[2];
 #pragma unroll
-                        for (int k = 0; k < KS; ++k) {
+                        for (int k = 1; k < KS; ++k) {
                             const float w = win.w[k];
                             h0 += w * pd[k * 9]; h1 += w * pd[k * 9 + 1]; h2 += w * pd[k * 9 + 2];
                         }
@@ -355,16 +368,20 @@ __global__ __launch_bounds__(FT2) void k_ssim_fused(int LH, int H, int W, const 
                         if (rp >= 2 * HALO2) {
                             const int io = i0 + rp - 2 * HALO2;
                             if (io < H && j < W) {
-                                float a0 = 0, a1 = 0, a2 = 0;
+                                float a0, a1, a2;
+                                {
+                                    const int slot = (sp + SSIM_U - 10) % SSIM_U;
+                                    a0 = win.w[0] * ring[slot][0]; a1 = win.w[0] * ring[slot][1]; a2 = win.w[0] * ring[slot][2];
+                                }
 #pragma unroll
-                                for (int k = 0; k < KS; ++k) {
+                                for (int k = 1; k < KS; ++k) {
                                     const int slot = (sp + SSIM_U - 10 + k) % SSIM_U;
                                     const float w = win.w[k];
                                     a0 += w * ring[slot][0]; a1 += w * ring[slot][1]; a2 += w * ring[slot][2];
                                 }
-                                const int64_t q = (((int64_t)cam * H + io) * W + j) * 3 + ch;
+                                float* vrow = v_render + ((int64_t)cam * H + io) * (W * 3);   // (uniform row pointer)
                                 const float sgn = (x > y) ? 1.0f : ((x < y) ? -1.0f : 0.0f);
-                                v_render[q] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
+                                vrow[(unsigned)(j * 3 + ch)] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
                             }
                         }
                     }
