@@ -481,7 +481,11 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
         float my_op = 0.f, my_ca = 0.f, my_cbb = 0.f, my_cc = 0.f;
         if ((int)threadIdx.x < bsz) {
             const int t = threadIdx.x;
+#ifdef BWD_ABL_SEQ_STAGE   // ablation: no dependent gather (wrong records, same instructions)
+            const int64_t my_id = (bs + t) >> 2;
+#else
             const int64_t my_id = flat[bs + t];
+#endif
             const float4 a = splats[my_id * 3 + 0];   // x y opacity conic.a
             const float4 b = splats[my_id * 3 + 1];   // conic.b conic.c r g
             const float4 c = splats[my_id * 3 + 2];   // b depth radius 0
