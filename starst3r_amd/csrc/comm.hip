@@ -278,12 +278,19 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
     char first_error[512];
     if (rc_local) snprintf(first_error, sizeof(first_error), "%s", st3r_last_error());
     // ---- the status word, reduced with the gradients
+    const int64_t total = (int64_t)23 * N;
     HIP_TRY(hipMemsetAsync(counts + PEER_WORD, rc_local ? 1 : 0, sizeof(int32_t), s));
+    // (plain all-reduce form: the status word and the gradients travel as ONE grouped launch)
+    const bool grouped = mode == ST3R_EXCHANGE_ALLREDUCE || (K == 1 && mode == ST3R_EXCHANGE_RANGES);
+    if (grouped) RCCL_TRY(api, api->group_start());
     RCCL_TRY(api, api->all_reduce(counts + PEER_WORD, counts + PEER_WORD, 1, ncclInt32, ncclMax, comm, s));
+    if (grouped) {
+        RCCL_TRY(api, api->all_reduce(grads, grads, (size_t)total, ncclFloat32, ncclSum, comm, s));
+        RCCL_TRY(api, api->group_end());
+    }
     HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + PEER_PINNED), counts + PEER_WORD, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(ctx->peer_event, s));
     ctx->peer_pending = 1;
-    const int64_t total = (int64_t)23 * N;
     const int32_t* guard; uint32_t count_cap;
     st3r_adam_guard(ctx, &guard, &count_cap);
     rc = ST3R_OK;
@@ -337,8 +344,7 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
                 rc = st3r_params_from_stage_impl(s, N, means, quats, scales, opacities, sh, sh_stride, pstage, r * q,
                                                  (r + 1) * q, tail0, guard, count_cap);
         }
-    } else {
-        RCCL_TRY(api, api->all_reduce(grads, grads, (size_t)total, ncclFloat32, ncclSum, comm, s));
+    } else {   // (the gradients were all-reduced together with the status word above)
         st3r_prof_begin(ctx, s, STG_ADAM);
         rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
                             guard, count_cap, -1, -1, 0, -1, nullptr, nullptr, nullptr);
