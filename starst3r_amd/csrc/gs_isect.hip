@@ -458,8 +458,8 @@ int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, 
 //                    rectangles: 4 MB at 1 M Gaussians in the 32-bit form;
 //   k_isect_emit     the same workgroup shape: scans its pairs' tile counts (rectangle areas), finds its first output
 //                    position as  cum[c N - 1]  (pair ids are camera-major too: the first record of camera c sits at the
-//                    pair-order scan's value in front of it)  +  the tile counts of the camera's earlier workgroups (at
-//                    most a few KB of sequential reads), and emits.  Work is dealt by OUTPUT element, not by pair:
+//                    pair-order scan's value in front of it)  +  the tile counts of the camera's earlier workgroups
+//                    (k_isect_wg_scan: one tiny launch between the two), and emits.  Work is dealt by OUTPUT element, not by pair:
 //                    every pair with tiles marks its first output with its index, a prefix maximum over the chunk
 //                    spreads the marks to the right (thread t scans 16 consecutive entries in registers, the thread
 //                    maxima meet in one workgroup scan), then the outputs are dealt to the threads with a stride of 256
@@ -518,9 +518,24 @@ __global__ __launch_bounds__(256) void k_isect_gather(int N, int C, int bpc, con
     if (t == 0) wg_tiles[c * bpc + k] = total;   // < 2^30: 1024 rectangles of < 2^20 tiles
 }
 
+// per camera: exclusive prefix of the workgroup tile counts (one workgroup per camera walks its bpc entries 256 at a time;
+// 977 entries at 1 M Gaussians) -- the emission then reads ONE base per workgroup, whatever the number of Gaussians
+__global__ __launch_bounds__(256) void k_isect_wg_scan(int bpc, const int32_t* __restrict__ wg_tiles,
+                                                       long long* __restrict__ wg_base) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    long long carry = 0;
+    for (int b0 = 0; b0 < bpc; b0 += 256) {
+        const int v = b0 + t < bpc ? wg_tiles[c * bpc + b0 + t] : 0;
+        int tot;
+        const int inc = block_incl_scan(v, &tot);
+        if (b0 + t < bpc) wg_base[c * bpc + b0 + t] = carry + (long long)(inc - v);
+        carry += tot;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, const int32_t* __restrict__ perm,
                                                       const void* __restrict__ rects_d, int rect32,
-                                                      const int32_t* __restrict__ wg_tiles,
+                                                      const long long* __restrict__ wg_base,
                                                       const int32_t* __restrict__ cum, int tile_w, int tile_h,
                                                       uint32_t* __restrict__ tile_keys, int32_t* __restrict__ vals,
                                                       int64_t cap) {
@@ -530,15 +545,11 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     __shared__ int32_t s_pid[EP];
     __shared__ uint16_t s_own[ECH];   // owner (pair index + 1) of every output of the current emission chunk
     __shared__ unsigned s_wmax[4];
-    __shared__ long long s_wsum[4];
     int c, k;
     emit_item(C, bpc, &c, &k);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t first = (int64_t)c * N + (int64_t)k * EP;
     const int np = (int)min((int64_t)EP, (int64_t)(c + 1) * N - first);
-    // first output position: the camera's first record + the tile counts of the camera's earlier workgroups
-    long long before = 0;
-    for (int j = t; j < k; j += 256) before += wg_tiles[c * bpc + j];
     int cnt[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -552,9 +563,6 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
         s_pid[e] = pid; s_org[e] = org; s_w[e] = rw;
         cnt[j] = (int)(rw * rh);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
-    if (lane == 0) s_wsum[w] = before;
     // scan in pair order: EPT block scans of 256 consecutive pairs, the carry in a register
     int carry = 0;
 #pragma unroll
@@ -567,8 +575,8 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     const int total = carry;
     __syncthreads();
     // (a true count above 2^31 wraps the int32 pair-order scan: the position test below keeps such writes out)
-    const long long base = (long long)(uint32_t)(c == 0 ? 0 : cum[(int64_t)c * N - 1]) +
-                           ((s_wsum[0] + s_wsum[1]) + (s_wsum[2] + s_wsum[3]));
+    // first output position: the camera's first record + the tile counts of the camera's earlier workgroups (k_isect_wg_scan)
+    const long long base = (long long)(uint32_t)(c == 0 ? 0 : cum[(int64_t)c * N - 1]) + wg_base[c * bpc + k];
     const uint32_t key0 = (uint32_t)c * (uint32_t)(tile_w * tile_h);
     int carry_owner = 0;   // owner (+1) of the last output of the previous chunk (uniform)
     for (int c0 = 0; c0 < total; c0 += ECH) {
@@ -649,11 +657,13 @@ int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const
     int rc = st3r_arena_get(ctx, SLOT_RECTS_D, (rect32 ? sizeof(uint32_t) : sizeof(uint64_t)) * (size_t)n_pairs, &p);
     if (rc) return rc;
     void* rects_d = p;
-    rc = st3r_arena_get(ctx, SLOT_CUM_D, sizeof(int32_t) * (size_t)grid, &p);
+    rc = st3r_arena_get(ctx, SLOT_CUM_D, (sizeof(long long) + sizeof(int32_t)) * (size_t)grid, &p);
     if (rc) return rc;
-    int32_t* wg_tiles = (int32_t*)p;
+    long long* wg_base = (long long*)p;
+    int32_t* wg_tiles = (int32_t*)(wg_base + grid);
     hipLaunchKernelGGL(k_isect_gather, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects, rect32, rects_d, wg_tiles);
-    hipLaunchKernelGGL(k_isect_emit_d, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects_d, rect32, wg_tiles, cum, tile_w,
+    hipLaunchKernelGGL(k_isect_wg_scan, dim3(C), dim3(256), 0, s, bpc, wg_tiles, wg_base);
+    hipLaunchKernelGGL(k_isect_emit_d, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects_d, rect32, wg_base, cum, tile_w,
                        tile_h, tile_keys, vals, cap);
     LAUNCH_CHECK();
     return ST3R_OK;

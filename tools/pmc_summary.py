@@ -40,7 +40,7 @@ def main(paths):
 STAGE_KERNELS = {
     "blend_bwd": ("k_blend_bwd", "k_gather_vtile"), "blend_fwd": ("k_blend_fwd_cells",), "loss": ("k_ssim_fused",),
     "project": ("k_project_sh_fwd", "k_reg_reduce"), "project_bwd": ("k_project_sh_bwd",), "adam": ("k_adam",),
-    "emit": ("k_isect_gather", "k_isect_emit_d"), "offsets": ("k_isect_offsets32",), "scan": ("k_scan_chained",),
+    "emit": ("k_isect_gather", "k_isect_wg_scan", "k_isect_emit_d"), "offsets": ("k_isect_offsets32",), "scan": ("k_scan_chained",),
 }
 
 
