@@ -1,8 +1,9 @@
 // K2/K3/K5: tile-intersection bookkeeping.
 //   scan    -- inclusive prefix sum of tiles_per_gauss (gsplat: torch.cumsum between the two
-//              isect_tiles passes), three-phase: per-block reduce, one-block scan of the
-//              block sums, per-block downsweep with wave64 prefix scans;
-//   emit    -- gsplat isect_tiles pass 2: one (key,value) per touched tile;
+//              isect_tiles passes): one single-pass kernel with decoupled look-back (k_scan_chained);
+//   emit    -- gsplat isect_tiles pass 2: one (key,value) per touched tile (k_isect_emit: the stage API's
+//              64-bit keys in pair order; k_isect_gather / k_isect_wg_scan / k_isect_emit_d: the fused
+//              path's 32-bit (camera, tile) keys in (camera, depth) order);
 //   offsets -- gsplat isect_offset_encode.
 // All integer work: results are bit-exact against oracle/gs_oracle.c.
 #include "common.h"
@@ -39,10 +40,10 @@ __device__ __forceinline__ int block_incl_scan(int v, int* total) {
 }
 
 // Single-pass prefix sum (decoupled look-back, Merrill & Garland 2016, restated for wave64): a workgroup owns a tile of
-// 4096 consecutive elements, publishes the tile's sum as soon as it is known, and wave 0 adds up the published sums of
-// its predecessors -- 64 status words per trip, one per lane -- back to the nearest tile whose inclusive prefix is
-// already known.  Round 3 ran three launches per scan (reduce, one workgroup over the tile sums, downsweep) and read the
-// input twice.
+// 4096 consecutive elements, publishes the tile's sum as soon as it is known, and adds up the published sums of its
+// predecessors -- 256 status words per trip, one per thread (chain_lookback256) -- back to the nearest tile whose
+// inclusive prefix is already known.  Round 3 ran three launches per scan (reduce, one workgroup over the tile sums,
+// downsweep) and read the input twice.
 //   status word = flag (2 bits: 1 = tile sum, 2 = inclusive prefix) | launch generation (14 bits) | value (48 bits)
 // in ONE 64-bit word published and polled with relaxed agent-scope atomics: no fences, independent of XCD placement.
 // The generation makes words of earlier launches invisible, so the status array is never cleared between launches
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const int32_t* in
 }
 
 // Control block of the single-pass scan in one arena slot: two ticket counters, four rotating totals, then one status
-// word per tile.  Nothing is cleared between launches (generation-stamped words, the ticket counters take turns); the host clears the block when it is (re)allocated and when the 14-bit generation is about
-// to repeat.
+// word per tile.  Nothing is cleared between launches (generation-stamped words, the ticket counters take turns); the
+// host clears the block when it is (re)allocated and when the 14-bit generation is about to repeat.
 struct ChainCtl { uint32_t* tickets; int32_t* total; u64* status; uint32_t gen; };
 static int chain_ctl(st3r_ctx* ctx, hipStream_t s, int64_t nwords, ChainCtl* c) {
     void* p; int grown = 0;
