@@ -91,14 +91,15 @@ def test_backward_of_one_view_of_synth_1m_against_the_c_oracle(synth_1m_view):
         med, p99 = float(np.median(rel)), float(np.percentile(rel, 99))
         dist[name] = (float(err), med, p99, int(big.sum()))
         assert err < tol and med <= med_bound and p99 <= p99_bound, (name, err, med, p99)
-    # the regular-scene bounds of test_backward_vs_oracle: 2e-4 / 1e-3 of the maximum, median 2e-6, p99 1e-4
+    # 2e-4 of the tensor's maximum for pairs AND parameters (measured at this size: <= 5.6e-5; round 3's parameter bound was
+    # 1e-3), median 2e-6 and p99 1e-4 of the element-wise relative error as on the regular small scenes
     close(vs[:, 0:2], pk["v_means2d"], "v_means2d", 2e-4, 2e-6, 1e-4)
     close(vs[:, 2], pk["v_opacities"], "v_opacities", 2e-4, 2e-6, 1e-4)
     close(vs[:, 3:6], pk["v_conics"], "v_conics", 2e-4, 2e-6, 1e-4)
     close(vs[:, 6:9], pk["v_colors"], "v_colors", 2e-4, 2e-6, 1e-4)
     G = {k: v.cpu().numpy() for k, v in ops.split_grads(grads, N).items()}
     for k in ("means", "quats", "scales", "opacities", "sh"):
-        close(G[k], ref[k], k, 1e-3, 2e-6, 1e-4)
+        close(G[k], ref[k], k, 2e-4, 2e-6, 1e-4)
     print("SYNTH-1M view, gradient error (max / tensor max, median rel, p99 rel, elements):",
           {k: (f"{a:.1e}", f"{b:.1e}", f"{c:.1e}", n) for k, (a, b, c, n) in dist.items()})
 

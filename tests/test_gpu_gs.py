@@ -186,13 +186,20 @@ def test_backward_vs_oracle(ctx, name):
     pk = go_grads["packed"]
 
     dist = {}
+    maxerr = {}
     # measured (round 3): regular scenes median <= 7e-7, p99 <= 4e-5; stress scenes median <= 4e-5, p99 <= 5e-3
     MED_BOUND, P99_BOUND = (1e-4, 1e-2) if name.startswith("fuzz") else (2e-6, 1e-4)
 
-    def close(a, b, name, tol=2e-4):
+    # bounds against the tensor's maximum, set from the measured errors (round 4: regular scenes <= 1.5e-5 per pair and
+    # <= 1.0e-5 per parameter, stress scenes <= 6.7e-5 and <= 1.0e-3 -- the needle-shaped Gaussians' quaternion chain rule);
+    # round 3 allowed 2e-4 / 1e-3 / 4e-3
+    PAIR_TOL, PARAM_TOL = (2e-4, 3e-3) if name.startswith("fuzz") else (5e-5, 5e-5)
+
+    def close(a, b, name, tol=PAIR_TOL):
         # the bound: relative to the tensor's max magnitude (the sums group differently in kernel and oracle) ...
         scale = np.abs(b).max() + 1e-20
         err = np.abs(a - b).max() / scale
+        maxerr[name] = err
         assert err < tol, (name, err)
         # ... which says nothing about small-gradient Gaussians, so the DISTRIBUTION of the element-wise relative error
         # is pinned as well, over the elements above 1e-4 of the maximum (below that the float32 sums are rounding noise)
@@ -212,8 +219,9 @@ def test_backward_vs_oracle(ctx, name):
     G = {k: v.cpu().numpy() for k, v in ops.split_grads(grads, N).items()}
     # (stress scenes: needle-shaped Gaussians make the covariance chain rule sum terms far larger than the result)
     for k in ("means", "quats", "scales", "opacities", "sh"):
-        close(G[k], go_grads[k], k, tol=4e-3 if name.startswith("fuzz") else 1e-3)
+        close(G[k], go_grads[k], k, tol=PARAM_TOL)
     print(name, "relative gradient error (median, p99):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in dist.items()})
+    print(name, "max error / tensor max:", {k: f"{v:.1e}" for k, v in maxerr.items()})
 
 
 def test_backward_is_deterministic(ctx):
