@@ -343,7 +343,8 @@ int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset,
  * Multi-GPU: one process per GPU, views sharded, Gaussians and Adam state replicated; the one
  * exchange step is a sum all-reduce of the [23N] gradient buffer per iteration over RCCL.  The reference is
  * single-process (starster/gs.py:143-164); sharding is valid because its loss is a sum over views
- * (gs.py:149-152).  RCCL is bound at run time (dlopen); without it only these entry points fail.
+ * (gs.py:149-152).  RCCL is bound at run time (dlopen: the library named by ST3R_RCCL_LIB if set, else the librccl.so.1
+ * already in the process, else a fresh one); without it only these entry points fail.
  *
  *   st3r_comm_unique_id  rank 0 creates the 128-byte id, the host distributes it by its own means
  *   st3r_comm_init       every rank joins (collective; the ctx then owns the communicator)

@@ -58,7 +58,13 @@ RcclApi* rccl_api() {
     static bool tried = false;
     if (tried) return api.handle ? &api : nullptr;
     tried = true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    // ST3R_RCCL_LIB: the library to bind instead (a site's own RCCL build; the multi-rank-on-one-GPU shim of the tests)
+    void* h = nullptr;
+    if (const char* e = getenv("ST3R_RCCL_LIB")) {
+        h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { st3r_set_error("ST3R_RCCL_LIB=%s: %s", e, dlerror()); return nullptr; }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) { st3r_set_error("RCCL not found: %s", dlerror()); return nullptr; }

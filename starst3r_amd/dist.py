@@ -30,7 +30,12 @@ def all_reduce_sum(t):
     """In-place sum over ranks (no-op for a single process)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda and dist.get_backend() != "nccl":   # a host-side process group (gloo): staged through the host
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 

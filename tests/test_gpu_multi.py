@@ -21,11 +21,18 @@ import torch
 import torch.multiprocessing as mp
 
 N_GPUS = torch.cuda.device_count() if torch.cuda.is_available() else 0
-# ST3R_TEST_MULTI_FORCE=1 runs the same code with ONE spawned rank on a single-GPU box (plumbing check only: process
-# group, communicator, exchange forms, Scene loop -- every comparison then holds trivially)
+HERE = os.path.dirname(os.path.abspath(__file__))
+# ONE visible GPU (the builder's box, the round-end box): the same tests run with EMULATED ranks -- `EMULATED_WORLD`
+# processes that all use cuda:0, torch.distributed on gloo, and the library's communicator bound to the test shim
+# tests/fake_rccl (ST3R_RCCL_LIB; RCCL itself refuses two ranks on one device).  Everything above the six nccl* entry points
+# is the product code: st3r_comm_init, the three exchange forms with their piece / range arithmetic for w > 1, the status
+# word, the sharded Adam, Scene's loop, the pair exchange.  What emulation cannot show is RCCL's own behaviour and timing.
+# ST3R_TEST_MULTI_FORCE=1 keeps the older plumbing check instead: ONE spawned rank on real RCCL.
 FORCED = os.environ.get("ST3R_TEST_MULTI_FORCE") == "1" and N_GPUS == 1
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(N_GPUS < 2 and not FORCED,
-                                                  reason="needs >= 2 visible GPUs (one process per GPU)")]
+EMULATED = N_GPUS == 1 and not FORCED
+EMULATED_WORLD = int(os.environ.get("ST3R_TEST_MULTI_EMULATE", "2"))
+WORLD = EMULATED_WORLD if EMULATED else max(1, min(N_GPUS, 8))
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(N_GPUS < 1, reason="needs a GPU")]
 
 N, W, H = 20000, 320, 240
 
@@ -43,11 +50,38 @@ def _scene(world, views_per_rank=2):
     return g, w2c, Ks, V
 
 
+def _shim():
+    """Build (when stale) and return the path of the RCCL stand-in for ranks that share one GPU."""
+    import subprocess
+    src, out = os.path.join(HERE, "fake_rccl", "fake_rccl.cpp"), os.path.join(HERE, "_build", "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-x", "c++", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", src, "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"], check=True)
+    return out
+
+
+def _device(rank):
+    return torch.device("cuda:0" if EMULATED else f"cuda:{rank}")
+
+
 def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    dev = _device(rank)
+    torch.cuda.set_device(dev)
+    if EMULATED:
+        os.environ["ST3R_RCCL_LIB"] = _shim()            # read when the library first binds its collectives
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+
+def _same_on_every_rank(t):
+    """rank 0's copy of `t`, for bit-equality checks (staged through the host: gloo carries the emulated ranks)."""
+    ref = t.detach().cpu().clone() if EMULATED else t.detach().clone()
+    torch.distributed.broadcast(ref, src=0)
+    return torch.equal(ref.to(t.device), t.detach())
 
 
 def _gt(ctx, g, w2c, Ks, dev):
@@ -66,7 +100,7 @@ def _grad_worker(rank, world, port, out, exchange):
     os.environ["ST3R_EXCHANGE"] = exchange
     _init(rank, world, port)
     from starst3r_amd import dist as sdist, ops
-    dev = torch.device(f"cuda:{rank}")
+    dev = _device(rank)
     ctx = ops.get_context(dev)
     g, w2c, Ks, V = _scene(world)
     gt = _gt(ctx, g, w2c, Ks, dev)
@@ -80,13 +114,13 @@ def _grad_worker(rank, world, port, out, exchange):
     # exchanged gradient for every exchange form (under rs_ag `grads` itself only holds the rank's own piece)
     ops.train_step(ctx, P, vm, K, ops.camera_positions(vm), gt[views].contiguous(), W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3,
                    0.9, 0.999, 1e-8, 1, loss)
-    torch.distributed.all_reduce(loss)
     torch.cuda.synchronize()
+    total = loss.cpu()
+    torch.distributed.all_reduce(total)
+    loss.copy_(total)
     # replicas: identical parameters on every rank (and moments, except under rs_ag where a rank maintains its piece only)
     for name, t in list(P.items()) + ([] if exchange == "rs_ag" else [("m", m), ("v", v)]):
-        ref = t.clone()
-        torch.distributed.broadcast(ref, src=0)
-        assert torch.equal(ref, t), (exchange, name, rank)
+        assert _same_on_every_rank(t), (exchange, name, rank)
     if rank == 0:
         torch.save(dict(P={k: x.cpu() for k, x in P.items()}, m=m.cpu(), v=v.cpu(), loss=loss.cpu()), out)
     sdist.detach_native_comm(ctx)
@@ -96,7 +130,7 @@ def _grad_worker(rank, world, port, out, exchange):
 @pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag"])
 def test_exchanged_step_equals_single_gpu_step(tmp_path, exchange):
     from starst3r_amd import ops
-    world = max(1, min(N_GPUS, 8))
+    world = WORLD
     out = str(tmp_path / "r0.pt")
     mp.spawn(_grad_worker, args=(world, _free_port(), out, exchange), nprocs=world, join=True)
     z = torch.load(out)
@@ -115,9 +149,13 @@ def test_exchanged_step_equals_single_gpu_step(tmp_path, exchange):
     scale = float(m.abs().max())
     own = (23 * N) // world if exchange == "rs_ag" else 23 * N     # rank 0's piece of the buffer
     assert float((z["m"].to(dev)[:own] - m[:own]).abs().max()) <= 1e-5 * scale
-    for k in P:   # the update is ~ lr * sign(g) on the first step: identical up to gradients that are rounding noise
-        same = (z["P"][k].to(dev) == P[k]).float().mean().item()
-        assert same > 0.99, (k, same)
+    # the first update is lr * g / (|g| + eps) ~ lr * sign(g): the parameters agree to the rounding of the sum over ranks,
+    # except where the gradient itself is rounding noise around 0 (there the update is anything in [-lr, lr])
+    for k in P:
+        d = (z["P"][k].to(dev) - P[k]).abs()
+        assert float(d.max()) <= 2.01e-3, (k, float(d.max()))
+        close = (d <= 1e-6 * P[k].abs().clamp(min=1.0)).float().mean().item()
+        assert close > 0.99, (k, close)
     ctx.close()
 
 
@@ -126,7 +164,7 @@ def _scene_worker(rank, world, port, out, iters):
     _init(rank, world, port)
     from starst3r_amd import dist as sdist, ops
     from starst3r_amd.scene import Scene
-    dev = torch.device(f"cuda:{rank}")
+    dev = _device(rank)
     ctx = ops.get_context(dev)
     g, w2c, Ks, V = _scene(world)
     gt = _gt(ctx, g, w2c, Ks, dev).cpu().numpy()
@@ -139,9 +177,7 @@ def _scene_worker(rank, world, port, out, iters):
     losses = sc.run_3dgs_optim(iters, enable_pruning=True)
     torch.cuda.synchronize()
     for k, t in sc.gaussians.items():
-        ref = t.data.clone()
-        torch.distributed.broadcast(ref, src=0)
-        assert torch.equal(ref, t.data), (k, rank)       # replicas bit-identical, MCMC noise included
+        assert _same_on_every_rank(t.data), (k, rank)    # replicas bit-identical, MCMC noise included
     if rank == 0:
         torch.save(dict(P={k: t.data.cpu() for k, t in sc.gaussians.items()}, losses=losses), out)
     sdist.detach_native_comm(ctx)
@@ -151,7 +187,7 @@ def _scene_worker(rank, world, port, out, iters):
 def test_replicas_stay_identical_over_iterations_with_mcmc_hooks(tmp_path):
     from starst3r_amd import ops
     from starst3r_amd.scene import Scene
-    world, iters = max(1, min(N_GPUS, 8)), 8
+    world, iters = WORLD, 8
     out = str(tmp_path / "r0.pt")
     mp.spawn(_scene_worker, args=(world, _free_port(), out, iters), nprocs=world, join=True)
     z = torch.load(out)
@@ -169,7 +205,13 @@ def test_replicas_stay_identical_over_iterations_with_mcmc_hooks(tmp_path):
     for k, t in sc.gaussians.items():
         a, b = z["P"][k].to(dev), t.data
         assert a.shape == b.shape, k
-        assert float((a - b).abs().max()) <= 1e-2 * iters * 1e-3 + 1e-6 or (a == b).float().mean() > 0.98, k
+        # Adam's first steps move a parameter by ~ lr * sign(g): where g is rounding noise around 0 the two summation orders
+        # (ranks' partial sums vs one sum over all views) may step in opposite directions, so a few per cent of the
+        # entries differ by a few lr while the rest agree to the bit (measured with 2 ranks: >= 97.8 % equal, shN lowest)
+        d = (a - b).abs()
+        # -- or everything agrees to rounding (means, 2-4 ranks: max 1.2e-4, mean 1.6e-8)
+        assert float(d.mean()) <= 1e-5 and (float(d.max()) <= 1e-3 or (a == b).float().mean() > 0.95), \
+            (k, float((a == b).float().mean()), float(d.mean()), float(d.max()))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -182,7 +224,7 @@ def _pairs_worker(rank, world, port, base):
     imgs = [dict(instance=f"{i}.png", idx=i) for i in range(n_views)]
     pairs = [(imgs[i], imgs[j]) for i in range(n_views) for j in range(i + 1, n_views)]
     cache = os.path.join(base, f"rank{rank}")            # rank-private caches: the exchange has to fill them
-    res, _ = forward.forward_mast3r(pairs, net, cache, device=f"cuda:{rank}", subsample=8)
+    res, _ = forward.forward_mast3r(pairs, net, cache, device=str(_device(rank)), subsample=8)
     assert len(res) == len(pairs)
     assert net.calls == len(range(rank, len(pairs), world)), (rank, net.calls)
     torch.save({k: (torch.load(v[0][0]), torch.load(v[0][1]), torch.load(v[1])) for k, v in res.items()},
@@ -191,7 +233,7 @@ def _pairs_worker(rank, world, port, base):
 
 
 def test_pair_sharding_fills_every_cache(tmp_path):
-    world = max(1, min(N_GPUS, 8))
+    world = WORLD
     mp.spawn(_pairs_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     outs = [torch.load(tmp_path / f"out{r}.pth") for r in range(world)]
 
@@ -205,3 +247,84 @@ def test_pair_sharding_fills_every_cache(tmp_path):
         assert outs[r].keys() == outs[0].keys()
         for k in outs[0]:
             assert same(outs[r][k], outs[0][k]), (k, r)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _failing_rank_worker(rank, world, port, form):
+    """The LAST rank's forward/backward fails in step 2 (debug flag 2048): it alone gets its own error, everybody else
+    learns ST3R_ERR_PEER at the next call, nobody applied step 2, and the job goes on with identical replicas."""
+    os.environ["ST3R_EXCHANGE"] = form
+    _init(rank, world, port)
+    from starst3r_amd import _lib, dist as sdist, ops
+    dev = _device(rank)
+    ctx = ops.get_context(dev)
+    g, w2c, Ks, V = _scene(world)
+    gt = _gt(ctx, g, w2c, Ks, dev)
+    views = sdist.shard_views(V, rank, world)
+    P = {k: torch.from_numpy(g[k]).to(dev) for k in ("means", "quats", "scales", "opacities", "shN")}
+    vm, K = torch.from_numpy(w2c).to(dev)[views].contiguous(), torch.from_numpy(Ks).to(dev)[views].contiguous()
+    sdist.attach_native_comm(ctx)
+    grads = torch.empty(23 * N, device=dev); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+    loss = torch.zeros(1, device=dev)
+
+    def step(i):
+        ops.train_step(ctx, P, vm, K, ops.camera_positions(vm), gt[views].contiguous(), W, H, 0.2, 0.01, 0.01, grads, m, v,
+                       1e-3, 0.9, 0.999, 1e-8, i, loss)
+        torch.cuda.synchronize()
+    step(1)
+    before = {k: t.clone() for k, t in P.items()}
+    m1 = m.clone()
+    failing = rank == world - 1
+    if failing:
+        ops.set_debug(ctx, 2048)
+        with pytest.raises(_lib.St3rError) as e:
+            step(2)
+        assert e.value.code == -4, e.value
+        ops.set_debug(ctx, 0)
+    else:
+        step(2)                       # returns normally: the status word is read on the device, the host learns later
+    for k in P:
+        assert torch.equal(P[k], before[k]), (form, rank, k)        # step 2 was applied by NOBODY
+    assert torch.equal(m, m1), (form, rank)
+    with pytest.raises(_lib.St3rError) as e:                        # every rank, the failing one included
+        step(2)
+    assert e.value.code == -5, (rank, e.value)
+    for k in P:
+        assert torch.equal(P[k], before[k]), (form, rank, k)
+    step(2)                                                         # the job continues
+    for k, t in P.items():
+        assert not torch.equal(t, before[k]), k
+        assert _same_on_every_rank(t), (form, k, rank)
+    ops.settle(ctx)
+    sdist.detach_native_comm(ctx)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(WORLD < 2, reason="one rank: covered by tests/test_gpu_comm.py")
+@pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag"])
+def test_one_failing_rank_of_several_strands_nobody(form):
+    mp.spawn(_failing_rank_worker, args=(WORLD, _free_port(), form), nprocs=WORLD, join=True)
+
+
+def _pieces_worker(rank, world, port):
+    _init(rank, world, port)
+    from starst3r_amd import dist as sdist, ops
+    dev = _device(rank)
+    ctx = ops.get_context(dev)
+    sdist.attach_native_comm(ctx)
+    n = 23 * 1001                                            # does not divide by 2, 3, 4: a tail nobody owns alone
+    q = n // world
+    want = torch.arange(n, device=dev, dtype=torch.float32)
+    x = torch.full((n,), -1.0, device=dev)
+    x[rank * q:(rank + 1) * q] = want[rank * q:(rank + 1) * q]       # the rank's own piece ...
+    x[world * q:] = want[world * q:]                                 # ... and the tail every rank maintains
+    ops.allgather_pieces(ctx, x)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want), rank
+    sdist.detach_native_comm(ctx)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(WORLD < 2, reason="one rank: covered by tests/test_gpu_comm.py")
+def test_piece_allgather_over_several_ranks():
+    mp.spawn(_pieces_worker, args=(WORLD, _free_port()), nprocs=WORLD, join=True)
