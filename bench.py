@@ -447,6 +447,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # ST3R_BENCH_EMULATE_RANKS=1 (tools/experiments/bench_emulated_ranks.sh; never for a reported number): every rank
+    # uses cuda:0, torch.distributed runs on gloo and the library's communicator binds ST3R_RCCL_LIB (tests/fake_rccl) --
+    # a crash test of the N > 1 code path of this file on a one-GPU box; the line says "emulated" in config.parallelism
+    EMULATED = os.environ.get("ST3R_BENCH_EMULATE_RANKS") == "1"
+    if EMULATED:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -454,7 +460,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if EMULATED:
+            assert os.environ.get("ST3R_RCCL_LIB"), "emulated ranks need ST3R_RCCL_LIB (tests/_build/libfake_rccl.so)"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from starst3r_amd import ops
     from st3r_synth import synth
@@ -665,6 +675,8 @@ def main():
                                 if native_comm else
                                 f"view-dp{world} (torch.distributed all_reduce of the [23N] gradients between "
                                 f"st3r_gs_train_fwd_bwd and st3r_adam_step)"),
+                **({"emulated_ranks": "ALL ranks share cuda:0 over a shared-memory RCCL stand-in: a crash test of the "
+                                      "N > 1 path, not a measurement"} if EMULATED else {}),
                 "n_visible_pairs": V, "n_isects_reference_algorithm": I, "n_isects_kept_after_exact_culling": I_kept,
                 "sort_key_bits": {"reference_single_key": keybits, "level1": key1_bits, "level2": key2_bits},
                 "mean_tiles_per_visible_gaussian": (I_kept / V) if V else 0.0,
