@@ -175,7 +175,7 @@ ST3R_EXPORT int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* co
 // ---- internal stage launchers (other translation units) ----
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
                          int64_t* n_isects_host, const void* pack_rects, int rect32, uint64_t* pack_out,
-                         int32_t** total_dev_out);
+                         int32_t** total_dev_out, int32_t* total_copy);
 int st3r_isect_emit_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* cum, int tile_size,
                          int tile_w, int tile_h, int64_t* isect_ids, int32_t* flatten_ids);
 int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t* keys_in, int32_t* vals_in,
@@ -186,7 +186,8 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32);
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32,
+                      int reg_overwrite, double* zero_ptr, int zero_n);
 int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
                                int rect32, const int32_t* cum, int tile_w, int tile_h, uint32_t* tile_keys,
                                int32_t* vals, int64_t cap);
@@ -216,7 +217,7 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
                              float scale_fac, float* grads, bool accumulate, int g_begin, int g_end, bool range_major);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
-                   float w_l1, float w_ssim, double* sums, float* v_render);
+                   float w_l1, float w_ssim, double* sums, float* v_render, bool sums_cleared);
 
 static int bit_length_u32(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
 
@@ -285,7 +286,10 @@ struct RasterOut {
 static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* means, const float* quats,
                            const float* scales, const float* opacities, const float* sh, int sh_stride,
                            const float* viewmats, const float* Ks, const float* campos, int W, int H,
-                           double* reg_sums, int tight, const float* records_in, bool allow_async, RasterOut* o) {
+                           double* reg_sums, int tight, const float* records_in, bool allow_async, RasterOut* o,
+                           double* loss_sums = nullptr) {
+    // reg_sums is OVERWRITTEN with the projection's sums, and loss_sums[0 .. 2C) (the loss kernel's accumulators, when
+    // given) is cleared along the way -- by the projection's reduction launch, not by memsets of their own
     // records_in != NULL: the splat records were projected elsewhere (Gaussian-sharded mode); the projection is
     // replaced by k_records_prepare and the records are used in place
     const int tile = 16;
@@ -325,7 +329,8 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
                                              key_base, rects, rect32)
                  : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
                                      W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, nullptr, reg_sums, dkeys_a,
-                                     dvals_a, tight, key_base, rects, rect32);
+                                     dvals_a, tight, key_base, rects, rect32, 1, loss_sums, 2 * C);
+    if (!rc && records_in && loss_sums) HIP_TRY(hipMemsetAsync(loss_sums, 0, sizeof(double) * 2 * (size_t)C, s));
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
@@ -345,22 +350,21 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
         rectbase = rb;
     }
     // (its total is the record count; the emit kernel finds the write positions of the depth-ordered records itself)
-    int32_t* total_dev = nullptr;
-    rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev);
-    st3r_prof_end(ctx, s, STG_SCAN);
-    if (rc) return rc;
     // The record count is produced on the device.  Steady state (allow_async and a count from an earlier call): no host
     // round trip -- the buffers are sized from the previous count (+25 %, +1024), every kernel downstream reads the count
-    // from device memory, and the count travels to pinned memory behind an event that the NEXT call checks (it also
-    // notices, loudly, if this call's count exceeded its capacity).  Otherwise (first call, or the caller wants exact
-    // statistics back): copy + synchronise, as in round 1.
+    // from device memory (the scan's last workgroup leaves it in the ctx's count word as well), and the count travels to
+    // pinned memory behind an event that the NEXT call checks (it also notices, loudly, if this call's count exceeded its
+    // capacity).  Otherwise (first call, or the caller wants exact statistics back): copy + synchronise, as in round 1.
     const int32_t* n_dev = nullptr;
     const int64_t sig = ((int64_t)N << 34) ^ ((int64_t)C << 26) ^ ((int64_t)W << 13) ^ (int64_t)H;
     const bool async = allow_async && ctx->isect_hint > 0 && ctx->hint_sig == sig;
+    int32_t* counts = nullptr;
+    if (async) { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
+    int32_t* total_dev = nullptr;
+    rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev, counts);
+    st3r_prof_end(ctx, s, STG_SCAN);
+    if (rc) return rc;
     if (async) {
-        int32_t* counts;
-        { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
-        HIP_TRY(hipMemcpyAsync(counts, total_dev, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + 8), total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (!ctx->count_event) HIP_TRY(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ctx->count_event, s));
@@ -430,7 +434,7 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     const int64_t n_pairs = (int64_t)N * C, n_px = (int64_t)C * H * W;
     RasterOut ro;
     int rc = rasterize_front(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
-                             reg_sums, 1, nullptr, allow_async, &ro);
+                             reg_sums, 1, nullptr, allow_async, &ro, sums);
     if (rc) return rc;
     const bool eio = true;   // the fused path's offsets table carries the total as its last entry
     GET(SLOT_RGB, float, n_px * 3, rgb);
@@ -444,7 +448,7 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     st3r_prof_end(ctx, s, STG_BLEND_FWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_LOSS);
-    rc = st3r_loss_impl(ctx, s, C, H, W, rgb, gt_images, 1.0f - ssim_fac, ssim_fac, sums, v_rgb);
+    rc = st3r_loss_impl(ctx, s, C, H, W, rgb, gt_images, 1.0f - ssim_fac, ssim_fac, sums, v_rgb, true);
     st3r_prof_end(ctx, s, STG_LOSS);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
@@ -518,7 +522,6 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
             const int c0 = (int)((int64_t)k * C / chunks), c1 = (int)((int64_t)(k + 1) * C / chunks);
             if (c1 == c0) continue;
             double* rs = first ? reg_sums : reg_scratch;
-            HIP_TRY(hipMemsetAsync(rs, 0, sizeof(double) * 4, s));
             RasterOut ro;
             // exact statistics need the count on the host: a caller that passes stats_host pays the synchronisation;
             // chunked calls size every chunk exactly (the hint of the steady state belongs to one set of views); with a
@@ -587,7 +590,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     st3r_prof_end(ctx, s, STG_BLEND_FWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_LOSS);
-    rc = st3r_loss_impl(ctx, s, C, H, W, rgb, gt_images, 1.0f - ssim_fac, ssim_fac, sums, v_rgb);
+    rc = st3r_loss_impl(ctx, s, C, H, W, rgb, gt_images, 1.0f - ssim_fac, ssim_fac, sums, v_rgb, false);
     st3r_prof_end(ctx, s, STG_LOSS);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);

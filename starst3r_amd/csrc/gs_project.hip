@@ -210,10 +210,14 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
     }
 }
 
-// reg_sums[k] += sum over blocks of reg_part[., k], in a fixed order (bit-reproducible; thousands of
-// same-address double atomics from the projection kernel used to cost more than the projection itself)
+// reg_sums[k] += (or =, `overwrite`) sum over blocks of reg_part[., k], in a fixed order (bit-reproducible; thousands of
+// same-address double atomics from the projection kernel used to cost more than the projection itself).  The fused
+// training calls also let this one small workgroup clear the loss kernel's accumulators (zero_ptr[0 .. zero_n)): two
+// memset launches less per step.
 __global__ __launch_bounds__(256) void k_reg_reduce(int n_blocks, const double* __restrict__ reg_part,
-                                                    double* __restrict__ reg_sums) {
+                                                    double* __restrict__ reg_sums, int overwrite,
+                                                    double* __restrict__ zero_ptr, int zero_n) {
+    for (int i = threadIdx.x; i < zero_n; i += 256) zero_ptr[i] = 0.0;
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
     for (int b = threadIdx.x; b < n_blocks; b += 256)
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void k_reg_reduce(int n_blocks, const double* 
             for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x < 4) reg_sums[threadIdx.x] += sh[threadIdx.x][0];
+    if (threadIdx.x < 4) reg_sums[threadIdx.x] = (overwrite ? 0.0 : reg_sums[threadIdx.x]) + sh[threadIdx.x][0];
 }
 
 // depth_keys/depth_vals (optional, [C*N]): per-pair (camera | depth bits) key and pair id for the
@@ -234,8 +238,13 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* opacities, const float* sh, int sh_stride, const float* viewmats, const float* Ks,
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
-                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32) {
-    if (N == 0) return ST3R_OK;
+                      uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32,
+                      int reg_overwrite, double* zero_ptr, int zero_n) {
+    if (N == 0) {
+        if (reg_sums && reg_overwrite) HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 4, s));
+        if (zero_ptr && zero_n > 0) HIP_TRY(hipMemsetAsync(zero_ptr, 0, sizeof(double) * (size_t)zero_n, s));
+        return ST3R_OK;
+    }
     int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
     dim3 grid(ceil_div(N, 256)), block(256);
     size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
@@ -250,7 +259,11 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                        viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
                        radius_clip, (float4*)splats, tiles_per_gauss, reg_part, depth_keys, depth_vals, tight, key_base,
                        rects, rect32);
-    if (reg_sums) hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(256), 0, s, (int)grid.x, reg_part, reg_sums);
+    if (reg_sums)
+        hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(256), 0, s, (int)grid.x, reg_part, reg_sums, reg_overwrite, zero_ptr,
+                           zero_ptr ? zero_n : 0);
+    else if (zero_ptr && zero_n > 0)
+        HIP_TRY(hipMemsetAsync(zero_ptr, 0, sizeof(double) * (size_t)zero_n, s));
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -265,5 +278,5 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
     return st3r_project_impl(ctx, (hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
                              campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,
-                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0, 0u, nullptr, 0);
+                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0, 0u, nullptr, 0, 0, nullptr, 0);
 }

@@ -406,9 +406,9 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k
 }
 
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
-                   float w_l1, float w_ssim, double* sums, float* v_render) {
+                   float w_l1, float w_ssim, double* sums, float* v_render, bool sums_cleared) {
     static const Win win = make_window();
-    HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)C, s));
+    if (!sums_cleared) HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)C, s));
     // A strip of LH output rows streams LH + 20 input rows: tall strips waste less, but the launch needs a few
     // workgroups per CU -- as few row strips as still give ~1000 workgroups, at least 64 rows each
 #ifndef SSIM_TARGET_WGS
@@ -438,5 +438,5 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
 ST3R_EXPORT int st3r_loss_l1_ssim(st3r_ctx* ctx, void* stream, int C, int height, int width, const float* render,
                                   const float* gt, float w_l1, float w_ssim, double* sums, float* v_render) {
     ARG_CHECK(ctx && C > 0 && height > 0 && width > 0 && render && gt && sums);
-    return st3r_loss_impl(ctx, (hipStream_t)stream, C, height, width, render, gt, w_l1, w_ssim, sums, v_render);
+    return st3r_loss_impl(ctx, (hipStream_t)stream, C, height, width, render, gt, w_l1, w_ssim, sums, v_render, false);
 }
