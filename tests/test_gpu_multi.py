@@ -328,3 +328,69 @@ def _pieces_worker(rank, world, port):
 @pytest.mark.skipif(WORLD < 2, reason="one rank: covered by tests/test_gpu_comm.py")
 def test_piece_allgather_over_several_ranks():
     mp.spawn(_pieces_worker, args=(WORLD, _free_port()), nprocs=WORLD, join=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] with its EIGHT ranks: 32 views, 4 per rank, the gradient exchange inside st3r_gs_train_step.
+# (tests/test_gpu_configs.py sums the eight ranks' gradient buffers by hand; here the library's exchange does it.)
+CFG3 = dict(N=300_000, V=32, W=512, H=384, world=8, steps=3, seed=12)
+
+
+def _cfg3_problem(dev):
+    from starst3r_amd import ops
+    from st3r_synth import synth
+    c = CFG3
+    g, w2c_np, Ks_np = synth.make_scene(c["N"], c["V"], c["W"], c["H"], seed=c["seed"])
+    ctx = ops.get_context(dev)
+    w2c, Ks = torch.tensor(w2c_np, device=dev), torch.tensor(Ks_np, device=dev)
+    Q = {k: torch.tensor(v, device=dev) for k, v in synth.perturb_for_gt(g).items()}
+    gt, _, _ = ops.render(ctx, Q, w2c, Ks, ops.camera_positions(w2c), c["W"], c["H"])
+    P = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    return ctx, P, w2c, Ks, gt.clamp(0, 1).contiguous()
+
+
+def _cfg3_steps(ctx, P, w2c, Ks, gt, dev):
+    from starst3r_amd import ops
+    c = CFG3
+    grads = torch.empty(23 * c["N"], device=dev); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+    losses = torch.zeros(c["steps"], device=dev)
+    for i in range(c["steps"]):
+        ops.train_step(ctx, P, w2c, Ks, ops.camera_positions(w2c), gt, c["W"], c["H"], 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9,
+                       0.999, 1e-8, i + 1, losses[i:i + 1])
+    torch.cuda.synchronize()
+    return losses
+
+
+def _cfg3_worker(rank, world, port, out, exchange):
+    os.environ["ST3R_EXCHANGE"] = exchange
+    _init(rank, world, port)
+    from starst3r_amd import dist as sdist
+    dev = _device(rank)
+    ctx, P, w2c, Ks, gt = _cfg3_problem(dev)
+    views = sdist.shard_views(CFG3["V"], rank, world)
+    assert len(views) == 4
+    sdist.attach_native_comm(ctx)
+    losses = _cfg3_steps(ctx, P, w2c[views].contiguous(), Ks[views].contiguous(), gt[views].contiguous(), dev).cpu()
+    torch.distributed.all_reduce(losses)                      # the reference's loss is the sum over the views
+    for k, t in P.items():
+        assert _same_on_every_rank(t), (exchange, k, rank)
+    if rank == 0:
+        torch.save(dict(P={k: t.cpu() for k, t in P.items()}, losses=losses), out)
+    sdist.detach_native_comm(ctx)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(not EMULATED and N_GPUS < 8, reason="eight ranks: an 8-GPU node, or emulated on one GPU")
+@pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag"])
+def test_cfg3_eight_ranks_train_like_one(tmp_path, exchange):
+    world, out = CFG3["world"], str(tmp_path / "r0.pt")
+    mp.spawn(_cfg3_worker, args=(world, _free_port(), out, exchange), nprocs=world, join=True)
+    z = torch.load(out)
+    dev = torch.device("cuda:0")
+    ctx, P, w2c, Ks, gt = _cfg3_problem(dev)
+    losses = _cfg3_steps(ctx, P, w2c, Ks, gt, dev).cpu()
+    np.testing.assert_allclose(z["losses"].numpy(), losses.numpy(), rtol=2e-5)
+    assert losses[-1] < losses[0]
+    for k in P:   # Adam's first steps move every entry by ~lr: the two summation orders agree except where g ~ 0
+        d = (z["P"][k].to(dev) - P[k]).abs()
+        assert float(d.max()) <= 2.01e-3 * CFG3["steps"] and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))
