@@ -209,3 +209,25 @@ def test_adam_matches_torch_optim(oracle_built):
     st = opt.state[P]
     np.testing.assert_allclose(m, st["exp_avg"].numpy(), rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(v, st["exp_avg_sq"].numpy(), rtol=1e-6, atol=1e-20)
+
+
+def test_ssim_against_scipy_gaussian_filter(oracle_built):
+    """An implementation of the windowed moments that is NOT the builder's: scipy.ndimage.gaussian_filter with
+    sigma 1.5, truncate 3.5 (= the 11-tap window of Wang et al. 2004, which torchmetrics' data_range=1 default and
+    scikit-image's gaussian_weights=True both use), population statistics, K1 = .01, K2 = .03, mean over the pixels whose
+    window lies inside the image (what torchmetrics keeps after cropping its padding; starster/gs.py:39,129)."""
+    nd = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(7)
+    H, W = 41, 53
+    x = rng.uniform(0, 1, (H, W, 3))
+    y = np.clip(x + rng.normal(0, 0.15, x.shape), 0, 1)
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    vals = []
+    for ch in range(3):
+        f = lambda a: nd.gaussian_filter(a, 1.5, truncate=3.5, mode="constant")[5:-5, 5:-5]
+        mx, my = f(x[..., ch]), f(y[..., ch])
+        sxx, syy, sxy = f(x[..., ch] ** 2) - mx * mx, f(y[..., ch] ** 2) - my * my, f(x[..., ch] * y[..., ch]) - mx * my
+        vals.append(((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2)))
+    want = float(np.mean(vals))
+    _, ss, _ = go.l1_ssim(x.astype(np.float32), y.astype(np.float32), want_grad=False)
+    assert abs(ss - want) < 2e-6, (ss, want)
