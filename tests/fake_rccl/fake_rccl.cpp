@@ -28,7 +28,7 @@ typedef int ncclRedOp_t;    // ncclSum = 0, ncclMax = 2
 }
 
 namespace {
-constexpr size_t SLOT_BYTES = 128u << 20;  // per rank (sparse: only what a collective touches is ever backed by /dev/shm)
+constexpr size_t SLOT_BYTES = 512u << 20;  // per rank (sparse: only what a collective touches is ever backed by /dev/shm)
 constexpr double BARRIER_TIMEOUT_S = 120.0; // a rank that died must fail the others, not hang them
 struct Shared {
     std::atomic<int> arrived, sense, attached;
