@@ -80,14 +80,19 @@ int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
 /* test hook. bit 0: the blend forward walks every staged record in every wave (no per-quadrant relevance test):
  * images must come out bit-identical, which is how the culling is validated at full size.
  * st3r_ctx_peek(which = 8 / 9): rgb [C,H,W,3] / alpha [C,H,W] of the last st3r_gs_train_fwd_bwd call.
- * bit 10 (1024): st3r_align_run* runs as one persistent kernel with grid barriers instead of two launches per
- * iteration (A/B, tests; measured not faster, see csrc/align.hip). */
+ * (the other bits: csrc/common.h, st3r_ctx::debug_flags) */
 int st3r_ctx_set_debug(st3r_ctx* ctx, int flags);
 /* Waits for the record count of the last asynchronous training step (st3r_gs_train_fwd_bwd / st3r_gs_train_step with
  * stats_host == NULL) and reports it like the next training call would: ST3R_ERR_CAPACITY if that step outgrew its
  * buffers (its Adam update was then skipped on the device: repeat the step).  For the end of a training loop
  * (starster/gs.py:143-166 returns after the last iteration); a no-op when nothing is in flight. */
 int st3r_ctx_settle(st3r_ctx* ctx);
+/* Gives the ctx's scratch back to the device allocator (the arena is grow-only otherwise: a 1 M-Gaussian / 8 x 1080p step
+ * holds ~6 GB, one rank of configs[4] ~150 GB): waits for the device, settles like st3r_ctx_settle (whose code it returns),
+ * frees every scratch buffer.  The ctx stays valid -- the next call allocates what it needs again, one synchronising
+ * step; communicator, settings and sizing hints are kept.  For a host that alternates phases on one GPU (Mast3r
+ * inference <-> training), or hands the GPU to another process. */
+int st3r_ctx_release_scratch(st3r_ctx* ctx);
 int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* counts_out);
 const char* st3r_stage_name(int stage);
 

@@ -25,6 +25,7 @@ SIGNATURES = {
     "st3r_ctx_set_profiling": [vp, i32],
     "st3r_ctx_set_debug": [vp, i32],
     "st3r_ctx_settle": [vp],
+    "st3r_ctx_release_scratch": [vp],
     "st3r_ctx_get_stage_ms": [vp, C.POINTER(f64), C.POINTER(i64)],
     "st3r_stage_name": [i32],
     "st3r_gs_project_sh": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32,

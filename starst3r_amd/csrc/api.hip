@@ -258,6 +258,17 @@ ST3R_EXPORT int st3r_ctx_settle(st3r_ctx* ctx) {
     return settle_pending_count(ctx);
 }
 
+ST3R_EXPORT int st3r_ctx_release_scratch(st3r_ctx* ctx) {
+    ARG_CHECK(ctx);
+    HIP_TRY(hipDeviceSynchronize());
+    const int rc = st3r_ctx_settle(ctx);   // an overflow / a peer's failure of the last asynchronous step is still reported
+    for (int i = 0; i < SLOT_COUNT; ++i) {
+        if (ctx->slot_ptr[i]) (void)hipFree(ctx->slot_ptr[i]);
+        ctx->slot_ptr[i] = nullptr; ctx->slot_bytes[i] = 0;   // (every user of a slot's CONTENTS re-initialises on growth)
+    }
+    return rc;
+}
+
 // The 16 device words next to the fused steps: [0] record count of an asynchronous step (k_adam compares it with the
 // step's capacity), [4] status word of an exchanged step (comm.hip).  Zeroed when allocated.
 int st3r_counts_buffer(st3r_ctx* ctx, hipStream_t s, int32_t** out) {

@@ -37,6 +37,12 @@ class Context:
     def arena_bytes(self):
         return int(_lib.lib().st3r_ctx_arena_bytes(self._h))
 
+    def release_scratch(self):
+        """Give the grow-only scratch arena back to the device allocator (st3r_ctx_release_scratch); the context stays
+        valid and allocates again on its next call.  Raises what `settle` would raise."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().st3r_ctx_release_scratch(self._h))
+
     def close(self):
         if self._h:
             _lib.lib().st3r_ctx_destroy(self._h)
@@ -58,6 +64,13 @@ def get_context(device):
     if idx not in _contexts:
         _contexts[idx] = Context(torch.device("cuda", idx))
     return _contexts[idx]
+
+
+def release_scratch():
+    """release_scratch() of every cached per-GPU context of this process (e.g. before handing the GPU to Mast3r
+    inference or to another process)."""
+    for ctx in _contexts.values():
+        ctx.release_scratch()
 
 
 def _stream():

@@ -253,3 +253,41 @@ def test_run_3dgs_optim_repeats_an_iteration_whose_update_was_dropped(monkeypatc
         for k in ("means", "scales", "opacities"):
             assert torch.allclose(sc.gaussians[k].data, ref.gaussians[k].data, atol=5e-3), k
         assert abs(losses[-1] - ref_losses[-1]) < 0.05 * abs(ref_losses[-1])
+
+
+def test_release_scratch_frees_the_arena_and_training_goes_on_unchanged():
+    """st3r_ctx_release_scratch between two steps: the arena is empty afterwards, the context stays valid, and the run
+    continues bit-identically to an uninterrupted one (asynchronous steps, i.e. with the record-count hint in play; the
+    stamped gradient slots, the scan's status words and the count words are re-initialised when they are allocated again)."""
+    import numpy as np
+    from starst3r_amd import ops
+    from st3r_synth import synth
+    N, V, W, H = 20000, 3, 320, 240
+    g, w2c, Ks = synth.make_scene(N, V, W, H, seed=6, scale_lo=0.004, scale_hi=0.03)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda:0")
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    P0 = {k: dev(v) for k, v in g.items()}
+
+    def run(release_at):
+        ctx = ops.Context("cuda:0")
+        rgb, _, _ = ops.render(ctx, P0, vm, K, campos, W, H)
+        gt = torch.clamp(rgb + 0.05, 0, 1).contiguous()
+        P = {k: v.clone() for k, v in P0.items()}
+        grads = torch.empty(23 * N, device="cuda:0"); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+        losses = torch.zeros(6, device="cuda:0")
+        for it in range(6):
+            if it in release_at:
+                assert ctx.arena_bytes() > 0
+                ctx.release_scratch()
+                assert ctx.arena_bytes() == 0
+            ops.train_step(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1,
+                           losses[it:it + 1], want_stats=it == 0)
+        torch.cuda.synchronize()
+        ctx.close()
+        return P, losses
+    Pa, la = run(())
+    Pb, lb = run((2, 5))
+    assert torch.equal(la, lb)
+    for k in Pa:
+        assert torch.equal(Pa[k], Pb[k]), k

@@ -50,6 +50,18 @@ def _scene(world, views_per_rank=2):
     return g, w2c, Ks, V
 
 
+def _spawn(fn, args, nprocs):
+    """mp.spawn after giving this process's GPU memory back: on one GPU the emulated ranks share the device with the
+    pytest process, whose contexts may hold the scratch of every test that ran before (configs[4]: ~150 GB)."""
+    if EMULATED:
+        import gc
+        from starst3r_amd import ops
+        ops.release_scratch()
+        gc.collect()
+        torch.cuda.empty_cache()
+    mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+
+
 def _shim():
     """Build (when stale) and return the path of the RCCL stand-in for ranks that share one GPU."""
     import subprocess
@@ -132,7 +144,7 @@ def test_exchanged_step_equals_single_gpu_step(tmp_path, exchange):
     from starst3r_amd import ops
     world = WORLD
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_grad_worker, args=(world, _free_port(), out, exchange), nprocs=world, join=True)
+    _spawn(_grad_worker, (world, _free_port(), out, exchange), world)
     z = torch.load(out)
     dev = torch.device("cuda:0")
     ctx = ops.Context(dev)
@@ -189,7 +201,7 @@ def test_replicas_stay_identical_over_iterations_with_mcmc_hooks(tmp_path):
     from starst3r_amd.scene import Scene
     world, iters = WORLD, 8
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_scene_worker, args=(world, _free_port(), out, iters), nprocs=world, join=True)
+    _spawn(_scene_worker, (world, _free_port(), out, iters), world)
     z = torch.load(out)
     dev = torch.device("cuda:0")
     ctx = ops.get_context(dev)
@@ -234,7 +246,7 @@ def _pairs_worker(rank, world, port, base):
 
 def test_pair_sharding_fills_every_cache(tmp_path):
     world = WORLD
-    mp.spawn(_pairs_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _spawn(_pairs_worker, (world, _free_port(), str(tmp_path)), world)
     outs = [torch.load(tmp_path / f"out{r}.pth") for r in range(world)]
 
     def same(a, b):
@@ -303,7 +315,7 @@ def _failing_rank_worker(rank, world, port, form):
 @pytest.mark.skipif(WORLD < 2, reason="one rank: covered by tests/test_gpu_comm.py")
 @pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag"])
 def test_one_failing_rank_of_several_strands_nobody(form):
-    mp.spawn(_failing_rank_worker, args=(WORLD, _free_port(), form), nprocs=WORLD, join=True)
+    _spawn(_failing_rank_worker, (WORLD, _free_port(), form), WORLD)
 
 
 def _pieces_worker(rank, world, port):
@@ -327,7 +339,7 @@ def _pieces_worker(rank, world, port):
 
 @pytest.mark.skipif(WORLD < 2, reason="one rank: covered by tests/test_gpu_comm.py")
 def test_piece_allgather_over_several_ranks():
-    mp.spawn(_pieces_worker, args=(WORLD, _free_port()), nprocs=WORLD, join=True)
+    _spawn(_pieces_worker, (WORLD, _free_port()), WORLD)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -384,7 +396,7 @@ def _cfg3_worker(rank, world, port, out, exchange):
 @pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag"])
 def test_cfg3_eight_ranks_train_like_one(tmp_path, exchange):
     world, out = CFG3["world"], str(tmp_path / "r0.pt")
-    mp.spawn(_cfg3_worker, args=(world, _free_port(), out, exchange), nprocs=world, join=True)
+    _spawn(_cfg3_worker, (world, _free_port(), out, exchange), world)
     z = torch.load(out)
     dev = torch.device("cuda:0")
     ctx, P, w2c, Ks, gt = _cfg3_problem(dev)
@@ -447,7 +459,7 @@ def test_cfg4_exchange_at_5M_gaussians_eight_ranks_with_pruning(tmp_path):
     import sys
     sys.path.insert(0, HERE)
     world, out = CFG4["world"], str(tmp_path / "r0.pt")
-    mp.spawn(_cfg4_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    _spawn(_cfg4_worker, (world, _free_port(), out), world)
     z = torch.load(out)
     L = np.asarray(z["losses"])
     assert len(L) == CFG4["iters"] and np.isfinite(L).all()
