@@ -55,8 +55,11 @@ def _spawn(fn, args, nprocs):
     pytest process, whose contexts may hold the scratch of every test that ran before (configs[4]: ~150 GB)."""
     if EMULATED:
         import gc
-        from starst3r_amd import ops
-        ops.release_scratch()
+        from starst3r_amd import _lib, ops
+        try:
+            ops.release_scratch()
+        except _lib.St3rError:      # an earlier test left an unsettled (deliberate) overflow on the shared context: the
+            ops.release_scratch()   # first call reported and cleared it
         gc.collect()
         torch.cuda.empty_cache()
     mp.spawn(fn, args=args, nprocs=nprocs, join=True)
