@@ -478,7 +478,7 @@ def main():
     # replicated, one sum-all-reduce of the [23N] gradient buffer per iteration, issued by the library itself
     # (st3r_gs_train_step over its own RCCL communicator).  --multi-gpu gaussian-sharded is the labelled alternative
     # (two all-to-alls of splat records, nothing replicated).
-    # ST3R_BENCH_FREEZE=1 (tools/abl.sh): no optimizer step, so that kernel variants with deliberately broken
+    # ST3R_BENCH_FREEZE=1 (tools/experiments/abl.sh): no optimizer step, so that kernel variants with deliberately broken
     # gradients are all timed on the same scene; never set for a reported number
     FREEZE = os.environ.get("ST3R_BENCH_FREEZE") == "1"
     mode = args.multi_gpu

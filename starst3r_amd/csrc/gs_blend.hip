@@ -38,7 +38,7 @@
 // with 3 to 5 workgroups per CU is 8-40 % slower).  PMC: 1.48 G VALU instructions per launch
 // (2.19 G for the per-record butterfly it replaces), the VALU pipes are busy for the whole kernel.
 //
-// Cost split of the backward at SYNTH-1M (ablations on a frozen scene, tools/abl.sh): phase 1 + 2 arithmetic
+// Cost split of the backward at SYNTH-1M (ablations on a frozen scene, tools/experiments/abl.sh): phase 1 + 2 arithmetic
 // 1.25 ms, staging + flush 0.9 ms, gather 0.27 ms.  The non-arithmetic part is a per-workgroup chain of dependent
 // loads (id -> record, id -> slot base) behind barriers; it is neither shortened by more workgroups per CU, nor by
 // slots addressed by sorted position plus an index indirection, nor by spreading staging and flush over all four

@@ -416,9 +416,9 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
 #endif
     const int strip = v_render ? FLW : LW;
     const int per_band = ceil_div(W, strip) * C;
-    // (measured, tools/ssim_bands.sh: ~1000 workgroups, strips of at least 64 rows -- 8 views: 5 bands, 1 view: 17)
+    // (measured, tools/experiments/ssim_bands.sh: ~1000 workgroups, strips of at least 64 rows -- 8 views: 5 bands, 1 view: 17)
     int bands = std::max(1, std::min(ceil_div(SSIM_TARGET_WGS, per_band), std::max(1, H / 64)));
-    if (const char* e = getenv("ST3R_SSIM_BANDS")) bands = std::max(1, atoi(e));   // tuning hook (tools/ssim_bands.sh)
+    if (const char* e = getenv("ST3R_SSIM_BANDS")) bands = std::max(1, atoi(e));   // tuning hook (tools/experiments/ssim_bands.sh)
     const int LH = ceil_div(H, bands);
     dim3 grid(ceil_div(W, strip), ceil_div(H, LH), C);
     if (!v_render) {   // loss value only

@@ -24,7 +24,7 @@ namespace {
 constexpr int RB = 8;
 constexpr int RADIX = 1 << RB;
 // Two tile shapes.  Large inputs: 1024 threads x 16 (32-bit keys) / 8 (64-bit keys) items, one workgroup per CU -- the
-// per-tile costs (256 status words, the chained scan) dominate, smaller tiles measured 12-25 % slower (tools/abl3.sh).
+// per-tile costs (256 status words, the chained scan) dominate, smaller tiles measured 12-25 % slower (tools/experiments/abl3.sh).
 // Small inputs (fewer than one large tile per CU: a rank's share of a view-sharded job): 512 threads x 8 / 4 items, so that
 // the tiles still cover the chip.
 #ifndef RS_THREADS
