@@ -32,7 +32,8 @@ def maps_of(P, img):
     return np.stack(pt), np.stack(cf)
 
 
-@pytest.mark.parametrize("views,W,H,S", [(2, 64, 48, 8), (4, 128, 96, 8), (3, 96, 64, 16)])
+@pytest.mark.parametrize("views,W,H,S", [(2, 64, 48, 8), (4, 128, 96, 8), (3, 96, 64, 16), (5, 80, 56, 8), (2, 72, 104, 8),
+                                          (6, 48, 48, 4)])
 def test_canonical_view_focal_anchors_vs_oracle(ctx, views, W, H, S):
     from starst3r_amd import ops
     P = synth_pairs.make_pair_predictions(views, W, H, subsample=S, seed=views, n_corr=400)

@@ -44,7 +44,8 @@ def make_problem(C=4, H=40, W=56, G=35, seed=0):
                 Ks=Ks, cam2w=cam2w, A=A, B=B)
 
 
-@pytest.mark.parametrize("seed,C,H,W", [(0, 4, 40, 56), (1, 2, 17, 23), (2, 6, 64, 48)])
+@pytest.mark.parametrize("seed,C,H,W", [(0, 4, 40, 56), (1, 2, 17, 23), (2, 6, 64, 48), (3, 3, 33, 65), (4, 5, 29, 31),
+                                        (5, 2, 100, 20), (6, 7, 24, 40)])
 def test_unproject_and_clean_vs_oracle(seed, C, H, W):
     from starst3r_amd import ops
     ctx = ops.get_context(torch.device(DEV))
