@@ -41,7 +41,7 @@ def golden(z, tag):
     return res, par
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes", "align_c8_small"])
 @pytest.mark.parametrize("iters", [(1, 0), (10, 0)])
 def test_first_steps_vs_reference_golden(name, iters):
     z, flat = load(name)
@@ -50,7 +50,7 @@ def test_first_steps_vs_reference_golden(name, iters):
     compare(res, par, g_res, g_par, 1e-4, f"{name} {iters}")
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes", "align_c8_small"])
 def test_stage2_first_step_vs_reference_golden(name):
     """500 coarse steps then ONE reprojection step: pins the loss_2d gradient (incl. focals and pps)."""
     z, flat = load(name)
@@ -64,7 +64,7 @@ def test_stage2_first_step_vs_reference_golden(name):
     assert d64 <= F32_DRIFT_BOUND["r500_0"]
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes", "align_c8_small"])
 def test_full_schedule_vs_reference_golden(name):
     """Full 500+200 schedule against the reference's float32 result AND against its float64 evaluation: the
     reference in float32 itself ends 0.9e-4 .. 1.5e-4 from the float64 run (tests/test_oracle_align.py), so 4e-4 is

@@ -61,7 +61,7 @@ def check(z, tag, res, params, tol, root=0):
         np.testing.assert_allclose(a[k], b[k], rtol=tol, atol=tol * scale, err_msg=f"{tag} {k}")
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes", "align_c8_small"])
 def test_first_steps_match_reference(name):
     """1 and 10 iterations pin the parametrisation, both losses' gradients, Adam(0.9,0.9), the cosine
     schedule and the quaternion renormalisation tightly (before any trajectory divergence)."""
@@ -71,7 +71,7 @@ def test_first_steps_match_reference(name):
         check(z, f"r{n1}_{n2}", res, params, 2e-5)
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes", "align_c8_small"])
 def test_full_schedule_matches_reference(name):
     """500 (+1, +200) iterations: float32 trajectories drift by rounding (quantified against the float64 reference in
     test_float32_drift_is_bounded_by_the_float64_reference): 4e-5 after the coarse stage, 4e-4 after the full schedule."""
@@ -147,7 +147,7 @@ def drift(a, b):
 F32_DRIFT_BOUND = {"r500_0": 4e-5, "r500_200": 4e-4}
 
 
-@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes"])
+@pytest.mark.parametrize("name", ["align_c2", "align_c4_badpair", "align_c3_mixed_sizes", "align_c8_small"])
 def test_float32_drift_is_bounded_by_the_float64_reference(name):
     """The reference in float32, and the oracle, sit at the same distance from the reference in float64 -- the
     justification for comparing full-schedule float32 results at a few 1e-4 rather than at 1e-4.  (After 10

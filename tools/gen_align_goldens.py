@@ -166,7 +166,10 @@ def main():
     configs = [("align_c2", dict(n_views=2, n_corr=400, seed=1)),
                ("align_c4_badpair", dict(n_views=4, n_corr=250, seed=2, bad_pair=True)),
                # one landscape, one portrait, one smaller landscape photo: core-depth vectors of 3072 / 3072 / 1728 values
-               ("align_c3_mixed_sizes", dict(n_views=3, n_corr=300, seed=5, sizes=[(512, 384), (384, 512), (384, 288)]))]
+               ("align_c3_mixed_sizes", dict(n_views=3, n_corr=300, seed=5, sizes=[(512, 384), (384, 512), (384, 288)])),
+               # eight views (the view count of configs[1] and of bench.py's alignment line): a deeper spanning tree, 28 pairs;
+               # small images keep the fixture small
+               ("align_c8_small", dict(n_views=8, n_corr=120, seed=11, sizes=[(256, 192)] * 8))]
     only = sys.argv[1:]
     if not only or "align_c3_opts" in only:
         # non-default optimiser options of the same function (reconstruct.py:118-122): other robust losses, the linear
