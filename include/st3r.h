@@ -49,7 +49,7 @@ extern "C" {
 #define ST3R_ERR_HIP (-2)      /* a HIP runtime call failed */
 #define ST3R_ERR_CAPACITY (-3) /* caller-supplied capacity too small */
 #define ST3R_ERR_NOMEM (-4)
-#define ST3R_ERR_PEER (-5)     /* the previous exchanged training step failed on another rank: nobody applied it */
+#define ST3R_ERR_PEER (-5)     /* the previous exchanged training step failed on a rank of the communicator: nobody applied it */
 
 #define ST3R_SPLAT_STRIDE 12
 #define ST3R_MAX_VIEWS 256    /* views per call (the camera table lives in LDS: 128 B per view) */
@@ -370,9 +370,15 @@ int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset,
  * when the communicator is created or attached; never written by the library), else with the all-reduce.  All ranks must
  * use the same form.
  *
- * Errors under a communicator: a step that fails on one rank (that rank returns the error) is applied on NO rank -- the
- * failing rank still takes part in every collective, a max-reduced status word guards the update on the device -- and
- * every other rank's next training call (or st3r_ctx_settle) returns ST3R_ERR_PEER: replicas stay identical, nobody hangs.
+ * Errors under a communicator: a step whose forward / backward fails on one rank (that rank returns the error) is applied
+ * on NO rank -- the failing rank still takes part in every collective, a max-reduced status word guards the update on the
+ * device -- and the next training call (or st3r_ctx_settle) of EVERY rank, the failing one included, returns ST3R_ERR_PEER
+ * without issuing a collective: all ranks skip that call together and then repeat the step (a host that retries on one
+ * rank only desynchronises the collective sequence).  Replicas stay identical, nobody hangs.  The guarantee covers the
+ * step's computation; a HIP / RCCL call of the exchange itself that fails (after the status word has travelled) is
+ * returned by that rank once it has issued the step's remaining collectives -- the other ranks cannot be told, the
+ * communicator should be torn down.  The status word guards the update kernels of st3r_gs_train_step only; the
+ * stand-alone st3r_adam_step / st3r_adam_step_range / st3r_params_from_stage never look at it.
  * ---------------------------------------------------------------------------------- */
 #define ST3R_COMM_ID_BYTES 128
 #define ST3R_EXCHANGE_ALLREDUCE 0

@@ -13,6 +13,9 @@ struct AdamK {
     float step_size, bc2_sqrt, w1, w2, b2, eps;
 };
 
+#define ADAM_SKIP(count_dev, count_cap, status_dev) \
+    (((count_dev) && (uint32_t)(count_dev)[0] > (count_cap)) || ((status_dev) && (status_dev)[0] != 0))
+
 // The update covers either a range [i0, i1) of the 23N scalars in buffer order (reduce-scatter exchange: a rank owns
 // one contiguous piece of the gradient buffer) or the 23 scalars of the Gaussians [g0, g1) (range-wise exchange); the
 // whole buffer is the range [0, 23N).  pstage != NULL: the new parameter value is also left in pstage[i] (buffer
@@ -33,16 +36,18 @@ __global__ __launch_bounds__(256) void k_adam(int64_t N, float* __restrict__ mea
                                               float* __restrict__ sh, int sh_stride,
                                               const float* __restrict__ grads, float* __restrict__ m,
                                               float* __restrict__ v, AdamK k, const int32_t* __restrict__ count_dev,
-                                              uint32_t count_cap, int64_t i0, int64_t i1, int64_t g0, int64_t g1,
+                                              uint32_t count_cap, const int32_t* __restrict__ status_dev, int64_t i0,
+                                              int64_t i1, int64_t g0, int64_t g1,
                                               float* __restrict__ pstage, const float* __restrict__ gstage,
                                               float* __restrict__ grads_out) {
     // Asynchronous training steps keep the record count on the device; a step whose count outgrew the capacity of its
     // buffers dropped records, so its gradients are incomplete: the update is skipped HERE, on the device, and the next
     // call reports ST3R_ERR_CAPACITY -- the caller repeats the iteration with nothing to undo (a count above 2^31 wraps
     // negative: the unsigned compare catches it).
-    // Under a communicator the same buffer carries the step's max-reduced status word (comm.hip): a step that failed on
-    // any rank is applied on none.
-    if (count_dev && ((uint32_t)count_dev[0] > count_cap || count_dev[4] != 0)) return;
+    // status_dev: the max-reduced status word of an exchanged step (comm.hip): a step that failed on any rank is applied
+    // on none.  ONLY st3r_gs_train_step passes it -- the word is rewritten by the next exchanged step and by nothing else,
+    // so the stand-alone entry points (st3r_adam_step, _range, st3r_params_from_stage) must not look at it.
+    if (ADAM_SKIP(count_dev, count_cap, status_dev)) return;
     const bool by_gaussian = g1 - g0 < N || gstage;
     const int64_t n = g1 - g0;
     const int64_t total = by_gaussian ? 23 * n : i1 - i0;
@@ -82,8 +87,9 @@ __global__ __launch_bounds__(256) void k_adam4(int64_t N, float* __restrict__ me
                                                float* __restrict__ sh, int sh_stride,
                                                const float* __restrict__ grads, float* __restrict__ m,
                                                float* __restrict__ v, AdamK k, const int32_t* __restrict__ count_dev,
-                                               uint32_t count_cap, int64_t i0, int64_t i1, float* __restrict__ pstage) {
-    if (count_dev && ((uint32_t)count_dev[0] > count_cap || count_dev[4] != 0)) return;
+                                               uint32_t count_cap, const int32_t* __restrict__ status_dev, int64_t i0,
+                                               int64_t i1, float* __restrict__ pstage) {
+    if (ADAM_SKIP(count_dev, count_cap, status_dev)) return;
     const int64_t total4 = (i1 - i0) >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total4; j += stride) {
@@ -114,8 +120,8 @@ __global__ __launch_bounds__(256) void k_params_from_stage(int64_t N, float* __r
                                                            float* __restrict__ sh, int sh_stride,
                                                            const float* __restrict__ pstage, int64_t i0, int64_t i1,
                                                            int64_t lim, const int32_t* __restrict__ count_dev,
-                                                           uint32_t count_cap) {
-    if (count_dev && ((uint32_t)count_dev[0] > count_cap || count_dev[4] != 0)) return;
+                                                           uint32_t count_cap, const int32_t* __restrict__ status_dev) {
+    if (ADAM_SKIP(count_dev, count_cap, status_dev)) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < lim; i += stride) {
         if (i >= i0 && i < i1) continue;
@@ -135,8 +141,8 @@ static AdamK adam_constants(double lr, double b1, double b2, double eps, int ste
 // i0 < 0: the whole buffer.  [g0, g1) a proper sub-range of the Gaussians: that range instead of [i0, i1).
 int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities, float* sh,
                    int sh_stride, const float* grads, float* m, float* v, double lr, double b1, double b2,
-                   double eps, int step, const int32_t* count_dev, uint32_t count_cap, int64_t i0, int64_t i1,
-                   int64_t g0, int64_t g1, float* pstage, const float* gstage, float* grads_out) {
+                   double eps, int step, const int32_t* count_dev, uint32_t count_cap, const int32_t* status_dev, int64_t i0,
+                   int64_t i1, int64_t g0, int64_t g1, float* pstage, const float* gstage, float* grads_out) {
     if (N == 0) return ST3R_OK;
     if (i0 < 0) { i0 = 0; i1 = 23 * (int64_t)N; }
     if (g1 < 0) { g0 = 0; g1 = N; }
@@ -151,7 +157,7 @@ int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scal
         int blocks4 = ceil_div(total / 4, 256);
         if (blocks4 > 256 * 16) blocks4 = 256 * 16;
         hipLaunchKernelGGL(k_adam4, dim3(blocks4), dim3(256), 0, s, (int64_t)N, means, quats, scales, opacities, sh,
-                           sh_stride, grads, m, v, k, count_dev, count_cap, i0, i1, pstage);
+                           sh_stride, grads, m, v, k, count_dev, count_cap, status_dev, i0, i1, pstage);
         LAUNCH_CHECK();
         return ST3R_OK;
     }
@@ -159,32 +165,30 @@ int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scal
     int blocks = ceil_div(total, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, (int64_t)N, means, quats, scales, opacities, sh,
-                       sh_stride, grads, m, v, k, count_dev, count_cap, i0, i1, g0, g1, pstage, gstage, grads_out);
+                       sh_stride, grads, m, v, k, count_dev, count_cap, status_dev, i0, i1, g0, g1, pstage, gstage, grads_out);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
 
 int st3r_params_from_stage_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities,
                                 float* sh, int sh_stride, const float* pstage, int64_t i0, int64_t i1, int64_t lim,
-                                const int32_t* count_dev, uint32_t count_cap) {
+                                const int32_t* count_dev, uint32_t count_cap, const int32_t* status_dev) {
     if (lim <= 0) return ST3R_OK;
     int blocks = ceil_div(lim, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_params_from_stage, dim3(blocks), dim3(256), 0, s, (int64_t)N, means, quats, scales, opacities, sh,
-                       sh_stride, pstage, i0, i1, lim, count_dev, count_cap);
+                       sh_stride, pstage, i0, i1, lim, count_dev, count_cap, status_dev);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
 
 // the device-side guard of an asynchronous step that is still in flight (see k_adam)
-// (word 0 of the counts buffer: the record count of the step, compared with its capacity; word 4: the status word of
-// an exchanged step -- zero unless a communicator is attached.  With a communicator every step is sized exactly, so
-// only the status word guards: the capacity then is "no limit".)
+// (word 0 of the counts buffer: the record count of the step, compared with its capacity.  Word 4 of the same buffer is
+// the status word of an exchanged step; it is NOT part of this guard: st3r_gs_train_step hands it to the kernels itself.)
 void st3r_adam_guard(st3r_ctx* ctx, const int32_t** count_dev, uint32_t* count_cap) {
-    const bool have = ctx->slot_ptr[SLOT_COUNTS] != nullptr;
-    const bool guard = have && (ctx->count_pending || ctx->comm);
+    const bool guard = ctx->slot_ptr[SLOT_COUNTS] != nullptr && ctx->count_pending;
     *count_dev = guard ? (const int32_t*)ctx->slot_ptr[SLOT_COUNTS] : nullptr;
-    *count_cap = (guard && ctx->count_pending) ? (uint32_t)ctx->count_cap : 0xFFFFFFFFu;
+    *count_cap = guard ? (uint32_t)ctx->count_cap : 0xFFFFFFFFu;
 }
 
 ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
@@ -197,7 +201,7 @@ ST3R_EXPORT int st3r_adam_step(st3r_ctx* ctx, void* stream, int N, float* means,
     const int32_t* count_dev; uint32_t count_cap;
     st3r_adam_guard(ctx, &count_dev, &count_cap);
     int rc = st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr,
-                            beta1, beta2, eps, step, count_dev, count_cap, -1, -1, 0, -1, nullptr, nullptr, nullptr);
+                            beta1, beta2, eps, step, count_dev, count_cap, nullptr, -1, -1, 0, -1, nullptr, nullptr, nullptr);
     st3r_prof_end(ctx, (hipStream_t)stream, STG_ADAM);
     return rc;
 }
@@ -211,7 +215,7 @@ ST3R_EXPORT int st3r_adam_step_range(st3r_ctx* ctx, void* stream, int N, float* 
     const int32_t* count_dev; uint32_t count_cap;
     st3r_adam_guard(ctx, &count_dev, &count_cap);
     return st3r_adam_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1,
-                          beta2, eps, step, count_dev, count_cap, i0, i1, 0, -1, param_stage, nullptr, nullptr);
+                          beta2, eps, step, count_dev, count_cap, nullptr, i0, i1, 0, -1, param_stage, nullptr, nullptr);
 }
 
 ST3R_EXPORT int st3r_params_from_stage(st3r_ctx* ctx, void* stream, int N, float* means, float* quats, float* scales,
@@ -222,5 +226,5 @@ ST3R_EXPORT int st3r_params_from_stage(st3r_ctx* ctx, void* stream, int N, float
     const int32_t* count_dev; uint32_t count_cap;
     st3r_adam_guard(ctx, &count_dev, &count_cap);
     return st3r_params_from_stage_impl((hipStream_t)stream, N, means, quats, scales, opacities, sh, sh_stride, param_stage,
-                                       i0, i1, limit, count_dev, count_cap);
+                                       i0, i1, limit, count_dev, count_cap, nullptr);
 }

@@ -156,6 +156,7 @@ ST3R_EXPORT int st3r_comm_destroy(st3r_ctx* ctx) {
     RcclApi* api = rccl_api();
     if (api && ctx->comm_owned) (void)api->comm_destroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr; ctx->comm_owned = 0; ctx->comm_size = 0; ctx->comm_rank = 0;
+    ctx->peer_pending = 0;   // nobody is left to repeat a failed step with: a later single-process call must not report it
     return ST3R_OK;
 }
 
@@ -178,11 +179,11 @@ ST3R_EXPORT int st3r_grad_allreduce(st3r_ctx* ctx, void* stream, float* grads, i
 
 int st3r_adam_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities, float* sh,
                    int sh_stride, const float* grads, float* m, float* v, double lr, double b1, double b2,
-                   double eps, int step, const int32_t* count_dev, uint32_t count_cap, int64_t i0, int64_t i1,
-                   int64_t g0, int64_t g1, float* pstage, const float* gstage, float* grads_out);
+                   double eps, int step, const int32_t* count_dev, uint32_t count_cap, const int32_t* status_dev, int64_t i0,
+                   int64_t i1, int64_t g0, int64_t g1, float* pstage, const float* gstage, float* grads_out);
 int st3r_params_from_stage_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities,
                                 float* sh, int sh_stride, const float* pstage, int64_t i0, int64_t i1, int64_t lim,
-                                const int32_t* count_dev, uint32_t count_cap);
+                                const int32_t* count_dev, uint32_t count_cap, const int32_t* status_dev);
 void st3r_adam_guard(st3r_ctx* ctx, const int32_t** count_dev, uint32_t* count_cap);
 
 #define EXCH_RANGES_K 4
@@ -231,8 +232,9 @@ int st3r_peer_status_settle(st3r_ctx* ctx) {
     HIP_TRY(hipEventSynchronize(ctx->peer_event));
     ctx->peer_pending = 0;
     if (((volatile int32_t*)(ctx->pinned + PEER_PINNED))[0] != 0) {
-        st3r_set_error("the previous training step failed on another rank of the communicator: no rank applied its "
-                       "update (replicas are unchanged and identical) -- see that rank's error");
+        st3r_set_error("the previous training step failed on a rank of the communicator: no rank applied its "
+                       "update (replicas are unchanged and identical; every rank gets this code and repeats the step) "
+                       "-- see the failing rank's own error");
         return ST3R_ERR_PEER;
     }
     return ST3R_OK;
@@ -283,22 +285,43 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
     ctx->n_ranges = 0;
     char first_error[512];
     if (rc_local) snprintf(first_error, sizeof(first_error), "%s", st3r_last_error());
+    // From here on nothing returns early: a HIP / RCCL call of the exchange machinery that fails is remembered (the first
+    // one) and every remaining collective of the step is still issued -- an open ncclGroupStart is always closed, the
+    // other ranks are never left waiting for a launch this rank skipped.  Such a failure comes after the
+    // status word has travelled, so the other ranks cannot be told: this rank returns the error, see st3r.h.
+    int rc_mach = ST3R_OK;
+    char mach_error[512];
+#define SOFT_FAIL(what, why)                                                                                    \
+    do {                                                                                                        \
+        if (!rc_mach) { rc_mach = ST3R_ERR_HIP; snprintf(mach_error, sizeof(mach_error), "%s:%d: %s -> %s", __FILE__, __LINE__, what, why); } \
+    } while (0)
+#define SOFT_RCCL(expr)                                                       \
+    do {                                                                      \
+        ncclResult_t _r = (expr);                                             \
+        if (_r != ncclSuccess) SOFT_FAIL(#expr, api->get_error_string(_r));   \
+    } while (0)
+#define SOFT_HIP(expr)                                                        \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) SOFT_FAIL(#expr, hipGetErrorString(_e));        \
+    } while (0)
     // ---- the status word, reduced with the gradients
     const int64_t total = (int64_t)23 * N;
-    HIP_TRY(hipMemsetAsync(counts + PEER_WORD, rc_local ? 1 : 0, sizeof(int32_t), s));
+    SOFT_HIP(hipMemsetAsync(counts + PEER_WORD, rc_local ? 1 : 0, sizeof(int32_t), s));
     // (plain all-reduce form: the status word and the gradients travel as ONE grouped launch)
     const bool grouped = mode == ST3R_EXCHANGE_ALLREDUCE || (K == 1 && mode == ST3R_EXCHANGE_RANGES);
-    if (grouped) RCCL_TRY(api, api->group_start());
-    RCCL_TRY(api, api->all_reduce(counts + PEER_WORD, counts + PEER_WORD, 1, ncclInt32, ncclMax, comm, s));
+    if (grouped) SOFT_RCCL(api->group_start());
+    SOFT_RCCL(api->all_reduce(counts + PEER_WORD, counts + PEER_WORD, 1, ncclInt32, ncclMax, comm, s));
     if (grouped) {
-        RCCL_TRY(api, api->all_reduce(grads, grads, (size_t)total, ncclFloat32, ncclSum, comm, s));
-        RCCL_TRY(api, api->group_end());
+        SOFT_RCCL(api->all_reduce(grads, grads, (size_t)total, ncclFloat32, ncclSum, comm, s));
+        SOFT_RCCL(api->group_end());
     }
-    HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + PEER_PINNED), counts + PEER_WORD, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(ctx->peer_event, s));
+    SOFT_HIP(hipMemcpyAsync((int32_t*)(ctx->pinned + PEER_PINNED), counts + PEER_WORD, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SOFT_HIP(hipEventRecord(ctx->peer_event, s));
     ctx->peer_pending = 1;
     const int32_t* guard; uint32_t count_cap;
     st3r_adam_guard(ctx, &guard, &count_cap);
+    const int32_t* status = counts + PEER_WORD;   // the reduced status word: read by THIS step's update kernels only
     rc = ST3R_OK;
     if (mode == ST3R_EXCHANGE_RANGES && K > 1) {
         // ---- range-wise: all-reduce of range j behind its backward event, Adam of range j behind its all-reduce.
@@ -308,18 +331,18 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
         float* sendbuf = gstage ? gstage : grads;
         for (int j = 0; j < K; ++j) {
             const int64_t g0 = (int64_t)N * j / K, g1 = (int64_t)N * (j + 1) / K;
-            HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, gstage ? ctx->ev_range_bwd[j] : ctx->peer_event, 0));
-            RCCL_TRY(api, api->all_reduce(sendbuf + 23 * g0, sendbuf + 23 * g0, (size_t)(23 * (g1 - g0)), ncclFloat32, ncclSum,
+            SOFT_HIP(hipStreamWaitEvent(ctx->comm_stream, gstage ? ctx->ev_range_bwd[j] : ctx->peer_event, 0));
+            SOFT_RCCL(api->all_reduce(sendbuf + 23 * g0, sendbuf + 23 * g0, (size_t)(23 * (g1 - g0)), ncclFloat32, ncclSum,
                                           comm, ctx->comm_stream));
-            HIP_TRY(hipEventRecord(ctx->ev_range_red[j], ctx->comm_stream));
+            SOFT_HIP(hipEventRecord(ctx->ev_range_red[j], ctx->comm_stream));
         }
         st3r_prof_begin(ctx, s, STG_ADAM);
         for (int j = 0; j < K; ++j) {
             const int64_t g0 = (int64_t)N * j / K, g1 = (int64_t)N * (j + 1) / K;
-            HIP_TRY(hipStreamWaitEvent(s, ctx->ev_range_red[j], 0));
+            SOFT_HIP(hipStreamWaitEvent(s, ctx->ev_range_red[j], 0));
             if (gstage && !rc)
                 rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
-                                    step, guard, count_cap, -1, -1, g0, g1, nullptr, gstage, grads);
+                                    step, guard, count_cap, status, -1, -1, g0, g1, nullptr, gstage, grads);
         }
         st3r_prof_end(ctx, s, STG_ADAM);
     } else if (mode == ST3R_EXCHANGE_RS_AG) {
@@ -330,32 +353,36 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
         const int rc_ps = st3r_arena_get(ctx, SLOT_PSTAGE, sizeof(float) * (size_t)total, &ps);
         float* pstage = rc_ps ? nullptr : (float*)ps;
         if (rc_ps && !rc_local) { rc_local = rc_ps; snprintf(first_error, sizeof(first_error), "%s", st3r_last_error()); }
-        if (q > 0) RCCL_TRY(api, api->reduce_scatter(grads, grads + r * q, (size_t)q, ncclFloat32, ncclSum, comm, s));
-        if (total > tail0) RCCL_TRY(api, api->all_reduce(grads + tail0, grads + tail0, (size_t)(total - tail0), ncclFloat32, ncclSum, comm, s));
+        if (q > 0) SOFT_RCCL(api->reduce_scatter(grads, grads + r * q, (size_t)q, ncclFloat32, ncclSum, comm, s));
+        if (total > tail0) SOFT_RCCL(api->all_reduce(grads + tail0, grads + tail0, (size_t)(total - tail0), ncclFloat32, ncclSum, comm, s));
         st3r_prof_begin(ctx, s, STG_ADAM);
         if (pstage) {
             rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
-                                guard, count_cap, r * q, (r + 1) * q, 0, -1, pstage, nullptr, nullptr);
+                                guard, count_cap, status, r * q, (r + 1) * q, 0, -1, pstage, nullptr, nullptr);
             if (!rc && total > tail0)   // the remainder: every rank holds its sum and updates it itself
                 rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
-                                    step, guard, count_cap, tail0, total, 0, -1, nullptr, nullptr, nullptr);
+                                    step, guard, count_cap, status, tail0, total, 0, -1, nullptr, nullptr, nullptr);
         }
         st3r_prof_end(ctx, s, STG_ADAM);
         if (q > 0) {
             // (without a staging buffer -- this rank is failing -- the gradient buffer stands in: the others' pieces are
             // discarded everywhere, the status word says so)
             float* ag = pstage ? pstage : grads;
-            RCCL_TRY(api, api->all_gather(ag + r * q, ag, (size_t)q, ncclFloat32, comm, s));
+            SOFT_RCCL(api->all_gather(ag + r * q, ag, (size_t)q, ncclFloat32, comm, s));
             if (pstage && !rc)
                 rc = st3r_params_from_stage_impl(s, N, means, quats, scales, opacities, sh, sh_stride, pstage, r * q,
-                                                 (r + 1) * q, tail0, guard, count_cap);
+                                                 (r + 1) * q, tail0, guard, count_cap, status);
         }
     } else {   // (the gradients were all-reduced together with the status word above)
         st3r_prof_begin(ctx, s, STG_ADAM);
         rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
-                            guard, count_cap, -1, -1, 0, -1, nullptr, nullptr, nullptr);
+                            guard, count_cap, status, -1, -1, 0, -1, nullptr, nullptr, nullptr);
         st3r_prof_end(ctx, s, STG_ADAM);
     }
     if (rc_local) { st3r_set_error("%s", first_error); return rc_local; }
+    if (rc_mach) { st3r_set_error("%s", mach_error); return rc_mach; }
     return rc;
+#undef SOFT_HIP
+#undef SOFT_RCCL
+#undef SOFT_FAIL
 }

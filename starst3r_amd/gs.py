@@ -306,42 +306,46 @@ def run_3dgs_optim(
     def capacity_error(e):
         return getattr(e, "code", 0) == -3 and world == 1
 
-    step = 0
-    for _ in it_range:
-        if enable_pruning:
-            scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
-        st.step += 1
-        try:
-            one_iteration(step)
-        except _lib_mod.St3rError as e:
-            # ST3R_ERR_CAPACITY is reported by the call AFTER the asynchronous step that outgrew its buffers (> 25 % more
-            # tile intersections than the step before it).  That step's records past the capacity were dropped and its
-            # Adam update was skipped on the device (k_adam's guard), so no parameter update has to be undone: the lost
-            # iteration is repeated -- the context is back on the exactly sized path -- and then this one runs.  With
-            # enable_pruning the strategy hooks of the lost iteration have already run on the un-updated parameters
-            # (its position noise, and on a refinement step its relocation / growth): they are NOT run again, i.e. the
-            # noise of that one iteration is drawn before its update instead of after it.  A deviation of one step's
-            # noise (tests/test_gpu_api.py::test_run_3dgs_optim_repeats_...); overflows need > 25 % more tile
-            # intersections than the step before.
-            if not capacity_error(e):
-                raise
-            if step > 0:
-                st.step -= 1
-                one_iteration(step - 1)
-                st.step += 1
-            one_iteration(step)
-        if enable_pruning:
-            scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
-        step += 1
-    if world == 1 and iters > 0:
-        try:   # the last step's count is still in flight: settle it now so that an overflow cannot go unnoticed
-            ops.settle(ctx)
-        except _lib_mod.St3rError as e:
-            if not capacity_error(e):
-                raise
-            one_iteration(iters - 1)   # its update was skipped on the device: repeat it
-    if restore_exchange is not None:   # (the moments stay complete on every rank: rs_ag goes on using its own piece)
-        ops.set_exchange(ctx, restore_exchange)
+    # A peer failure (ST3R_ERR_PEER: the step before failed on some rank, nobody applied it) ABORTS the run on every rank
+    # alike -- all ranks get the code from the same call --; the exchange form is restored whatever ends the loop.
+    try:
+        step = 0
+        for _ in it_range:
+            if enable_pruning:
+                scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
+            st.step += 1
+            try:
+                one_iteration(step)
+            except _lib_mod.St3rError as e:
+                # ST3R_ERR_CAPACITY is reported by the call AFTER the asynchronous step that outgrew its buffers (> 25 % more
+                # tile intersections than the step before it).  That step's records past the capacity were dropped and its
+                # Adam update was skipped on the device (k_adam's guard), so no parameter update has to be undone: the lost
+                # iteration is repeated -- the context is back on the exactly sized path -- and then this one runs.  With
+                # enable_pruning the strategy hooks of the lost iteration have already run on the un-updated parameters
+                # (its position noise, and on a refinement step its relocation / growth): they are NOT run again, i.e. the
+                # noise of that one iteration is drawn before its update instead of after it.  A deviation of one step's
+                # noise (tests/test_gpu_api.py::test_run_3dgs_optim_repeats_...); overflows need > 25 % more tile
+                # intersections than the step before.
+                if not capacity_error(e):
+                    raise
+                if step > 0:
+                    st.step -= 1
+                    one_iteration(step - 1)
+                    st.step += 1
+                one_iteration(step)
+            if enable_pruning:
+                scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
+            step += 1
+        if world == 1 and iters > 0:
+            try:   # the last step's count is still in flight: settle it now so that an overflow cannot go unnoticed
+                ops.settle(ctx)
+            except _lib_mod.St3rError as e:
+                if not capacity_error(e):
+                    raise
+                one_iteration(iters - 1)   # its update was skipped on the device: repeat it
+    finally:
+        if restore_exchange is not None:   # (the moments stay complete on every rank: rs_ag goes on using its own piece)
+            ops.set_exchange(ctx, restore_exchange)
     _dist.all_reduce_sum(losses)
     return losses[:iters].cpu().tolist()   # one device->host copy for the whole call (reference: .item() per step)
 

@@ -193,6 +193,58 @@ def test_a_failing_rank_still_takes_part_and_nobody_applies_the_step(form):
         sdist.detach_native_comm(ctx)
 
 
+def test_standalone_adam_ignores_the_status_word_of_a_failed_exchanged_step():
+    """the status word of a failed exchanged step stays in the counts buffer until the next exchanged step
+    rewrites it.  Only st3r_gs_train_step's own update kernels may look at it: the documented composition
+    st3r_gs_train_fwd_bwd -> st3r_grad_allreduce -> st3r_adam_step must apply its update under the communicator right
+    after such a failure, and so must a single-process asynchronous step after the communicator is gone."""
+    from starst3r_amd import _lib, dist as sdist, ops
+    ctx, P, w2c, Ks, gt, W, H = _problem()
+    N = P["means"].shape[0]
+    campos = ops.camera_positions(w2c)
+    sdist.attach_native_comm(ctx)
+    attached = True
+    try:
+        A = {k: t.clone() for k, t in P.items()}
+        grads = torch.zeros(23 * N, device=DEV); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+        ops.set_debug(ctx, 2048)
+        with pytest.raises(_lib.St3rError):
+            _one_step(ctx, A, w2c, Ks, gt, W, H, 1, grads, m, v)           # leaves the status word at 1
+        ops.set_debug(ctx, 0)
+        loss = torch.zeros(1, device=DEV)
+        # the two-call composition, still under the communicator, WITHOUT settling first: the stale word must not matter
+        ops.train_fwd_bwd(ctx, A, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss, want_stats=True)
+        _lib.check(_lib.lib().st3r_grad_allreduce(ctx.handle, ops._stream(), ops._p(grads), grads.numel()))
+        ops.adam_step(ctx, A, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, 1)
+        torch.cuda.synchronize()
+        assert m.abs().max() > 0 and not torch.equal(A["means"], P["means"])   # applied, not silently skipped
+        with pytest.raises(_lib.St3rError) as e:                            # the failed step is still reported, once
+            ops.settle(ctx)
+        assert e.value.code == -5
+        B = {k: t.clone() for k, t in P.items()}
+        _one_step(ctx, B, w2c, Ks, gt, W, H, 1)
+        for k in A:
+            assert torch.equal(A[k], B[k]), k
+        # a second failure, then the communicator goes away: single-process steps (asynchronous ones included) apply
+        ops.set_debug(ctx, 2048)
+        with pytest.raises(_lib.St3rError):
+            _one_step(ctx, A, w2c, Ks, gt, W, H, 2, grads, m, v)
+        ops.set_debug(ctx, 0)
+        sdist.detach_native_comm(ctx); attached = False
+        before = A["means"].clone()
+        for it in range(3):
+            ops.train_step(ctx, A, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, 2 + it,
+                           loss, want_stats=False)
+            torch.cuda.synchronize()
+            assert not torch.equal(A["means"], before), it
+            before = A["means"].clone()
+        ops.settle(ctx)
+    finally:
+        ops.set_debug(ctx, 0)
+        if attached:
+            sdist.detach_native_comm(ctx)
+
+
 def test_allgather_pieces_replicates_piecewise_moments():
     from starst3r_amd import dist as sdist, ops
     ctx = ops.get_context(DEV)
