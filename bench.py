@@ -135,9 +135,11 @@ def cpu_baseline(args):
     scale = args.views * d * d
     return {
         "value": 1.0 / (t * scale), "unit": "iters/sec", "cores": 1, "kind": "port",
-        "sample": f"oracle/gs_oracle.c, 1 thread: 1 view {W}x{H}, {N} gaussians, fwd+loss+bwd+Adam took {t:.2f}s; "
-                  f"value = 1/(t*{scale}) i.e. scaled by views*{d * d} pixel area only (optimistic for the CPU: "
-                  f"the full scene also has {d * d}x more gaussians per pixel list)",
+        # (kept under 128 characters: the driver's record truncates longer strings)
+        "sample": f"C oracle, 1 thread: 1 view {W}x{H}, {N} gaussians, fwd+loss+bwd+Adam {t:.2f}s; value=1/(t*{scale}), "
+                  f"area-scaled only",
+        "sample_note": f"scaled by views * {d * d} (pixel area) only: optimistic for the CPU, the full scene also has "
+                       f"{d * d}x more gaussians per pixel list",
         "sample_seconds": t,
     }
 
@@ -254,7 +256,7 @@ def pmc_traffic(stage, N, views, W, H, world):
     if rec.get("csrc_fingerprint") != csrc_fingerprint():
         return None, f"stale: measured at commit {rec.get('commit')} on other kernel sources"
     v = rec.get("traffic_bytes_per_launch", {}).get(stage)
-    return v, f"profiles/pmc_traffic.json (commit {rec.get('commit')}, {rec.get('source')})"
+    return v, f"profiles/pmc_traffic.json @ {rec.get('commit')}: rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE per launch"
 
 
 CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md)
@@ -430,7 +432,10 @@ def matching_bench(device, with_cpu=True):
                "speedup": cpu_ms / ms}
     return {"query": f"{n} seeds x {H * W} descriptors, D={D}", "query_ms": ms, "cpu_baseline": cpu,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": tflops / 157.3,
-                         "note": "fp32 v_mfma_f32_32x32x2_f32; flops = 2*n*m*D, score matrix never written"},
+                         # tools/probe/mfma_f32_peak.hip on this part: back-to-back v_mfma_f32_32x32x2_f32, random operands
+                         "peak_measured": 153.4, "frac_of_measured": tflops / 153.4,
+                         "note": "fp32 v_mfma_f32_32x32x2_f32; flops = 2*n*m*D, score matrix never written; "
+                                 "time = arg-max kernel + per-query row resolution kernel"},
             "fast_reciprocal_NNs_ms": recip_ms, "matches": int(i1.numel()),
             "loop": "device resident (st3r_recip_nn), 10 reciprocal iterations, no host sync"}
 
@@ -665,9 +670,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"SYNTH-1M (BASELINE.json configs[2]): {N} gaussians, {args.views} views {W}x{H}, "
-                            f"3DGS train only; views sharded {C_local}/GPU, gaussians "
-                            + ("sharded" if mode == "gaussian-sharded" else "replicated"),
+                "workload": f"SYNTH-1M (BASELINE configs[2]): {N} gaussians, {args.views} views {W}x{H}, train only; "
+                            f"{C_local} views/GPU, gaussians " + ("sharded" if mode == "gaussian-sharded" else "replicated"),
                 "gaussians": N, "views": args.views, "width": W, "height": H, "views_per_gpu": C_local,
                 "parallelism": (f"gaussians+views sharded x{world} (2 all-to-all of splat records / iteration)"
                                 if mode == "gaussian-sharded"
@@ -681,9 +685,15 @@ def main():
                 "sort_key_bits": {"reference_single_key": keybits, "level1": key1_bits, "level2": key2_bits},
                 "mean_tiles_per_visible_gaussian": (I_kept / V) if V else 0.0,
                 "mean_records_per_tile": I_kept / (C_local * tw * th),
-                "loss_first": float(L[0]), "loss_last": float(L[-1]),
+                # loss of the first step and of the LAST TIMED step (step warmup + steps), the step psnr_db_after is taken
+                # at; the loss at the end of the untimed continuation (windows.drift_ms_per_step) has its own key
+                "loss_first": float(L[0]), "loss_last": float(L[total - 1]), "loss_last_step": total,
+                **({"loss_after_drift_continuation": float(L[-1]), "drift_continuation_to_step": int(len(L))}
+                   if drift else {}),
                 # training views of rank 0 against their GT, before the first and after the last of the warmup + timed steps
                 "psnr_db_before": psnr_before, "psnr_db_after": psnr_after,
+                **({"iters_per_sec_steps_180_200": 1e3 / drift["steps_180_200"],
+                    "ms_per_step_steps_180_200": drift["steps_180_200"]} if drift and "steps_180_200" in drift else {}),
             },
             # five windows of steps/5 consecutive steps inside the one timed region (HIP events on the launch stream)
             "windows": {"ms_per_step": win_ms, "median_ms_per_step": win_sorted[len(win_sorted) // 2],
@@ -703,8 +713,7 @@ def main():
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": ab[dom], "launch_ms": dom_ms,
-                "formula": "per-unit bytes of SURVEY.md 8(d) x units the launch processes (records = "
-                           "n_isects_kept_after_exact_culling), / mean launch time from HIP events in the timed region",
+                "formula": "SURVEY 8(d) bytes per unit x executed units (records = n_isects_kept) / mean launch ms (HIP events)",
                 "whole_iter": {"algorithmic_bytes": iter_bytes,
                                "achieved": iter_bytes / (ms_per_step * 1e-3) / 1e9,
                                "frac": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -718,10 +727,16 @@ def main():
                 "algorithmic_bytes_by_stage": ab,
                 "stage_ms": per_stage,
                 "stage_ms_samples_in_timed_region": timed_samples,
-                "stage_ms_source": f"HIP events in the timed region, one stage per step ({dom} on every other step, the "
-                                   "others in turn); a stage without a sample there: warm-up steps",
+                "stage_ms_source": f"HIP events in the timed region, one stage per step ({dom} every other step)",
             },
         }
+        # the same numbers once more as FLAT scalars (the driver's record keeps the scalars of this object and drops nested
+        # ones): ms per stage, the whole iteration against the roofline
+        out["roofline"].update({f"ms_{k}": v for k, v in per_stage.items()})
+        out["roofline"]["whole_iter_GBps"] = out["roofline"]["whole_iter"]["achieved"]
+        out["roofline"]["whole_iter_frac"] = out["roofline"]["whole_iter"]["frac"]
+        if drift and "steps_180_200" in drift:   # SURVEY 8(d)'s >= 200-step regime next to the driver's 20-step headline
+            out["value_steps_180_200"] = 1e3 / drift["steps_180_200"]
         out["roofline"]["valu_issue"] = valu_issue(per_stage, N, args.views, W, H, world)
         if world == 1 and not FREEZE and not args.no_scaling_model and mode != "gaussian-sharded":
             out["scaling_model"] = scaling_model(ctx, ops, g_np, w2c_np, Ks_np, N, args.views, W, H, device)

@@ -7,6 +7,10 @@ pixels 1e-4 relative, indices exact.
 
 Reference call sites: starster/gs.py:76-87 (gsplat.rasterization, sh_degree=1, everything else default),
 starster/gs.py:39,129 (torchmetrics StructuralSimilarityIndexMeasure(data_range=1))."""
+import importlib
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -18,13 +22,26 @@ from st3r_synth import synth
 DEV = "cuda:0"
 
 
+def _upstream(name):
+    """The upstream package `name`, or skip.  ST3R_UPSTREAM_PATH (os.pathsep-separated directories, e.g. a checkout of
+    gsplat with its built extension, or a site-packages directory of another environment) is put on sys.path first, so
+    a box that carries gsplat / torchmetrics ANYWHERE pins path C without an install (README.md, "Upstream pins")."""
+    for d in reversed([d for d in os.environ.get("ST3R_UPSTREAM_PATH", "").split(os.pathsep) if d]):
+        if os.path.isdir(d) and d not in sys.path:
+            sys.path.insert(0, d)
+    try:
+        return importlib.import_module(name)
+    except Exception as e:   # ImportError, or a binary extension built for another torch / device
+        pytest.skip(f"upstream package {name!r} not usable here ({type(e).__name__}: {e}); set ST3R_UPSTREAM_PATH")
+
+
 def _dev(a):
     return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=DEV)
 
 
 @pytest.mark.parametrize("N,V,W,H,lo,hi", [(3000, 2, 128, 96, 0.01, 0.05), (20000, 4, 320, 240, 0.004, 0.03)])
 def test_rasterization_against_gsplat(N, V, W, H, lo, hi):
-    gsplat = pytest.importorskip("gsplat")
+    gsplat = _upstream("gsplat")
     from starst3r_amd import ops
     ctx = ops.get_context(DEV)
     g, w2c, Ks = synth.make_scene(N, V, W, H, seed=4, scale_lo=lo, scale_hi=hi)
@@ -65,7 +82,7 @@ def test_rasterization_against_gsplat(N, V, W, H, lo, hi):
 
 @pytest.mark.parametrize("shape", [(1, 96, 128), (3, 240, 320)])
 def test_l1_ssim_against_torchmetrics(shape):
-    tm = pytest.importorskip("torchmetrics")
+    tm = _upstream("torchmetrics")
     from starst3r_amd import ops
     ctx = ops.get_context(DEV)
     V, H, W = shape
@@ -88,8 +105,8 @@ def test_l1_ssim_against_torchmetrics(shape):
 
 
 def test_mcmc_relocation_against_gsplat():
-    gsplat = pytest.importorskip("gsplat")
-    rel = pytest.importorskip("gsplat.relocation")
+    gsplat = _upstream("gsplat")
+    rel = _upstream("gsplat.relocation")
     from oracle import mcmc_oracle as mo
     rng = np.random.default_rng(0)
     n = 4096
