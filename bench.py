@@ -768,7 +768,7 @@ def main():
         forms_ms = {}
         keep = ops.get_exchange(ctx)
         it_x = total - 1
-        for form in ("allreduce", "ranges", "rs_ag"):
+        for form in ops.EXCHANGE_FORMS:
             ops.set_exchange(ctx, form)
             step(it_x)                                   # warm-up of the form (streams, staging buffers)
             dist.barrier(); torch.cuda.synchronize()

@@ -366,7 +366,17 @@ int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset,
  *   ST3R_EXCHANGE_RS_AG      reduce-scatter -> Adam on the rank's piece -> all-gather of the parameters; the Adam
  *                            moments are then maintained on the own piece only (st3r_comm_allgather_pieces replicates
  *                            them again before the form is left)
- * A communicator starts with the form the environment variable ST3R_EXCHANGE names (allreduce | ranges | rs_ag; read once,
+ *   ST3R_EXCHANGE_DIRECT     the same three steps without RCCL on the data path: every rank exports its gradient buffer,
+ *                            a parameter staging buffer and a row of flags through HIP IPC (set up collectively over the
+ *                            communicator the first time the form is used, and again when the Gaussian set outgrows
+ *                            the buffers); per step a rank READS its 1/w piece of the gradients from all peers over
+ *                            the point-to-point links and sums it in rank order (one owner per element: replicas are
+ *                            bit-identical by construction), runs Adam on the piece, and READS the other pieces of
+ *                            the updated parameters from their owners; two device-side barriers per step over the
+ *                            exported flags (bounded: a peer that never arrives is a failed step, not a hang), the
+ *                            step's status word travels with them.  Moments as under RS_AG.  st3r_comm_destroy is
+ *                            COLLECTIVE once this form has been used (nobody may unmap a buffer a peer still reads).
+ * A communicator starts with the form the environment variable ST3R_EXCHANGE names (allreduce | ranges | rs_ag | direct; read once,
  * when the communicator is created or attached; never written by the library), else with the all-reduce.  All ranks must
  * use the same form.
  *
@@ -384,6 +394,7 @@ int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset,
 #define ST3R_EXCHANGE_ALLREDUCE 0
 #define ST3R_EXCHANGE_RANGES 1
 #define ST3R_EXCHANGE_RS_AG 2
+#define ST3R_EXCHANGE_DIRECT 3
 int st3r_comm_set_exchange(st3r_ctx* ctx, int form);
 int st3r_comm_get_exchange(st3r_ctx* ctx, int* form);
 int st3r_comm_allgather_pieces(st3r_ctx* ctx, void* stream, float* buf, int64_t count);

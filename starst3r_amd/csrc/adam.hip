@@ -129,6 +129,34 @@ __global__ __launch_bounds__(256) void k_params_from_stage(int64_t N, float* __r
     }
 }
 
+// the same from the owners' staging buffers directly (direct exchange, comm.hip): piece p of the buffer -- scalars
+// [p q, (p + 1) q) -- is read from tab[p], a peer's exported staging buffer mapped through HIP IPC; own piece skipped
+__global__ __launch_bounds__(256) void k_params_from_peers(int64_t N, float* __restrict__ means, float* __restrict__ quats,
+                                                           float* __restrict__ scales, float* __restrict__ opacities,
+                                                           float* __restrict__ sh, int sh_stride,
+                                                           const float* const* __restrict__ tab, int r, int64_t q,
+                                                           int64_t lim, const int32_t* __restrict__ status_dev) {
+    if (status_dev && status_dev[0] != 0) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < lim; i += stride) {
+        const int p = (int)(i / q);
+        if (p == r) continue;
+        *adam_param(i, N, means, quats, scales, opacities, sh, sh_stride) = tab[p][i];
+    }
+}
+
+int st3r_params_from_peers_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities,
+                                float* sh, int sh_stride, const float* const* tab, int r, int64_t q, int64_t lim,
+                                const int32_t* status_dev) {
+    if (lim <= 0 || q <= 0) return ST3R_OK;
+    int blocks = ceil_div(lim, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_params_from_peers, dim3(blocks), dim3(256), 0, s, (int64_t)N, means, quats, scales, opacities, sh,
+                       sh_stride, tab, r, q, lim, status_dev);
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
 static AdamK adam_constants(double lr, double b1, double b2, double eps, int step) {
     AdamK k;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);

@@ -189,8 +189,8 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32,
                       int reg_overwrite, double* zero_ptr, int zero_n);
 int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
-                               int rect32, const int32_t* cum, int tile_w, int tile_h, uint32_t* tile_keys,
-                               int32_t* vals, int64_t cap);
+                               int rect32, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* vals, int64_t cap,
+                               int32_t* rec_count);
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
                               int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base,
                               void* rects, int rect32);
@@ -290,7 +290,10 @@ int st3r_counts_buffer(st3r_ctx* ctx, hipStream_t s, int32_t** out) {
     }
 
 struct RasterOut {
-    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; const uint64_t* rects; uint64_t* rectbase; int64_t n_isects, n_isects_ref, n_visible; int tile_w, tile_h;
+    float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; const uint64_t* rects; uint64_t* rectbase;
+    // n_isects: the slot count (sum of the rectangle areas) = capacity of everything indexed by record or slot;
+    // n_records: the records actually emitted (masked rectangles, tile_rect.h), -1 while the count stays on the device
+    int64_t n_isects, n_records, n_isects_ref, n_visible; int tile_w, tile_h;
 };
 
 // project -> scan -> emit -> sort -> offsets, all in ctx scratch
@@ -329,9 +332,9 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_DVALS_A, int32_t, n_sort, dvals_a);
     GET(SLOT_DVALS_B, int32_t, n_sort, perm);
     // packed tile rectangle of every pair (pair-id order; the tile count of a pair is the area of its rectangle, no
-    // array of its own): 32-bit entries for tile grids up to 255 x 255 (tile_rect.h), 64-bit beyond -- and under debug
+    // array of its own): 32-bit entries for tile grids up to 255 x 127 (tile_rect.h), 64-bit beyond -- and under debug
     // flag 64, whose backward reads the 64-bit form
-    const int rect32 = (tile_w <= 255 && tile_h <= 255 && !(ctx->debug_flags & 64)) ? 1 : 0;
+    const int rect32 = (tile_w <= 255 && tile_h <= 127 && !(ctx->debug_flags & 64)) ? 1 : 0;
     GET(SLOT_RECTS, uint64_t, rect32 ? (n_pairs + 1) / 2 : n_pairs, rects);
     st3r_prof_begin(ctx, s, STG_PROJECT);
     const uint32_t key_base = key32 ? near_bits : 0u;
@@ -340,7 +343,11 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
                                              key_base, rects, rect32)
                  : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
                                      W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, nullptr, reg_sums, dkeys_a,
-                                     dvals_a, tight, key_base, rects, rect32, 1, loss_sums, 2 * C);
+                                     // (tight = 2, debug flag 4096: small rectangles also carry the exact tile mask -- 6 %
+                                     // fewer records on SYNTH-1M, measured NOT faster: the mask costs the projection what
+                                     // the record-proportional stages save, tools/experiments/README.md; off by default)
+                                     dvals_a, (tight && (ctx->debug_flags & 4096)) ? 2 : tight, key_base, rects, rect32, 1,
+                                     loss_sums, 2 * C);
     if (!rc && records_in && loss_sums) HIP_TRY(hipMemsetAsync(loss_sums, 0, sizeof(double) * 2 * (size_t)C, s));
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
@@ -370,16 +377,17 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     const int64_t sig = ((int64_t)N << 34) ^ ((int64_t)C << 26) ^ ((int64_t)W << 13) ^ (int64_t)H;
     const bool async = allow_async && ctx->isect_hint > 0 && ctx->hint_sig == sig;
     int32_t* counts = nullptr;
-    if (async) { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
+    { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
+    int32_t* const rec_count = counts + 8;   // the records the emission writes (<= the scan's total: masked rectangles)
     int32_t* total_dev = nullptr;
-    rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev, counts);
+    rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev,
+                              async ? counts : nullptr);
     st3r_prof_end(ctx, s, STG_SCAN);
     if (rc) return rc;
     if (async) {
         HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + 8), total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (!ctx->count_event) HIP_TRY(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ctx->count_event, s));
-        n_dev = counts;
         n_isects = ctx->isect_hint + ctx->isect_hint / 4 + 1024;   // capacity, not the count
         if (ctx->debug_flags & 8) n_isects = ctx->isect_hint / 2;   // test hook: provoke a capacity overflow
         if (n_isects > 2147483647LL) n_isects = 2147483647LL;
@@ -402,11 +410,24 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_KEYS_B, uint32_t, n_isects, tkeys_b);
     GET(SLOT_VALS_A, int32_t, n_isects, vals_a);
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
+    // the sort and the offsets read the record count from device memory in both paths: the emission leaves it there
+    n_dev = rec_count;
+    o->n_records = -1;
+    if (n_isects == 0) {   // nothing visible: no emission runs, the count word is set here
+        HIP_TRY(hipMemsetAsync(rec_count, 0, sizeof(int32_t), s));
+        o->n_records = 0;
+    }
     if (n_isects > 0) {
         st3r_prof_begin(ctx, s, STG_EMIT);
-        rc = st3r_isect_emit_chain_impl(ctx, s, N, C, perm, rects, rect32, cum, tile_w, tile_h, tkeys_a, vals_a, n_isects);
+        rc = st3r_isect_emit_chain_impl(ctx, s, N, C, perm, rects, rect32, tile_w, tile_h, tkeys_a, vals_a, n_isects,
+                                        rec_count);
         st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
+        if (!async) {   // exact statistics for the caller of the synchronous path (one more 4-byte round trip)
+            HIP_TRY(hipMemcpyAsync(ctx->pinned, rec_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            o->n_records = (int64_t)((int32_t*)ctx->pinned)[0];
+        }
         const int end_bit = bit_length_u32((uint32_t)((int64_t)C * tile_w * tile_h - 1));
         st3r_prof_begin(ctx, s, STG_SORT);
         rc = st3r_sort_tile_impl(ctx, s, n_isects, end_bit, tkeys_a, vals_a, tkeys_b, vals_b, n_dev);
@@ -542,7 +563,7 @@ ST3R_EXPORT int st3r_gs_train_fwd_bwd(st3r_ctx* ctx, void* stream, int N, int C,
                              Ks + 9 * c0, campos + 3 * c0, gt_images + (int64_t)c0 * H * W * 3, W, H, ssim_fac, opac_fac,
                              scale_fac, sums + 2 * c0, rs, stats_host == nullptr && chunks == 1 && !ctx->comm, !first, grads,
                              &ro);
-            if (!rc) { st_vis += ro.n_visible; st_is += ro.n_isects; st_ref += ro.n_isects_ref; }
+            if (!rc) { st_vis += ro.n_visible; st_is += ro.n_records; st_ref += ro.n_isects_ref; }
             first = false;
         }
         if (rc == ST3R_SPLIT_VIEWS && chunks < C) {
@@ -615,7 +636,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
                        cnt > 0 ? 1.0 / cnt : 0.0, (double)(1.0f - ssim_fac), (double)ssim_fac, 0.0, 0.0, 0.0, loss_out);
     LAUNCH_CHECK();
     if (stats_host) {
-        stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = -1;
+        stats_host[0] = -1; stats_host[1] = ro.n_records; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = -1;
     }
     return ST3R_OK;
 }
@@ -641,7 +662,7 @@ ST3R_EXPORT int st3r_gs_render(st3r_ctx* ctx, void* stream, int N, int C, const 
                              ro.n_isects, rgb, alpha, last, false, true);
     if (rc) return rc;
     if (stats_host) {
-        stats_host[0] = -1; stats_host[1] = ro.n_isects; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = 0;
+        stats_host[0] = -1; stats_host[1] = ro.n_records; stats_host[2] = st3r_ctx_arena_bytes(ctx); stats_host[3] = 0;
     }
     return ST3R_OK;
 }

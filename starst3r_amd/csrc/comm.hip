@@ -21,19 +21,31 @@
 //   rs_ag      reduce-scatter -> Adam on the rank's 1/w of the buffer (moments m, v are only maintained there: 2 x 92 MB
 //              of optimizer state become 2 x 92/w MB of live state) -> all-gather of the updated parameters through a
 //              staging buffer in gradient-buffer order -> a copy into the parameter tensors.  The same bytes on the links
-//              as an all-reduce (which IS a reduce-scatter + all-gather), but on the point-to-point xGMI mesh the two
-//              halves are direct sends -- 7 links x 1/8 of the buffer each -- instead of a ring, and the replicated
-//              0.14 ms Adam shrinks to 1/w.  The buffer is cut into w equal contiguous pieces in BUFFER order (Adam is
-//              element-wise over the 23N scalars, so a piece need not respect Gaussian boundaries); the < w floats that
-//              do not divide are all-reduced and updated by everyone.
+//              as an all-reduce (which IS a reduce-scatter + all-gather); the replicated 0.14 ms Adam shrinks to 1/w.
+//              WHICH algorithm RCCL runs for ncclReduceScatter / ncclAllGather on the xGMI mesh is RCCL's choice and
+//              unknown here (round 4 claimed "direct sends": unverified -- a one-rank communicator prints no tuning
+//              decision, profiles/r5_rccl_one_rank_probe.md; RCCL's default for both is a ring).  The buffer is cut into
+//              w equal contiguous pieces in BUFFER order (Adam is element-wise over the 23N scalars, so a piece need
+//              not respect Gaussian boundaries); the < w floats that do not divide are all-reduced and updated by everyone.
+//   direct     (round 5) the same three steps with NO RCCL call on the data path, i.e. the algorithm is this file's, not
+//              a tuner's: every rank exports its gradient buffer, a parameter staging buffer and a row of flags through
+//              HIP IPC; per step a rank reads ITS piece of the gradients from all w - 1 peers (w - 1 point-to-point
+//              links at once, 1/w of the buffer over each) and adds them in rank order, runs Adam on the piece, and reads
+//              the other pieces of the updated parameters from their owners.  One owner per element: replicas are
+//              bit-identical by construction.  Two device-side barriers per step (k_xbar: system-scope flags in the
+//              peers' exported rows, bounded spin); the step's status word rides on them.  Set-up / tear-down are
+//              collective (handles travel through one ncclAllGather).  SURVEY section 5's "direct RS + AG over IPC buffers".
 // None of this has run on more than one GPU (the builder's and the round-end box have one): tests/test_gpu_multi.py
-// spawns one process per visible GPU and checks all three against the single-GPU step as soon as two are visible;
-// tests/test_gpu_comm.py runs all three with a one-rank communicator.
+// spawns one process per visible GPU and checks all four against the single-GPU step as soon as two are visible; on one
+// GPU it runs them with emulated ranks -- `direct` then moves its data through REAL same-device HIP IPC mappings and real
+// device-side barriers between processes; tests/test_gpu_comm.py runs all four with a one-rank communicator.
 //
 // RCCL is resolved at run time with dlopen (the copy already mapped into the process, e.g. the one a host
 // framework ships, is preferred) so the library keeps loading on hosts without RCCL; only the comm entry
 // points then fail, loudly.
 #include <dlfcn.h>
+
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -104,11 +116,13 @@ static int exchange_from_env() {
     const char* e = getenv("ST3R_EXCHANGE");
     if (e && !strcmp(e, "ranges")) return ST3R_EXCHANGE_RANGES;
     if (e && !strcmp(e, "rs_ag")) return ST3R_EXCHANGE_RS_AG;
+    if (e && !strcmp(e, "direct")) return ST3R_EXCHANGE_DIRECT;
     return ST3R_EXCHANGE_ALLREDUCE;
 }
 
 ST3R_EXPORT int st3r_comm_set_exchange(st3r_ctx* ctx, int form) {
-    ARG_CHECK(ctx && (form == ST3R_EXCHANGE_ALLREDUCE || form == ST3R_EXCHANGE_RANGES || form == ST3R_EXCHANGE_RS_AG));
+    ARG_CHECK(ctx && (form == ST3R_EXCHANGE_ALLREDUCE || form == ST3R_EXCHANGE_RANGES || form == ST3R_EXCHANGE_RS_AG ||
+                      form == ST3R_EXCHANGE_DIRECT));
     ctx->exchange = form;
     return ST3R_OK;
 }
@@ -151,9 +165,12 @@ ST3R_EXPORT int st3r_comm_attach(st3r_ctx* ctx, void* rccl_comm, int world_size,
     return ST3R_OK;
 }
 
+static void xwin_destroy(st3r_ctx* ctx, RcclApi* api);
+
 ST3R_EXPORT int st3r_comm_destroy(st3r_ctx* ctx) {
     if (!ctx || !ctx->comm) return ST3R_OK;
     RcclApi* api = rccl_api();
+    if (ctx->xwin) xwin_destroy(ctx, api);   // (collective: see st3r.h)
     if (api && ctx->comm_owned) (void)api->comm_destroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr; ctx->comm_owned = 0; ctx->comm_size = 0; ctx->comm_rank = 0;
     ctx->peer_pending = 0;   // nobody is left to repeat a failed step with: a later single-process call must not report it
@@ -240,6 +257,170 @@ int st3r_peer_status_settle(st3r_ctx* ctx) {
     return ST3R_OK;
 }
 
+// ---- direct exchange: peer windows over HIP IPC ----
+#define XW_MAX_RANKS 64
+struct XWindow {
+    int w, r;
+    size_t cap;                                   // floats per data buffer
+    float* grad; float* param; unsigned long long* flag;   // this rank's exported buffers (flag: XW_MAX_RANKS words)
+    int flag_uncached;
+    void* peer[3][XW_MAX_RANKS];                  // [grad | param | flag][rank]: mapped peers, own entries = own buffers
+    void** dev_tab;                               // the same three tables on the device: dev_tab + k * XW_MAX_RANKS
+    unsigned long long gen;                       // barrier generation (the same on every rank: lockstep)
+    long long timeout_ticks;                      // bound of a barrier's spin (100 MHz ticks)
+};
+struct XHandles { hipIpcMemHandle_t h[3]; };
+
+static void xwin_free_local(XWindow* x) {
+    for (int k = 0; k < 3; ++k)
+        for (int p = 0; p < x->w; ++p)
+            if (p != x->r && x->peer[k][p]) (void)hipIpcCloseMemHandle(x->peer[k][p]);
+    if (x->grad) (void)hipFree(x->grad);
+    if (x->param) (void)hipFree(x->param);
+    if (x->flag) (void)hipFree(x->flag);
+    if (x->dev_tab) (void)hipFree(x->dev_tab);
+    delete x;
+}
+
+// every rank has finished reading its peers (device idle) AND everybody knows it (one tiny all-reduce, synchronised):
+// only then may the mappings and the buffers go
+static void xwin_destroy(st3r_ctx* ctx, RcclApi* api) {
+    XWindow* x = (XWindow*)ctx->xwin;
+    ctx->xwin = nullptr;
+    (void)hipDeviceSynchronize();
+    int32_t* word = nullptr;
+    if (api && x->w > 1 && hipMalloc((void**)&word, sizeof(int32_t)) == hipSuccess) {
+        (void)hipMemset(word, 0, sizeof(int32_t));
+        (void)api->all_reduce(word, word, 1, ncclInt32, ncclMax, (ncclComm_t)ctx->comm, nullptr);
+        (void)hipStreamSynchronize(nullptr);
+        (void)hipFree(word);
+    }
+    xwin_free_local(x);
+}
+
+// (Re)builds the window for `total` floats per buffer.  COLLECTIVE: all ranks call it in the same step (they hold the
+// same Gaussian count, so they decide alike).  The handles travel through one ncclAllGather on device memory.
+static int xwin_ensure(st3r_ctx* ctx, RcclApi* api, hipStream_t s, int64_t total) {
+    XWindow* x = (XWindow*)ctx->xwin;
+    if (x && x->cap >= (size_t)total && x->w == ctx->comm_size) return ST3R_OK;
+    if (ctx->comm_size > XW_MAX_RANKS) { st3r_set_error("direct exchange: at most %d ranks", XW_MAX_RANKS); return ST3R_ERR_INVALID; }
+    if (x) xwin_destroy(ctx, api);
+    HIP_TRY(hipStreamSynchronize(s));
+    x = new XWindow();
+    memset(x, 0, sizeof(*x));
+    x->w = ctx->comm_size; x->r = ctx->comm_rank;
+    x->cap = (size_t)total + (size_t)total / 4 + 1024;   // head-room for a growing Gaussian set (the same on every rank)
+    const char* te = getenv("ST3R_XBAR_TIMEOUT_MS");
+    x->timeout_ticks = (long long)(te ? atof(te) : 20000.0) * 100000LL;   // 100 MHz
+#define XW_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            st3r_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+            xwin_free_local(x);                                                                   \
+            return ST3R_ERR_HIP;                                                                  \
+        }                                                                                         \
+    } while (0)
+    XW_TRY(hipMalloc((void**)&x->grad, sizeof(float) * x->cap));
+    XW_TRY(hipMalloc((void**)&x->param, sizeof(float) * x->cap));
+    // the flags are written by peers while this rank's kernel polls them: uncached (fine-grained) memory where the
+    // runtime exports it, ordinary device memory + system-scope atomics otherwise
+    x->flag_uncached = 1;
+    if (hipExtMallocWithFlags((void**)&x->flag, sizeof(unsigned long long) * XW_MAX_RANKS, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        x->flag_uncached = 0;
+        XW_TRY(hipMalloc((void**)&x->flag, sizeof(unsigned long long) * XW_MAX_RANKS));
+    }
+    XW_TRY(hipMemset(x->flag, 0, sizeof(unsigned long long) * XW_MAX_RANKS));
+    XHandles mine;
+    memset(&mine, 0, sizeof(mine));
+    if (x->w > 1) {
+        XW_TRY(hipIpcGetMemHandle(&mine.h[0], x->grad));
+        XW_TRY(hipIpcGetMemHandle(&mine.h[1], x->param));
+        if (hipIpcGetMemHandle(&mine.h[2], x->flag) != hipSuccess && x->flag_uncached) {   // not exportable: plain memory
+            (void)hipGetLastError();
+            (void)hipFree(x->flag); x->flag = nullptr; x->flag_uncached = 0;
+            XW_TRY(hipMalloc((void**)&x->flag, sizeof(unsigned long long) * XW_MAX_RANKS));
+            XW_TRY(hipMemset(x->flag, 0, sizeof(unsigned long long) * XW_MAX_RANKS));
+            XW_TRY(hipIpcGetMemHandle(&mine.h[2], x->flag));
+        }
+    }
+    x->peer[0][x->r] = x->grad; x->peer[1][x->r] = x->param; x->peer[2][x->r] = x->flag;
+    if (x->w > 1) {
+        static_assert(sizeof(XHandles) % 4 == 0, "handles travel as int32 words");
+        char* hb = nullptr;
+        XW_TRY(hipMalloc((void**)&hb, sizeof(XHandles) * x->w));
+        XW_TRY(hipMemcpy(hb + sizeof(XHandles) * x->r, &mine, sizeof(XHandles), hipMemcpyHostToDevice));
+        ncclResult_t nr = api->all_gather(hb + sizeof(XHandles) * x->r, hb, sizeof(XHandles) / 4, ncclInt32,
+                                          (ncclComm_t)ctx->comm, s);
+        if (nr != ncclSuccess) {
+            st3r_set_error("direct exchange: ncclAllGather of the IPC handles -> %s", api->get_error_string(nr));
+            (void)hipFree(hb); xwin_free_local(x);
+            return ST3R_ERR_HIP;
+        }
+        std::vector<XHandles> all(x->w);
+        XW_TRY(hipMemcpyAsync(all.data(), hb, sizeof(XHandles) * x->w, hipMemcpyDeviceToHost, s));
+        XW_TRY(hipStreamSynchronize(s));
+        (void)hipFree(hb);
+        for (int p = 0; p < x->w; ++p) {
+            if (p == x->r) continue;
+            for (int k = 0; k < 3; ++k) XW_TRY(hipIpcOpenMemHandle(&x->peer[k][p], all[p].h[k], hipIpcMemLazyEnablePeerAccess));
+        }
+    }
+    XW_TRY(hipMalloc((void**)&x->dev_tab, sizeof(void*) * 3 * XW_MAX_RANKS));
+    XW_TRY(hipMemcpy(x->dev_tab, x->peer, sizeof(void*) * 3 * XW_MAX_RANKS, hipMemcpyHostToDevice));
+#undef XW_TRY
+    ctx->xwin = x;
+    return ST3R_OK;
+}
+
+// Barrier between the ranks on the device: thread p tells peer p "rank r has arrived at `gen`" (one system-scope store into
+// the peer's exported row, the step's failure bit in the low bits) and waits for peer p's word in this rank's own row.
+// A peer can be at most ONE barrier ahead (it cannot leave barrier gen + 1 before this rank arrives there), and both
+// barriers of a step carry the step's failure bit, so whichever word is read tells the truth about the step.  The wait is
+// bounded: a peer that does not arrive within the time-out marks the step failed (2) instead of hanging the device.
+// status_out (first barrier of a step only): the OR over the ranks -- the same word the other forms max-all-reduce.
+__global__ __launch_bounds__(XW_MAX_RANKS) void k_xbar(unsigned long long* const* __restrict__ flag_tab, int w, int r,
+                                                       unsigned long long gen, int my_fail, long long timeout_ticks,
+                                                       int32_t* __restrict__ status_out) {
+    __shared__ int s_any;
+    const int p = threadIdx.x;
+    if (p == 0) s_any = my_fail ? 1 : 0;
+    __syncthreads();
+    if (p < w && p != r) {
+        __hip_atomic_store(flag_tab[p] + r, (gen << 2) | (my_fail ? 1ull : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        unsigned long long v;
+        for (;;) {
+            v = __hip_atomic_load(flag_tab[r] + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((v >> 2) >= gen) break;
+            if (wall_clock64() - t0 > timeout_ticks) { v = 2ull; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (v & 3ull) atomicOr(&s_any, (int)(v & 3ull));
+    }
+    __syncthreads();
+    if (p == 0 && status_out) *status_out = s_any;
+    __threadfence_system();
+}
+
+// out[i] = sum over the ranks, in rank order, of their exported gradient buffers, for i in [i0, i1) and [t0, t1)
+__global__ __launch_bounds__(256) void k_xreduce(const float* const* __restrict__ grad_tab, int w, int64_t i0, int64_t i1,
+                                                 int64_t t0, int64_t t1, float* __restrict__ out) {
+    const int64_t n = (i1 - i0) + (t1 - t0);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const int64_t i = j < i1 - i0 ? i0 + j : t0 + (j - (i1 - i0));
+        float acc = grad_tab[0][i];
+        for (int p = 1; p < w; ++p) acc += grad_tab[p][i];
+        out[i] = acc;
+    }
+}
+
+int st3r_params_from_peers_impl(hipStream_t s, int N, float* means, float* quats, float* scales, float* opacities,
+                                float* sh, int sh_stride, const float* const* tab, int r, int64_t q, int64_t lim,
+                                const int32_t* status_dev);
+
 // One whole iteration of starster/gs.py:143-164 for this rank's C views: render -> loss -> backward ->
 // (exchange of the gradients when a communicator is attached: see the head of this file) -> Adam.  Asynchronous apart
 // from the intersection-count read-back inside the rasterizer.
@@ -277,11 +458,20 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
         if (rc) return rc;
         ctx->n_ranges = K;
     }
+    // direct form: the window is (re)built first -- collectively, every rank sees the same N -- and the backward leaves
+    // this rank's gradients in its EXPORTED buffer (the caller's buffer receives the reduced piece)
+    XWindow* xw = nullptr;
+    if (mode == ST3R_EXCHANGE_DIRECT) {
+        rc = xwin_ensure(ctx, api, s, (int64_t)23 * N);
+        if (rc) return rc;
+        xw = (XWindow*)ctx->xwin;
+    }
+    float* const grads_local = xw ? xw->grad : grads;
     int rc_local = (ctx->debug_flags & 2048)   // test hook: this rank "fails" before it has computed anything
                        ? (st3r_set_error("debug flag 2048: simulated failure of this rank's step"), ST3R_ERR_NOMEM)
                        : st3r_gs_train_fwd_bwd(ctx, stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats,
-                                               Ks, campos, gt_images, width, height, ssim_fac, opac_fac, scale_fac, grads,
-                                               loss_out, stats_host);
+                                               Ks, campos, gt_images, width, height, ssim_fac, opac_fac, scale_fac,
+                                               grads_local, loss_out, stats_host);
     ctx->n_ranges = 0;
     char first_error[512];
     if (rc_local) snprintf(first_error, sizeof(first_error), "%s", st3r_last_error());
@@ -307,11 +497,18 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
     } while (0)
     // ---- the status word, reduced with the gradients
     const int64_t total = (int64_t)23 * N;
-    SOFT_HIP(hipMemsetAsync(counts + PEER_WORD, rc_local ? 1 : 0, sizeof(int32_t), s));
+    if (xw) {   // direct form: the first barrier of the step carries the status word
+        ++xw->gen;
+        hipLaunchKernelGGL(k_xbar, dim3(1), dim3(XW_MAX_RANKS), 0, s, (unsigned long long* const*)(xw->dev_tab + 2 * XW_MAX_RANKS),
+                           xw->w, xw->r, xw->gen, rc_local ? 1 : 0, xw->timeout_ticks, counts + PEER_WORD);
+        SOFT_HIP(hipGetLastError());
+    } else {
+        SOFT_HIP(hipMemsetAsync(counts + PEER_WORD, rc_local ? 1 : 0, sizeof(int32_t), s));
+    }
     // (plain all-reduce form: the status word and the gradients travel as ONE grouped launch)
     const bool grouped = mode == ST3R_EXCHANGE_ALLREDUCE || (K == 1 && mode == ST3R_EXCHANGE_RANGES);
     if (grouped) SOFT_RCCL(api->group_start());
-    SOFT_RCCL(api->all_reduce(counts + PEER_WORD, counts + PEER_WORD, 1, ncclInt32, ncclMax, comm, s));
+    if (!xw) SOFT_RCCL(api->all_reduce(counts + PEER_WORD, counts + PEER_WORD, 1, ncclInt32, ncclMax, comm, s));
     if (grouped) {
         SOFT_RCCL(api->all_reduce(grads, grads, (size_t)total, ncclFloat32, ncclSum, comm, s));
         SOFT_RCCL(api->group_end());
@@ -373,6 +570,32 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
                 rc = st3r_params_from_stage_impl(s, N, means, quats, scales, opacities, sh, sh_stride, pstage, r * q,
                                                  (r + 1) * q, tail0, guard, count_cap, status);
         }
+    } else if (mode == ST3R_EXCHANGE_DIRECT) {
+        // ---- own piece summed from the peers' exported buffers -> Adam on it -> barrier -> the other pieces of the
+        // parameters from their owners' staging buffers
+        const int w = xw->w, r = xw->r;
+        const int64_t q = total / w, tail0 = q * w;
+        int blocks = ceil_div(q + (total - tail0), 256 * 4);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(k_xreduce, dim3(blocks), dim3(256), 0, s, (const float* const*)xw->dev_tab, w, r * q, (r + 1) * q,
+                           tail0, total, grads);
+        SOFT_HIP(hipGetLastError());
+        st3r_prof_begin(ctx, s, STG_ADAM);
+        if (q > 0)
+            rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,
+                                guard, count_cap, status, r * q, (r + 1) * q, 0, -1, xw->param, nullptr, nullptr);
+        if (!rc && total > tail0)   // the remainder: every rank summed it itself and updates it itself
+            rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps,
+                                step, guard, count_cap, status, tail0, total, 0, -1, nullptr, nullptr, nullptr);
+        st3r_prof_end(ctx, s, STG_ADAM);
+        ++xw->gen;
+        hipLaunchKernelGGL(k_xbar, dim3(1), dim3(XW_MAX_RANKS), 0, s, (unsigned long long* const*)(xw->dev_tab + 2 * XW_MAX_RANKS),
+                           w, r, xw->gen, rc_local ? 1 : 0, xw->timeout_ticks, (int32_t*)nullptr);
+        SOFT_HIP(hipGetLastError());
+        if (!rc)
+            rc = st3r_params_from_peers_impl(s, N, means, quats, scales, opacities, sh, sh_stride,
+                                             (const float* const*)(xw->dev_tab + XW_MAX_RANKS), r, q, tail0, status);
     } else {   // (the gradients were all-reduced together with the status word above)
         st3r_prof_begin(ctx, s, STG_ADAM);
         rc = st3r_adam_impl(s, N, means, quats, scales, opacities, sh, sh_stride, grads, m, v, lr, beta1, beta2, eps, step,

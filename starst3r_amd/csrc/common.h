@@ -106,7 +106,8 @@ struct st3r_ctx {
                       // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks;
                       // 6: backward gathers rectangle and slot base separately; 7 (128): training forward on the quadrant
                       // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 11 (2048): under a communicator
-                      // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip)
+                      // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip); 12 (4096): the fused
+                      // path drops the tiles of small rectangles that the exact ellipse test rejects (masked rectangles)
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     uint32_t scan_gen;   // single-pass scan (gs_isect.hip): generation of its status words
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back
@@ -125,6 +126,7 @@ struct st3r_ctx {
     // range; the ranges' all-reduces run on comm_stream behind those events, Adam per range behind the all-reduces
     hipStream_t comm_stream;
     hipEvent_t ev_range_bwd[ST3R_MAX_RANGES], ev_range_red[ST3R_MAX_RANGES];
+    void* xwin;              // direct exchange (comm.hip): this rank's exported buffers and the peers' mapped ones
     int n_ranges;            // > 1: train_views splits the projection backward (set by st3r_gs_train_step for one call)
     int ranges_recorded;     // how many ev_range_bwd the last train_views recorded (0: it ran as one launch)
     int prof_enabled;

@@ -459,10 +459,10 @@ int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, 
 //                    depth order, plus the workgroup's tile count.  With eight views (or a multiple) the workgroups of
 //                    a camera run on one XCD (workgroup b runs on XCD b % 8), whose L2 then serves that camera's
 //                    rectangles: 4 MB at 1 M Gaussians in the 32-bit form;
-//   k_isect_emit     the same workgroup shape: scans its pairs' tile counts (rectangle areas), finds its first output
-//                    position as  cum[c N - 1]  (pair ids are camera-major too: the first record of camera c sits at the
-//                    pair-order scan's value in front of it)  +  the tile counts of the camera's earlier workgroups
-//                    (k_isect_wg_scan: one tiny launch between the two), and emits.  Work is dealt by OUTPUT element, not by pair:
+//   k_isect_emit     the same workgroup shape: scans its pairs' tile counts (rectangle areas, or the set bits of a masked
+//                    rectangle), finds its first output position as the tile counts of all earlier workgroups,
+//                    camera-major (k_isect_wg_scan: one tiny launch between the two; it also leaves the record count),
+//                    and emits.  Work is dealt by OUTPUT element, not by pair:
 //                    every pair with tiles marks its first output with its index, a prefix maximum over the chunk
 //                    spreads the marks to the right (thread t scans 16 consecutive entries in registers, the thread
 //                    maxima meet in one workgroup scan), then the outputs are dealt to the threads with a stride of 256
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_isect_gather(int N, int C, int bpc, con
             if (rect32) {
                 const uint32_t r = reinterpret_cast<const uint32_t*>(rects)[pid[j]];
                 reinterpret_cast<uint32_t*>(rects_d)[dst] = r;
-                sum += (int)((r >> 16) & 0xFFu) * (int)(r >> 24);
+                sum += rect32_count(r);   // (a masked entry emits fewer tiles than its rectangle holds)
             } else {
                 const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[pid[j]];
                 reinterpret_cast<uint64_t*>(rects_d)[dst] = r;
@@ -521,30 +521,45 @@ __global__ __launch_bounds__(256) void k_isect_gather(int N, int C, int bpc, con
     if (t == 0) wg_tiles[c * bpc + k] = total;   // < 2^30: 1024 rectangles of < 2^20 tiles
 }
 
-// per camera: exclusive prefix of the workgroup tile counts (one workgroup per camera walks its bpc entries 256 at a time;
-// 977 entries at 1 M Gaussians) -- the emission then reads ONE base per workgroup, whatever the number of Gaussians
-__global__ __launch_bounds__(256) void k_isect_wg_scan(int bpc, const int32_t* __restrict__ wg_tiles,
-                                                       long long* __restrict__ wg_base) {
-    const int c = blockIdx.x, t = threadIdx.x;
-    long long carry = 0;
-    for (int b0 = 0; b0 < bpc; b0 += 256) {
-        const int v = b0 + t < bpc ? wg_tiles[c * bpc + b0 + t] : 0;
-        int tot;
-        const int inc = block_incl_scan(v, &tot);
-        if (b0 + t < bpc) wg_base[c * bpc + b0 + t] = carry + (long long)(inc - v);
-        carry += tot;
+// Exclusive prefix of the workgroup tile counts over ALL cameras, camera-major (one workgroup walks the C * bpc entries
+// 256 at a time; 7816 entries at 1 M Gaussians and 8 views) -- the emission then reads ONE absolute base per workgroup,
+// whatever the number of Gaussians -- and the number of records emitted (*rec_count).  Round 4 took a camera's base from
+// the pair-order scan (cum[c N - 1]); with masked rectangles (tile_rect.h) that scan counts SLOTS, not records.
+__global__ __launch_bounds__(1024) void k_isect_wg_scan(int n, const int32_t* __restrict__ wg_tiles,
+                                                        long long* __restrict__ wg_base, int32_t* __restrict__ rec_count) {
+    // thread t owns the consecutive entries [t per, (t + 1) per): their sum, one scan over the 1024 sums, then the
+    // entries again (a loop of block scans over 256 entries at a time took 45 us here: 31 dependent rounds)
+    __shared__ long long s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int per = (n + 1023) / 1024;
+    const int e0 = min(t * per, n), e1 = min(e0 + per, n);
+    long long sum = 0;
+    for (int e = e0; e < e1; ++e) sum += wg_tiles[e];
+    long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
     }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    long long base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { base += i < w ? s_wave[i] : 0; total += s_wave[i]; }
+    long long run = base + inc - sum;
+    for (int e = e0; e < e1; ++e) { wg_base[e] = run; run += wg_tiles[e]; }
+    // (past 2^31 - 1 the count is reported as -1, like the pair-order scan's total)
+    if (t == 0 && rec_count) rec_count[0] = total > 2147483647LL ? -1 : (int32_t)total;
 }
 
 __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, const int32_t* __restrict__ perm,
                                                       const void* __restrict__ rects_d, int rect32,
-                                                      const long long* __restrict__ wg_base,
-                                                      const int32_t* __restrict__ cum, int tile_w, int tile_h,
+                                                      const long long* __restrict__ wg_base, int tile_w, int tile_h,
                                                       uint32_t* __restrict__ tile_keys, int32_t* __restrict__ vals,
                                                       int64_t cap) {
     __shared__ int s_end[EP];         // inclusive scan of the workgroup's tile counts
     __shared__ uint32_t s_org[EP];    // x0 | y0 << 16
-    __shared__ uint32_t s_w[EP];      // rectangle width
+    __shared__ uint32_t s_w[EP];      // rectangle width | tile mask << 16 (0: every tile of the rectangle)
     __shared__ int32_t s_pid[EP];
     __shared__ uint16_t s_own[ECH];   // owner (pair index + 1) of every output of the current emission chunk
     __shared__ unsigned s_wmax[4];
@@ -558,13 +573,13 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     for (int j = 0; j < EPT; ++j) {
         const int e = j * 256 + t;
         int32_t pid = 0;
-        uint32_t org = 0, rw = 0, rh = 0;
+        uint32_t org = 0, rw = 0, rh = 0, msk = 0;
         if (e < np) {
             pid = perm[first + e];
-            rect_load(rects_d, rect32, first + e, &org, &rw, &rh);
+            rect_load(rects_d, rect32, first + e, &org, &rw, &rh, &msk);
         }
-        s_pid[e] = pid; s_org[e] = org; s_w[e] = rw;
-        cnt[j] = (int)(rw * rh);
+        s_pid[e] = pid; s_org[e] = org; s_w[e] = rw | (msk << 16);
+        cnt[j] = msk ? __popc(msk) : (int)(rw * rh);
     }
     // scan in pair order: EPT block scans of 256 consecutive pairs, the carry in a register
     int carry = 0;
@@ -578,8 +593,8 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     const int total = carry;
     __syncthreads();
     // (a true count above 2^31 wraps the int32 pair-order scan: the position test below keeps such writes out)
-    // first output position: the camera's first record + the tile counts of the camera's earlier workgroups (k_isect_wg_scan)
-    const long long base = (long long)(uint32_t)(c == 0 ? 0 : cum[(int64_t)c * N - 1]) + wg_base[c * bpc + k];
+    // first output position: the tile counts of all earlier workgroups, camera-major (k_isect_wg_scan)
+    const long long base = wg_base[c * bpc + k];
     const uint32_t key0 = (uint32_t)c * (uint32_t)(tile_w * tile_h);
     int carry_owner = 0;   // owner (+1) of the last output of the previous chunk (uniform)
     for (int c0 = 0; c0 < total; c0 += ECH) {
@@ -631,13 +646,20 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
         for (int i = t; i < lim; i += 256) {
             const int p = (int)s_own[i] - 1;
             const int o = c0 + i;
-            const int kk = o - (p == 0 ? 0 : s_end[p - 1]);   // index inside the pair's rectangle, row major
-            const uint32_t w_ = s_w[p], org = s_org[p];
-            // kk / w with kk < w * h <= 2^20 and w < 2^10: float estimate, corrected by one either way
-            int qq = (int)((float)kk * __builtin_amdgcn_rcpf((float)w_));
-            int rem = kk - qq * (int)w_;
-            if (rem < 0) { --qq; rem += (int)w_; }
-            if (rem >= (int)w_) { ++qq; rem -= (int)w_; }
+            const int kk = o - (p == 0 ? 0 : s_end[p - 1]);   // index among the pair's emitted tiles, row major
+            const uint32_t wm = s_w[p], org = s_org[p];
+            const uint32_t w_ = wm & 0xFFFFu, msk = wm >> 16;
+            int qq, rem;
+            if (msk) {   // masked rectangle (<= 3 x 3): the kk-th set bit is tile dy * 3 + dx
+                const int b = mask9_nth(msk, kk);
+                qq = b >= 6 ? 2 : (b >= 3 ? 1 : 0); rem = b - 3 * qq;
+            } else {
+                // kk / w with kk < w * h <= 2^20 and w < 2^10: float estimate, corrected by one either way
+                qq = (int)((float)kk * __builtin_amdgcn_rcpf((float)w_));
+                rem = kk - qq * (int)w_;
+                if (rem < 0) { --qq; rem += (int)w_; }
+                if (rem >= (int)w_) { ++qq; rem -= (int)w_; }
+            }
             const uint32_t tx = (org & 0xFFFF) + (uint32_t)rem, ty = (org >> 16) + (uint32_t)qq;
             const long long pos = base + o;
             if (pos >= 0 && pos < cap) {
@@ -649,9 +671,11 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     }
 }
 
+// rec_count (device, may be NULL): receives the number of records emitted -- with masked rectangles fewer than the
+// pair-order scan's total, which counts rectangle areas
 int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
-                               int rect32, const int32_t* cum, int tile_w, int tile_h, uint32_t* tile_keys,
-                               int32_t* vals, int64_t cap) {
+                               int rect32, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* vals, int64_t cap,
+                               int32_t* rec_count) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
     const int bpc = ceil_div(N, EP);
@@ -665,8 +689,8 @@ int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const
     long long* wg_base = (long long*)p;
     int32_t* wg_tiles = (int32_t*)(wg_base + grid);
     hipLaunchKernelGGL(k_isect_gather, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects, rect32, rects_d, wg_tiles);
-    hipLaunchKernelGGL(k_isect_wg_scan, dim3(C), dim3(256), 0, s, bpc, wg_tiles, wg_base);
-    hipLaunchKernelGGL(k_isect_emit_d, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects_d, rect32, wg_base, cum, tile_w,
+    hipLaunchKernelGGL(k_isect_wg_scan, dim3(1), dim3(1024), 0, s, grid, wg_tiles, wg_base, rec_count);
+    hipLaunchKernelGGL(k_isect_emit_d, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects_d, rect32, wg_base, tile_w,
                        tile_h, tile_keys, vals, cap);
     LAUNCH_CHECK();
     return ST3R_OK;

@@ -74,26 +74,54 @@ __device__ __forceinline__ uint64_t pack_rect(TileRect r) {
 }
 
 // The fused path keeps one packed rectangle per (camera, Gaussian) pair and gathers it by pair id (emit kernel): half
-// the bytes per entry is half the cache footprint of that gather, so tile grids of up to 255 x 255 tiles (images up
-// to 4080 pixels a side: every BASELINE configuration) use a 32-bit form, x0 | y0 << 8 | w << 16 | h << 24.
-__device__ __forceinline__ uint32_t pack_rect32(TileRect r) {
+// the bytes per entry is half the cache footprint of that gather, so tile grids of up to 255 x 127 tiles (images up
+// to 4080 x 2032 pixels) use a 32-bit form.  Two layouts, told apart by bit 31:
+//   plain   x0 | y0 << 8 | w << 16 | h << 24                       (h < 128): every tile of the rectangle
+//   masked  x0 | y0 << 8 | w << 16 | h << 18 | mask << 20 | 1 << 31  (w, h <= 3): bit dy * 3 + dx of the 9-bit mask says
+//           whether tile (x0 + dx, y0 + dy) is emitted.  Round 5: the rectangle is the bounding box of the ellipse
+//           {alpha >= 1/255}; on SYNTH-1M 49 % of the visible pairs have a 2 x 2 rectangle and the ellipse misses one
+//           of its corners often enough that 6.0 % of all (record, tile) pairs are dead weight for the sort, the
+//           emission and the staging of both blend kernels (they fail the alpha test on all 256 pixels).
+// The RECTANGLE keeps defining the slots of the backward's partial sums (slot = base + index of the tile inside the
+// rectangle; a tile that is not emitted leaves its slot unstamped and k_gather_vtile skips it), so the pair-order scan
+// still runs over the areas; only what is emitted, sorted and staged shrinks.
+__device__ __forceinline__ uint32_t pack_rect32(TileRect r, unsigned mask9 = 0u) {
     const uint32_t w = (uint32_t)(r.x1 - r.x0), h = (uint32_t)(r.y1 - r.y0);
     if (w == 0 || h == 0) return 0u;
+    if (mask9) return (uint32_t)r.x0 | ((uint32_t)r.y0 << 8) | (w << 16) | (h << 18) | (mask9 << 20) | 0x80000000u;
     return (uint32_t)r.x0 | ((uint32_t)r.y0 << 8) | (w << 16) | (h << 24);
 }
-__device__ __forceinline__ void rect_store(void* rects, int is32, int64_t i, TileRect r) {
-    if (is32) reinterpret_cast<uint32_t*>(rects)[i] = pack_rect32(r);
+__device__ __forceinline__ void rect_store(void* rects, int is32, int64_t i, TileRect r, unsigned mask9 = 0u) {
+    if (is32) reinterpret_cast<uint32_t*>(rects)[i] = pack_rect32(r, mask9);
     else reinterpret_cast<uint64_t*>(rects)[i] = pack_rect(r);
 }
-// entry i of either form: origin x0 | y0 << 16, width, height (is32 is uniform over the launch)
-__device__ __forceinline__ void rect_load(const void* rects, int is32, int64_t i, uint32_t* org, uint32_t* w, uint32_t* h) {
+// 32-bit entry -> origin x0 | y0 << 16, width, height, tile mask (0: every tile of the rectangle)
+__device__ __forceinline__ void rect32_decode(uint32_t r, uint32_t* org, uint32_t* w, uint32_t* h, uint32_t* mask) {
+    *org = (r & 0xFFu) | ((r & 0xFF00u) << 8);
+    if (r & 0x80000000u) { *w = (r >> 16) & 3u; *h = (r >> 18) & 3u; *mask = (r >> 20) & 0x1FFu; }
+    else { *w = (r >> 16) & 0xFFu; *h = r >> 24; *mask = 0u; }
+}
+// number of tiles a 32-bit entry emits
+__device__ __forceinline__ int rect32_count(uint32_t r) {
+    return (r & 0x80000000u) ? __popc((r >> 20) & 0x1FFu) : (int)((r >> 16) & 0xFFu) * (int)(r >> 24);
+}
+// entry i of either form: origin x0 | y0 << 16, width, height (is32 is uniform over the launch); *mask as above
+__device__ __forceinline__ void rect_load(const void* rects, int is32, int64_t i, uint32_t* org, uint32_t* w, uint32_t* h,
+                                          uint32_t* mask = nullptr) {
     if (is32) {
-        const uint32_t r = reinterpret_cast<const uint32_t*>(rects)[i];
-        *org = (r & 0xFFu) | ((r & 0xFF00u) << 8); *w = (r >> 16) & 0xFFu; *h = r >> 24;
+        uint32_t m;
+        rect32_decode(reinterpret_cast<const uint32_t*>(rects)[i], org, w, h, &m);
+        if (mask) *mask = m;
     } else {
         const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[i];
         *org = (uint32_t)(r & 0xFFFFFFFFull); *w = (uint32_t)((r >> 32) & 0xFFFF); *h = (uint32_t)(r >> 48);
+        if (mask) *mask = 0u;
     }
+}
+// the k-th emitted tile of a masked entry (k < popcount): its index dy * 3 + dx
+__device__ __forceinline__ int mask9_nth(uint32_t mask, int k) {
+    for (int i = 0; i < k; ++i) mask &= mask - 1u;
+    return __ffs((int)mask) - 1;
 }
 
 // ---- exact culling: does the ellipse {sigma(p - mean) <= tau} reach a square of pixel centres? ----
@@ -131,6 +159,31 @@ __device__ __forceinline__ bool ellipse_hits_square(const EllipseTest& e, float 
         hit |= (0.5f * (e.A * ex * ex + e.C * ey * ey) + e.B * ex * ey) <= e.tau;
     }
     return hit;
+}
+
+// Which tiles of a rectangle of at most 3 x 3 tiles can the ellipse {alpha >= 1/255} reach?  Bit dy * 3 + dx.  The tile's
+// pixel centres 16 t + 0.5 ... 16 t + 15.5 are widened by 0.05 px on every side (the slack of tight_tile_rect, above the
+// 0.02 / 0.01 px of the blend kernels' own quadrant and cell tests): a tile dropped here fails those tests as well, and
+// the alpha test of the blend loop on all of its 256 pixels.  Returns 0 when every tile is reachable (no mask needed).
+__device__ __forceinline__ unsigned exact_tile_mask9(TileRect r, float x, float y, float opac, float ca, float cb, float cc) {
+#pragma clang fp contract(off)
+    const int w = r.x1 - r.x0, h = r.y1 - r.y0;
+    if (w <= 0 || h <= 0 || w > 3 || h > 3 || w * h == 1) return 0u;
+    EllipseTest e;
+    if (!ellipse_prepare(opac, ca, cb, cc, &e)) return 0u;
+    unsigned m = 0u, full = 0u;
+    for (int dy = 0; dy < h; ++dy) {
+        const float y0 = (float)(16 * (r.y0 + dy)) + 0.45f - y;
+        for (int dx = 0; dx < w; ++dx) {
+            const float x0 = (float)(16 * (r.x0 + dx)) + 0.45f - x;
+            const unsigned bit = 1u << (dy * 3 + dx);
+            full |= bit;
+            if (ellipse_hits_square(e, x0, x0 + 15.1f, y0, y0 + 15.1f)) m |= bit;
+        }
+    }
+    // (never drop a pair altogether here: the rectangle says the box reaches its tiles; an empty mask would be a rounding
+    // artefact of two different conservative tests)
+    return (m == full || m == 0u) ? 0u : m;
 }
 
 // ---- exact culling at cell granularity: which of the sixteen 4x4-pixel cells of a tile can the ellipse reach? ----

@@ -279,8 +279,8 @@ def run_3dgs_optim(
     losses = torch.zeros(max(iters, 1), device=scene.device)
     fused = world == 1 or getattr(ctx, "native_comm", False)
     restore_exchange = None
-    if enable_pruning and fused and world > 1 and ops.get_exchange(ctx) == "rs_ag":
-        # reduce-scatter exchange: a rank maintains the Adam moments of its piece of the buffer only; growing the set
+    if enable_pruning and fused and world > 1 and ops.get_exchange(ctx) in ("rs_ag", "direct"):
+        # reduce-scatter exchange (through RCCL or through the peers' exported buffers): a rank maintains the Adam moments of its piece of the buffer only; growing the set
         # moves the piece boundaries, so a refinement run uses the plain all-reduce (replicated moments) for its duration:
         # the pieces are all-gathered first so that every rank holds the same, complete moments
         ops.allgather_pieces(ctx, st.m); ops.allgather_pieces(ctx, st.v)

@@ -390,12 +390,12 @@ def peek(ctx, which, count, dtype=torch.int32):
     return out
 
 
-EXCHANGE_FORMS = ("allreduce", "ranges", "rs_ag")   # ST3R_EXCHANGE_* of include/st3r.h, in order
+EXCHANGE_FORMS = ("allreduce", "ranges", "rs_ag", "direct")   # ST3R_EXCHANGE_* of include/st3r.h, in order
 
 
 def set_exchange(ctx, form):
     """The form the gradient exchange inside train_step takes from now on (a setting of the ctx; all ranks must agree):
-    'allreduce' | 'ranges' | 'rs_ag' (csrc/comm.hip).  Returns the previous form."""
+    'allreduce' | 'ranges' | 'rs_ag' | 'direct' (csrc/comm.hip).  Returns the previous form."""
     prev = get_exchange(ctx)
     _lib.check(_lib.lib().st3r_comm_set_exchange(ctx.handle, EXCHANGE_FORMS.index(form)))
     return prev

@@ -53,7 +53,7 @@ def test_native_comm_single_rank_and_fused_step():
     # ranges and the staging buffer are the real ones.
     try:
         assert ops.get_exchange(ctx) == "allreduce"       # the default of a fresh communicator (ST3R_EXCHANGE unset)
-        for mode in ("allreduce", "ranges", "rs_ag"):
+        for mode in ("allreduce", "ranges", "rs_ag", "direct"):
             assert ops.set_exchange(ctx, mode) in ops.EXCHANGE_FORMS and ops.get_exchange(ctx) == mode
             B = {k: v_.clone() for k, v_ in P.items()}
             grads_b = torch.empty(23 * N, device=DEV); mb = torch.zeros_like(grads); vb = torch.zeros_like(grads)
@@ -152,7 +152,7 @@ def test_range_exchange_of_a_chunked_call_equals_the_allreduce_result():
         ctx.close()
 
 
-@pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag"])
+@pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag", "direct"])
 def test_a_failing_rank_still_takes_part_and_nobody_applies_the_step(form):
     """A step that fails on one rank must not strand the others in the collective: the failing rank issues
     every collective of the step and returns its error, the max-reduced status word skips the Adam update on the device

@@ -388,6 +388,43 @@ def test_fused_train_gradients_equal_stage_path(ctx, name):
 
 
 @pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
+def test_masked_rectangles_drop_only_dead_records(ctx, name):
+    """Debug flag 4096 (round 5, opt-in: measured not faster): rectangles of at most 3 x 3 tiles carry the mask of the tiles
+    the exact ellipse test keeps; the emission writes fewer records, the backward's slots stay rectangle-indexed.  A
+    dropped (record, tile) pair fails the alpha test on all 256 pixels: images bit-identical, gradients bit-identical
+    (the same per-record sums in the same slots, the dropped slots were never stamped with anything but zeros)."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make(name)
+    N = g["means"].shape[0]
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
+    torch.manual_seed(5)
+    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
+    out = {}
+    try:
+        for flag in (0, 4096):
+            ops.set_debug(ctx, flag)
+            grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+            st = ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+            torch.cuda.synchronize()
+            img = ops.peek(ctx, 8, rgb.numel(), torch.float32).clone()
+            out[flag] = (st, grads, float(loss[0]), img)
+    finally:
+        ops.set_debug(ctx, 0)
+    (st0, g0, l0, i0), (st1, g1, l1, i1) = out[0], out[4096]
+    assert st1["n_isects_ref"] == st0["n_isects_ref"] and st1["n_visible"] == st0["n_visible"]
+    assert 0 <= st1["n_isects"] <= st0["n_isects"]
+    assert torch.equal(i0.view(torch.int32), i1.view(torch.int32)) and l0 == l1
+    # gradients: the per-(record, tile) sums are unchanged, but the contribution words of a forward batch group other
+    # records now (batches of 256 consecutive LIST entries), so the backward's rounds -- and with them the grouping of the
+    # float sums per record -- may differ: equal to rounding
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= (2e-3 if name.startswith("fuzz") else 2e-5) * scale
+
+
+@pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
 def test_cell_list_forward_equals_quadrant_forward(ctx, name):
     """The fused training path blends with 4x4-cell lists (gs_blend_cells.hip: four records per trip, one per 16-lane row,
     exec-masked tests); st3r_gs_render takes the same kernel under debug flag 512.  Same records per pixel in the same

@@ -133,8 +133,8 @@ def _grad_worker(rank, world, port, out, exchange):
     total = loss.cpu()
     torch.distributed.all_reduce(total)
     loss.copy_(total)
-    # replicas: identical parameters on every rank (and moments, except under rs_ag where a rank maintains its piece only)
-    for name, t in list(P.items()) + ([] if exchange == "rs_ag" else [("m", m), ("v", v)]):
+    # replicas: identical parameters on every rank (and moments, except under rs_ag / direct where a rank maintains its piece only)
+    for name, t in list(P.items()) + ([] if exchange in ("rs_ag", "direct") else [("m", m), ("v", v)]):
         assert _same_on_every_rank(t), (exchange, name, rank)
     if rank == 0:
         torch.save(dict(P={k: x.cpu() for k, x in P.items()}, m=m.cpu(), v=v.cpu(), loss=loss.cpu()), out)
@@ -142,7 +142,7 @@ def _grad_worker(rank, world, port, out, exchange):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag"])
+@pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag", "direct"])
 def test_exchanged_step_equals_single_gpu_step(tmp_path, exchange):
     from starst3r_amd import ops
     world = WORLD
@@ -162,7 +162,7 @@ def test_exchanged_step_equals_single_gpu_step(tmp_path, exchange):
     assert float(z["loss"]) == pytest.approx(float(loss), rel=1e-5)
     # first Adam moment = (1 - beta1) * gradient: the exchanged gradient against the one-GPU gradient over all views
     scale = float(m.abs().max())
-    own = (23 * N) // world if exchange == "rs_ag" else 23 * N     # rank 0's piece of the buffer
+    own = (23 * N) // world if exchange in ("rs_ag", "direct") else 23 * N     # rank 0's piece of the buffer
     assert float((z["m"].to(dev)[:own] - m[:own]).abs().max()) <= 1e-5 * scale
     # the first update is lr * g / (|g| + eps) ~ lr * sign(g): the parameters agree to the rounding of the sum over ranks,
     # except where the gradient itself is rounding noise around 0 (there the update is anything in [-lr, lr])
@@ -316,7 +316,7 @@ def _failing_rank_worker(rank, world, port, form):
 
 
 @pytest.mark.skipif(WORLD < 2, reason="one rank: covered by tests/test_gpu_comm.py")
-@pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag"])
+@pytest.mark.parametrize("form", ["allreduce", "ranges", "rs_ag", "direct"])
 def test_one_failing_rank_of_several_strands_nobody(form):
     _spawn(_failing_rank_worker, (WORLD, _free_port(), form), WORLD)
 
@@ -396,7 +396,7 @@ def _cfg3_worker(rank, world, port, out, exchange):
 
 
 @pytest.mark.skipif(not EMULATED and N_GPUS < 8, reason="eight ranks: an 8-GPU node, or emulated on one GPU")
-@pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag"])
+@pytest.mark.parametrize("exchange", ["allreduce", "ranges", "rs_ag", "direct"])
 def test_cfg3_eight_ranks_train_like_one(tmp_path, exchange):
     world, out = CFG3["world"], str(tmp_path / "r0.pt")
     _spawn(_cfg3_worker, (world, _free_port(), out, exchange), world)
@@ -440,12 +440,13 @@ def _cfg4_scene(dev):
     return ctx, sc
 
 
-def _cfg4_worker(rank, world, port, out):
+def _cfg4_worker(rank, world, port, out, exchange, pruning):
+    os.environ["ST3R_EXCHANGE"] = exchange
     _init(rank, world, port)
     from starst3r_amd import dist as sdist, gs
     ctx, sc = _cfg4_scene(_device(rank))
     sdist.attach_native_comm(ctx)
-    losses = gs.run_3dgs_optim(sc, CFG4["iters"], enable_pruning=True)
+    losses = gs.run_3dgs_optim(sc, CFG4["iters"], enable_pruning=pruning)
     torch.cuda.synchronize()
     for k, t in sc.gaussians.items():
         assert _same_on_every_rank(t.data), (k, rank)
@@ -457,19 +458,22 @@ def _cfg4_worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
+# (with the pruning hooks on, run_3dgs_optim takes the plain all-reduce for the run -- growth moves the piece boundaries of
+# the piece-wise forms --; the `direct` form therefore moves its 460 MB through the IPC windows with the hooks off)
 @pytest.mark.skipif(not EMULATED and N_GPUS < 8, reason="eight ranks: an 8-GPU node, or emulated on one GPU")
-def test_cfg4_exchange_at_5M_gaussians_eight_ranks_with_pruning(tmp_path):
+@pytest.mark.parametrize("exchange,pruning", [("allreduce", True), ("direct", False)])
+def test_cfg4_exchange_at_5M_gaussians_eight_ranks_with_pruning(tmp_path, exchange, pruning):
     import sys
     sys.path.insert(0, HERE)
     world, out = CFG4["world"], str(tmp_path / "r0.pt")
-    _spawn(_cfg4_worker, (world, _free_port(), out), world)
+    _spawn(_cfg4_worker, (world, _free_port(), out, exchange, pruning), world)
     z = torch.load(out)
     L = np.asarray(z["losses"])
     assert len(L) == CFG4["iters"] and np.isfinite(L).all()
-    assert z["n"] == CFG4["N"] and z["dead"] == 0                      # relocated, nothing added above cap_max
+    assert z["n"] == CFG4["N"] and (z["dead"] == 0) == pruning         # relocated, nothing added above cap_max
     # the same six iterations in ONE process over the eight views: the summed losses agree (the MCMC noise is counter-based:
     # identical on every layout)
     from starst3r_amd import gs
     ctx, sc = _cfg4_scene(torch.device("cuda:0"))
-    ref = np.asarray(gs.run_3dgs_optim(sc, CFG4["iters"], enable_pruning=True))
+    ref = np.asarray(gs.run_3dgs_optim(sc, CFG4["iters"], enable_pruning=pruning))
     np.testing.assert_allclose(L, ref, rtol=2e-4)

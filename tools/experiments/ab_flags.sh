@@ -6,5 +6,5 @@ for F in "$@"; do
   ST3R_DEBUG_FLAGS=$F ST3R_BENCH_FREEZE=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); s = d['roofline']['stage_ms']
-print('ms', round(d['ms_per_step'], 3), 'fwd', round(s['blend_fwd'], 3), 'bwd', round(s['blend_bwd'], 3), 'loss', round(s['loss'], 3), 'sorts', round(s['sort'] + s['sort_depth'], 3))"
+print('ms', round(d['ms_per_step'], 3), {k: round(v, 3) for k, v in s.items()}, 'records', d['config']['n_isects_kept_after_exact_culling'])"
 done
