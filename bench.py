@@ -377,17 +377,24 @@ def scaling_model(ctx, ops, g_np, w2c_np, Ks_np, N, V, W, H, device):
         pred[str(w)] = {
             "link_ms_ring_allreduce": ring, "link_ms_direct_rs_ag": direct,
             "iters_per_sec_allreduce_form_ring": 1e3 / (local + ring),
-            "iters_per_sec_rs_ag_form_direct": 1e3 / (local + direct - adam_ms * (1.0 - 1.0 / w)),
+            # `direct` form (csrc/comm.hip, round 5): this library's own one-shot reduce-scatter + all-gather over HIP-IPC
+            # peer windows -- every rank READS 1/w of the buffer from each peer over that peer's link, twice
+            "iters_per_sec_direct_form": 1e3 / (local + direct - adam_ms * (1.0 - 1.0 / w)),
+            # RCCL's reduce-scatter + all-gather (rs_ag form): whichever algorithm RCCL picks; a ring moves the same bytes
+            # per link as the ring all-reduce
+            "iters_per_sec_rs_ag_form_if_ring": 1e3 / (local + ring - adam_ms * (1.0 - 1.0 / w)),
             # layout 2 (Gaussians and views sharded): same blending / loss / sorts per rank, Adam on 1/w of the Gaussians,
             # two all-to-alls of 48-byte records over direct links instead of the gradient exchange
             "iters_per_sec_gaussian_sharded_direct": 1e3 / (local - adam_ms * (1.0 - 1.0 / w) +
                                                             (2.0 * 48 * (V // w) * N / w / LINK * 1e3 if w > 1 else 0.0)),
         }
     out["predicted"] = pred
-    out["assumptions"] = ("exchange not overlapped with compute (the all-reduce follows the last kernels of the iteration); "
-                          "ring = what RCCL's default all-reduce is bound by on a point-to-point mesh, direct = every "
-                          "rank sends 1/w of the buffer to each peer over its own link (rs_ag form); the rs_ag / sharded "
-                          "rows subtract the replicated Adam's share that those forms do not run")
+    out["assumptions"] = ("exchange not overlapped with compute; ring = RCCL's default algorithm for all-reduce, "
+                          "reduce-scatter and all-gather (which one RCCL 2.26 picks on this mesh is UNKNOWN: a one-rank "
+                          "communicator logs no tuning decision, profiles/r5_rccl_one_rank_probe.md); direct = the "
+                          "`direct` exchange form, whose algorithm is the library's own (peer reads over HIP IPC): "
+                          "1/w of the buffer per link and phase BY CONSTRUCTION, its link rate and barrier cost "
+                          "unmeasured; the piece-wise rows subtract the replicated Adam's share those forms do not run")
     return out
 
 

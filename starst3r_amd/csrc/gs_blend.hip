@@ -486,19 +486,27 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
 #else
             const int64_t my_id = flat[bs + t];
 #endif
-            const float4 a = splats[my_id * 3 + 0];   // x y opacity conic.a
-            const float4 b = splats[my_id * 3 + 1];   // conic.b conic.c r g
-            const float4 c = splats[my_id * 3 + 2];   // b depth radius 0
-            sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
-            sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
-            sC[t] = c.x;
+            const int64_t word = mbase + hb;   // HB = 64: one (wave-uniform) mask word per round and wave
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
+            // only a record some wave contributed to is ever read from the staging arrays: the others' 48 bytes are not
+            // fetched (their slots of sA / sB / sC keep whatever an earlier round left there)
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+#ifndef BWD_STAGE_ALL
+            if (my_cb)
+#endif
+            {
+                a = splats[my_id * 3 + 0];   // x y opacity conic.a
+                b = splats[my_id * 3 + 1];   // conic.b conic.c r g
+                c = splats[my_id * 3 + 2];   // b depth radius 0
+                sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
+                sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
+                sC[t] = c.x;
+            }
             // opacity * exp(-sigma) can only exceed the 0.999 clamp when the opacity does (sigma >= 0 for every included
             // pixel): rounds whose records all stay below it skip the clamp handling
             const uint64_t cw = __builtin_amdgcn_ballot_w64(a.z > 0.999f);
             if (t == 0) sClampW = cw;
-            const int64_t word = mbase + hb;   // HB = 64: one (wave-uniform) mask word per round and wave
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
             if (my_cb && rectbase) {   // fused path: slot base and rectangle in one gathered word
                 const uint64_t r = rectbase[my_id];
                 const int x0 = (int)(r & 0x3FF), y0 = (int)((r >> 10) & 0x3FF), rw = (int)((r >> 20) & 0x3FF);
