@@ -321,6 +321,52 @@ def test_one_failing_rank_of_several_strands_nobody(form):
     _spawn(_failing_rank_worker, (WORLD, _free_port(), form), WORLD)
 
 
+def _absent_peer_worker(rank, world, port):
+    """`direct` form: the last rank stops calling.  The others' device-side barriers give up after ST3R_XBAR_TIMEOUT_MS and
+    mark the step failed -- no update is applied, the next call reports ST3R_ERR_PEER -- instead of spinning for ever."""
+    os.environ["ST3R_EXCHANGE"] = "direct"
+    os.environ["ST3R_XBAR_TIMEOUT_MS"] = "400"
+    _init(rank, world, port)
+    from starst3r_amd import _lib, dist as sdist, ops
+    dev = _device(rank)
+    ctx = ops.get_context(dev)
+    g, w2c, Ks, V = _scene(world)
+    gt = _gt(ctx, g, w2c, Ks, dev)
+    views = sdist.shard_views(V, rank, world)
+    P = {k: torch.from_numpy(g[k]).to(dev) for k in ("means", "quats", "scales", "opacities", "shN")}
+    vm, K = torch.from_numpy(w2c).to(dev)[views].contiguous(), torch.from_numpy(Ks).to(dev)[views].contiguous()
+    sdist.attach_native_comm(ctx)
+    grads = torch.empty(23 * N, device=dev); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+    loss = torch.zeros(1, device=dev)
+
+    def step(i):
+        ops.train_step(ctx, P, vm, K, ops.camera_positions(vm), gt[views].contiguous(), W, H, 0.2, 0.01, 0.01, grads, m, v,
+                       1e-3, 0.9, 0.999, 1e-8, i, loss)
+        torch.cuda.synchronize()
+    step(1)                                    # everybody: the window is built, the first step is exchanged
+    for k, t in P.items():
+        assert _same_on_every_rank(t), (k, rank)
+    if rank != world - 1:
+        before = {k: t.clone() for k, t in P.items()}
+        import time
+        t0 = time.perf_counter()
+        step(2)                                # the last rank never arrives: two barriers time out (0.4 s each)
+        assert time.perf_counter() - t0 < 30.0
+        for k in P:
+            assert torch.equal(P[k], before[k]), (rank, k)       # the update was skipped on the device
+        with pytest.raises(_lib.St3rError) as e:
+            ops.settle(ctx)
+        assert e.value.code == -5, e.value
+    torch.distributed.barrier()                # (the absent rank keeps its buffers mapped until the others have given up)
+    sdist.detach_native_comm(ctx)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(WORLD < 2, reason="needs a peer")
+def test_direct_exchange_gives_up_on_a_peer_that_never_arrives():
+    _spawn(_absent_peer_worker, (WORLD, _free_port()), WORLD)
+
+
 def _pieces_worker(rank, world, port):
     _init(rank, world, port)
     from starst3r_amd import dist as sdist, ops
