@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void k_params_from_peers(int64_t N, float* __r
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < lim; i += stride) {
         const int p = (int)(i / q);
         if (p == r) continue;
-        *adam_param(i, N, means, quats, scales, opacities, sh, sh_stride) = tab[p][i];
+        // (another device's memory: a system-scope load, past whatever this device cached of it during the last step)
+        *adam_param(i, N, means, quats, scales, opacities, sh, sh_stride) =
+            __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(tab[p] + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     }
 }
 

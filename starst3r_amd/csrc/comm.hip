@@ -404,15 +404,24 @@ __global__ __launch_bounds__(XW_MAX_RANKS) void k_xbar(unsigned long long* const
     __threadfence_system();
 }
 
-// out[i] = sum over the ranks, in rank order, of their exported gradient buffers, for i in [i0, i1) and [t0, t1)
-__global__ __launch_bounds__(256) void k_xreduce(const float* const* __restrict__ grad_tab, int w, int64_t i0, int64_t i1,
-                                                 int64_t t0, int64_t t1, float* __restrict__ out) {
+// out[i] = sum over the ranks, in rank order, of their exported gradient buffers, for i in [i0, i1) and [t0, t1).
+// A peer's buffer is ordinary (coarse-grained) device memory of ANOTHER device, whose lines this device may have cached
+// during the previous step: peers are read with system-scope loads (they bypass the non-coherent caches), the own buffer
+// with plain ones.  (The barrier kernel's acquire invalidates the L2 of the one XCD it runs on, not the other seven.)
+__device__ __forceinline__ float peer_load(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__global__ __launch_bounds__(256) void k_xreduce(const float* const* __restrict__ grad_tab, int w, int r, int64_t i0,
+                                                 int64_t i1, int64_t t0, int64_t t1, float* __restrict__ out) {
     const int64_t n = (i1 - i0) + (t1 - t0);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const int64_t i = j < i1 - i0 ? i0 + j : t0 + (j - (i1 - i0));
-        float acc = grad_tab[0][i];
-        for (int p = 1; p < w; ++p) acc += grad_tab[p][i];
+        float acc = 0.f;
+        for (int p = 0; p < w; ++p) {
+            const float v = p == r ? grad_tab[p][i] : peer_load(grad_tab[p] + i);
+            acc = p == 0 ? v : acc + v;
+        }
         out[i] = acc;
     }
 }
@@ -578,8 +587,8 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
         int blocks = ceil_div(q + (total - tail0), 256 * 4);
         if (blocks < 1) blocks = 1;
         if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL(k_xreduce, dim3(blocks), dim3(256), 0, s, (const float* const*)xw->dev_tab, w, r * q, (r + 1) * q,
-                           tail0, total, grads);
+        hipLaunchKernelGGL(k_xreduce, dim3(blocks), dim3(256), 0, s, (const float* const*)xw->dev_tab, w, r, r * q,
+                           (r + 1) * q, tail0, total, grads);
         SOFT_HIP(hipGetLastError());
         st3r_prof_begin(ctx, s, STG_ADAM);
         if (q > 0)
