@@ -359,7 +359,7 @@ int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset,
  *                        one iteration of starster/gs.py:143-164 for this rank's views.  loss_out holds
  *                        this rank's part of the loss (sum over ranks = the reference's loss).
  *
- * The exchange inside st3r_gs_train_step takes one of three forms, a setting of the ctx (st3r_comm_set_exchange):
+ * The exchange inside st3r_gs_train_step takes one of four forms, a setting of the ctx (st3r_comm_set_exchange):
  *   ST3R_EXCHANGE_ALLREDUCE  one all-reduce of the 23N floats after the backward, then Adam (default)
  *   ST3R_EXCHANGE_RANGES     the projection backward runs per Gaussian range, a range's all-reduce overlaps the next
  *                            range's backward and the previous range's Adam

@@ -25,7 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ONE visible GPU (the builder's box, the round-end box): the same tests run with EMULATED ranks -- `EMULATED_WORLD`
 # processes that all use cuda:0, torch.distributed on gloo, and the library's communicator bound to the test shim
 # tests/fake_rccl (ST3R_RCCL_LIB; RCCL itself refuses two ranks on one device).  Everything above the six nccl* entry points
-# is the product code: st3r_comm_init, the three exchange forms with their piece / range arithmetic for w > 1, the status
+# is the product code: st3r_comm_init, the four exchange forms with their piece / range arithmetic for w > 1, the status
 # word, the sharded Adam, Scene's loop, the pair exchange.  What emulation cannot show is RCCL's own behaviour and timing.
 # ST3R_TEST_MULTI_FORCE=1 keeps the older plumbing check instead: ONE spawned rank on real RCCL.
 FORCED = os.environ.get("ST3R_TEST_MULTI_FORCE") == "1" and N_GPUS == 1
