@@ -332,9 +332,12 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_DVALS_A, int32_t, n_sort, dvals_a);
     GET(SLOT_DVALS_B, int32_t, n_sort, perm);
     // packed tile rectangle of every pair (pair-id order; the tile count of a pair is the area of its rectangle, no
-    // array of its own): 32-bit entries for tile grids up to 255 x 127 (tile_rect.h), 64-bit beyond -- and under debug
-    // flag 64, whose backward reads the 64-bit form
-    const int rect32 = (tile_w <= 255 && tile_h <= 127 && !(ctx->debug_flags & 64)) ? 1 : 0;
+    // array of its own): 32-bit entries for tile grids up to 255 x 255 (tile_rect.h), 64-bit beyond -- and under debug
+    // flag 64, whose backward reads the 64-bit form.  rect32 = 2 (debug flag 4096, training calls, grids up to 255 x 127):
+    // small rectangles also carry the exact tile mask -- 6 % fewer records on SYNTH-1M, measured NOT faster: the mask costs
+    // the projection what the record-proportional stages save (tools/experiments/README.md); off by default
+    int rect32 = (tile_w <= 255 && tile_h <= 255 && !(ctx->debug_flags & 64)) ? 1 : 0;
+    if (rect32 && tight && !records_in && (ctx->debug_flags & 4096) && tile_h <= 127) rect32 = 2;
     GET(SLOT_RECTS, uint64_t, rect32 ? (n_pairs + 1) / 2 : n_pairs, rects);
     st3r_prof_begin(ctx, s, STG_PROJECT);
     const uint32_t key_base = key32 ? near_bits : 0u;
@@ -343,11 +346,7 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
                                              key_base, rects, rect32)
                  : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
                                      W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, nullptr, reg_sums, dkeys_a,
-                                     // (tight = 2, debug flag 4096: small rectangles also carry the exact tile mask -- 6 %
-                                     // fewer records on SYNTH-1M, measured NOT faster: the mask costs the projection what
-                                     // the record-proportional stages save, tools/experiments/README.md; off by default)
-                                     dvals_a, (tight && (ctx->debug_flags & 4096)) ? 2 : tight, key_base, rects, rect32, 1,
-                                     loss_sums, 2 * C);
+                                     dvals_a, tight, key_base, rects, rect32, 1, loss_sums, 2 * C);
     if (!rc && records_in && loss_sums) HIP_TRY(hipMemsetAsync(loss_sums, 0, sizeof(double) * 2 * (size_t)C, s));
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;

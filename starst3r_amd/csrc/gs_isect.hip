@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_isect_gather(int N, int C, int bpc, con
             if (rect32) {
                 const uint32_t r = reinterpret_cast<const uint32_t*>(rects)[pid[j]];
                 reinterpret_cast<uint32_t*>(rects_d)[dst] = r;
-                sum += rect32_count(r);   // (a masked entry emits fewer tiles than its rectangle holds)
+                sum += rect32_count(r, rect32);   // (a masked entry emits fewer tiles than its rectangle holds)
             } else {
                 const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[pid[j]];
                 reinterpret_cast<uint64_t*>(rects_d)[dst] = r;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
             n_ref += (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
             if (tight) tr = tight_tile_rect(tr, m2x, m2y, opac, ca, cb, cc);  // fused train path only
             ntiles = (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
-            if (tight > 1 && rect32) tmask = exact_tile_mask9(tr, m2x, m2y, opac, ca, cb, cc);
+            if (rect32 == 2) tmask = exact_tile_mask9(tr, m2x, m2y, opac, ca, cb, cc);   // (masked rectangles: opt-in)
             r0 = make_float4(m2x, m2y, opac, ca);
             r1 = make_float4(cb, cc, col[0], col[1]);
             r2 = make_float4(col[2], z, __int_as_float((int)radius), 0.0f);

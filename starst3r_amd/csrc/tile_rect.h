@@ -74,9 +74,11 @@ __device__ __forceinline__ uint64_t pack_rect(TileRect r) {
 }
 
 // The fused path keeps one packed rectangle per (camera, Gaussian) pair and gathers it by pair id (emit kernel): half
-// the bytes per entry is half the cache footprint of that gather, so tile grids of up to 255 x 127 tiles (images up
-// to 4080 x 2032 pixels) use a 32-bit form.  Two layouts, told apart by bit 31:
-//   plain   x0 | y0 << 8 | w << 16 | h << 24                       (h < 128): every tile of the rectangle
+// the bytes per entry is half the cache footprint of that gather, so tile grids of up to 255 x 255 tiles (images up
+// to 4080 pixels a side: every BASELINE configuration) use a 32-bit form, `is32` = 1:
+//   plain   x0 | y0 << 8 | w << 16 | h << 24                         every tile of the rectangle
+// `is32` = 2 (opt-in, debug flag 4096; grids up to 255 x 127 so that h < 128): bit 31 tells two layouts apart, the plain
+// one above and
 //   masked  x0 | y0 << 8 | w << 16 | h << 18 | mask << 20 | 1 << 31  (w, h <= 3): bit dy * 3 + dx of the 9-bit mask says
 //           whether tile (x0 + dx, y0 + dy) is emitted.  Round 5: the rectangle is the bounding box of the ellipse
 //           {alpha >= 1/255}; on SYNTH-1M 49 % of the visible pairs have a 2 x 2 rectangle and the ellipse misses one
@@ -95,22 +97,23 @@ __device__ __forceinline__ void rect_store(void* rects, int is32, int64_t i, Til
     if (is32) reinterpret_cast<uint32_t*>(rects)[i] = pack_rect32(r, mask9);
     else reinterpret_cast<uint64_t*>(rects)[i] = pack_rect(r);
 }
-// 32-bit entry -> origin x0 | y0 << 16, width, height, tile mask (0: every tile of the rectangle)
-__device__ __forceinline__ void rect32_decode(uint32_t r, uint32_t* org, uint32_t* w, uint32_t* h, uint32_t* mask) {
+// 32-bit entry -> origin x0 | y0 << 16, width, height, tile mask (0: every tile of the rectangle); is32 = 2: the entry
+// may be a masked one
+__device__ __forceinline__ void rect32_decode(uint32_t r, int is32, uint32_t* org, uint32_t* w, uint32_t* h, uint32_t* mask) {
     *org = (r & 0xFFu) | ((r & 0xFF00u) << 8);
-    if (r & 0x80000000u) { *w = (r >> 16) & 3u; *h = (r >> 18) & 3u; *mask = (r >> 20) & 0x1FFu; }
+    if (is32 == 2 && (r & 0x80000000u)) { *w = (r >> 16) & 3u; *h = (r >> 18) & 3u; *mask = (r >> 20) & 0x1FFu; }
     else { *w = (r >> 16) & 0xFFu; *h = r >> 24; *mask = 0u; }
 }
 // number of tiles a 32-bit entry emits
-__device__ __forceinline__ int rect32_count(uint32_t r) {
-    return (r & 0x80000000u) ? __popc((r >> 20) & 0x1FFu) : (int)((r >> 16) & 0xFFu) * (int)(r >> 24);
+__device__ __forceinline__ int rect32_count(uint32_t r, int is32) {
+    return (is32 == 2 && (r & 0x80000000u)) ? __popc((r >> 20) & 0x1FFu) : (int)((r >> 16) & 0xFFu) * (int)(r >> 24);
 }
 // entry i of either form: origin x0 | y0 << 16, width, height (is32 is uniform over the launch); *mask as above
 __device__ __forceinline__ void rect_load(const void* rects, int is32, int64_t i, uint32_t* org, uint32_t* w, uint32_t* h,
                                           uint32_t* mask = nullptr) {
     if (is32) {
         uint32_t m;
-        rect32_decode(reinterpret_cast<const uint32_t*>(rects)[i], org, w, h, &m);
+        rect32_decode(reinterpret_cast<const uint32_t*>(rects)[i], is32, org, w, h, &m);
         if (mask) *mask = m;
     } else {
         const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[i];
