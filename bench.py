@@ -108,39 +108,46 @@ def make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device):
 
 def cpu_baseline(args):
     """Time the C oracle (single thread) on a bounded sample and extrapolate to the metric's unit.
-    Sample: 1 view at (W/d)x(H/d) with N/d^2 Gaussians whose scales are multiplied by ... nothing:
-    the scene extent and camera are unchanged, focal scales with the image, so the per-pixel list
-    length drops by d^2 too; the extrapolation is therefore reported as measured-sample only."""
+    Sample: three views at (W/d)x(H/d) with N/d^2 Gaussians (~12 s): the scene extent and the cameras are unchanged, the
+    focal scales with the image, so the per-pixel list length drops by d^2 too; the extrapolation is therefore reported
+    as measured-sample only."""
     from oracle import build as ob
     ob.build()
     from oracle import gs_oracle as go
     from st3r_synth import synth
     d = args.cpu_sample_div
     W, H, N = args.width // d, args.height // d, args.gaussians // (d * d)
-    g, w2c, Ks = synth.make_scene(N, 1, W, H)
+    # three views of the sample scene, one after the other (~12 s of CPU work: the contract asks for 10 - 30 s)
+    SV = 3
+    g, w2c_all, Ks_all = synth.make_scene(N, SV, W, H)
     gt_g = synth.perturb_for_gt(g)
-    gt_img, _, _ = go.rasterization(gt_g["means"], gt_g["quats"], gt_g["scales"], gt_g["opacities"], gt_g["shN"], w2c,
-                                    Ks, W, H)
-    gt_img = np.clip(gt_img, 0, 1)
-    t0 = time.perf_counter()
-    rgb, alpha, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H)
-    _, _, v_rgb = go.l1_ssim(rgb[0], gt_img[0], 0.8, 0.2)
-    grads = go.rasterization_backward(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H,
-                                      meta, alpha, v_rgb[None])
-    p = g["means"].reshape(-1).copy(); m = np.zeros_like(p); v = np.zeros_like(p)
-    for _ in range(23 // 3 + 1):  # Adam over ~23 scalars per gaussian
-        go.adam(p, grads["means"].astype(np.float32).reshape(-1), m, v, 1e-3, 0.9, 0.999, 1e-8, 1)
-    t = time.perf_counter() - t0
+    t = 0.0
+    for sv in range(SV):
+        w2c, Ks = w2c_all[sv:sv + 1], Ks_all[sv:sv + 1]
+        gt_img, _, _ = go.rasterization(gt_g["means"], gt_g["quats"], gt_g["scales"], gt_g["opacities"], gt_g["shN"], w2c,
+                                        Ks, W, H)
+        gt_img = np.clip(gt_img, 0, 1)
+        t0 = time.perf_counter()
+        rgb, alpha, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H)
+        _, _, v_rgb = go.l1_ssim(rgb[0], gt_img[0], 0.8, 0.2)
+        grads = go.rasterization_backward(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H,
+                                          meta, alpha, v_rgb[None])
+        p = g["means"].reshape(-1).copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+        for _ in range(23 // 3 + 1):  # Adam over ~23 scalars per gaussian
+            go.adam(p, grads["means"].astype(np.float32).reshape(-1), m, v, 1e-3, 0.9, 0.999, 1e-8, 1)
+        t += time.perf_counter() - t0
+    total_s = t
+    t = t / SV   # seconds per sample view
     # one full iteration = views x d^2 (pixels) samples of this size; d^2 more gaussians per pixel list too
     scale = args.views * d * d
     return {
         "value": 1.0 / (t * scale), "unit": "iters/sec", "cores": 1, "kind": "port",
         # (kept under 128 characters: the driver's record truncates longer strings)
-        "sample": f"C oracle, 1 thread: 1 view {W}x{H}, {N} gaussians, fwd+loss+bwd+Adam {t:.2f}s; value=1/(t*{scale}), "
-                  f"area-scaled only",
+        "sample": f"C oracle, 1 thread: {SV} views {W}x{H}, {N} gaussians, fwd+loss+bwd+Adam {t:.2f}s/view; "
+                  f"value=1/(t*{scale}), area-scaled",
         "sample_note": f"scaled by views * {d * d} (pixel area) only: optimistic for the CPU, the full scene also has "
                        f"{d * d}x more gaussians per pixel list",
-        "sample_seconds": t,
+        "sample_seconds": total_s,
     }
 
 
