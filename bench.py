@@ -267,6 +267,9 @@ def pmc_traffic(stage, N, views, W, H, world):
 
 
 CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md)
+# the clock the blend kernels were MEASURED to hold (GRBM_GUI_ACTIVE per XCD / launch duration, profiles/r5_clock_pmc.md):
+# power management under their instruction mix, not a property of the schedule
+MEASURED_CLOCK_GHZ = {"blend_fwd": 2.13, "blend_bwd": 2.10}
 
 
 def valu_issue(per_stage_ms, N, views, W, H, world):
@@ -301,7 +304,10 @@ def valu_issue(per_stage_ms, N, views, W, H, world):
             t = per_stage_ms[st] * 1e-3 * share.get(st, 1.0)
             per_simd = insts[st] / 1024.0
             out[st] = {"valu_insts_per_launch": insts[st], "kernel_ms": t * 1e3,
-                       "frac_at_2_cycles": per_simd * 2.0 / (CLOCK_GHZ * 1e9) / t}
+                       "frac_at_2_cycles": per_simd * 2.0 / (CLOCK_GHZ * 1e9) / t,
+                       # the same at the clock the kernel actually ran at when it was profiled (not measured in THIS run)
+                       "frac_at_2_cycles_at_profiled_clock": per_simd * 2.0 / (MEASURED_CLOCK_GHZ[st] * 1e9) / t,
+                       "profiled_clock_ghz": MEASURED_CLOCK_GHZ[st]}
             if st in mix_ns:
                 out[st]["frac_opcode_mix_weighted"] = per_simd * mix_ns[st] * 1e-9 / t
     return out
