@@ -789,11 +789,27 @@ def main():
         keep = ops.get_exchange(ctx)
         it_x = total - 1
         # (`direct` last: it is the one form that has never met real peer-to-peer links -- set-up over HIP IPC, device-side
-        # barriers --; an error there is recorded, not raised, and costs nothing measured before it)
+        # barriers --; an error there is recorded, not raised; the record of the RCCL forms is written BEFORE it is tried,
+        # and its barriers give up after 2 s each so that a window that maps but does not synchronise cannot eat the watchdog)
+        def record():
+            if rank == 0:
+                rec = {"n_gpus": world, "exchange_forms_ms_per_step": forms_ms}
+                print("exchange forms: " + json.dumps(rec), file=sys.stderr, flush=True)
+                try:
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    with open(os.path.join("gpurun_out", f"exchange_forms_n{world}.json"), "w") as f:
+                        json.dump(rec, f)
+                except OSError:
+                    pass
+        os.environ.setdefault("ST3R_XBAR_TIMEOUT_MS", "2000")
         for form in ops.EXCHANGE_FORMS:
+            if form == "direct":
+                record()
             try:
                 ops.set_exchange(ctx, form)
                 step(it_x)                                   # warm-up of the form (streams, staging buffers, windows)
+                if form == "direct":
+                    ops.settle(ctx)                          # a barrier that gave up shows here, before anything is timed
                 dist.barrier(); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -806,17 +822,12 @@ def main():
             except Exception as e:  # noqa: BLE001 -- a form that fails on this node is a finding, not a crash of the bench
                 forms_ms[form] = f"failed on rank {rank}: {e}"[:200]
                 break
-        ops.set_exchange(ctx, keep)
+        try:
+            ops.set_exchange(ctx, keep)
+        except Exception:  # noqa: BLE001
+            pass
         wd.cancel()
-        if rank == 0:
-            rec = {"n_gpus": world, "exchange_forms_ms_per_step": forms_ms}
-            print("exchange forms: " + json.dumps(rec), file=sys.stderr, flush=True)
-            try:
-                os.makedirs("gpurun_out", exist_ok=True)
-                with open(os.path.join("gpurun_out", f"exchange_forms_n{world}.json"), "w") as f:
-                    json.dump(rec, f)
-            except OSError:
-                pass
+        record()
     if dist is not None:
         dist.destroy_process_group()
 
