@@ -92,12 +92,20 @@ def test_reconstruct_scene_routes_a_bare_network_through_the_librarys_pipeline(f
     imgs = net.images()
     files = [f"{i}.png" for i in range(3)]                 # the fake names of Scene.add_images (scene.py:120)
     scene, params = rc.reconstruct_scene(bare, imgs, files, "cpu", optim_params={"warm": 1}, tmpdir=str(tmp_path))
-    assert seen["forward"] == (6, "Mast3rNetwork", 8, "desc_conf")            # complete symmetrized graph of 3 views
+    # the settings are not literals copied from reading the reference: tests/golden/reconstruct_calls.npz holds what the
+    # reference's own reconstruct_scene / run_sparse_ga (starster/reconstruct.py:19-113) passed down when they were RUN
+    # with recorders in place of Mast3r (tools/gen_reconstruct_call_goldens.py)
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reconstruct_calls.npz"))
+    assert z["call_order"].tolist() == list(range(9)) and z["make_pairs_complete_symmetrize_noprefilter"].all()
+    assert int(z["forward_desc_conf_is_desc_conf"]) and int(z["returns_tuple_scene_params"]) and int(z["sparsega_gets_fine_result"])
+    assert seen["forward"] == (int(z["n_pairs_of_3_views"]), "Mast3rNetwork", int(z["forward_subsample"]), "desc_conf")
     assert seen["instances"] == files                                         # convert_dust3r_pairs_naming
     assert calls and calls[0][0] is bare                                      # upstream f(model, img1, img2, device)
-    assert seen["condense"] == (files, {"pairs": True}, 8, 5.0, True)
+    assert seen["condense"] == (files, {"pairs": True}, int(z["canon_subsample"]), float(z["matching_conf_thr"]), True)
     kw = seen["align"]                                                        # the reference's settings (:61-66)
-    assert (kw["lr1"], kw["niter1"], kw["lr2"], kw["niter2"]) == (0.07, 500, 0.014, 200)
+    assert (kw["lr1"], kw["niter1"], kw["lr2"], kw["niter2"]) == (float(z["lr1"]), int(z["niter1"]), float(z["lr2"]), int(z["niter2"]))
+    assert not int(z["opt_depth"]) and not int(z["shared_intrinsics"]) and int(z["prev_params_is_optim_params"])
     assert kw["prev_params"] == {"warm": 1} and params == {"quats": 1}
     assert isinstance(scene, rc.SparseGAResult) and scene._dense == ["d"]
     assert len(scene.imgs) == 3 and scene.imgs[0].shape == (48, 64, 3)
