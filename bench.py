@@ -527,6 +527,10 @@ def main():
     else:
         views = list(range(rank, args.views, world))  # this rank's views
         P = {k: torch.tensor(v, device=device) for k, v in g_np.items()}
+        # like gs.run_3dgs_optim: the loop trains the four SH rows the kernels use as a compact [N, 4, 3] tensor (sh_stride 12;
+        # rows 4..23 of the reference's [N, 24, 3] `shN` never change) -- ST3R_BENCH_COMPACT_SH=0: the 288-byte-stride rows in place
+        if os.environ.get("ST3R_BENCH_COMPACT_SH", "1") != "0":
+            P["shN"] = P["shN"][:, :4].contiguous()
         w2c = torch.tensor(w2c_np[views], device=device)
         Ks = torch.tensor(Ks_np[views], device=device)
         campos = ops.camera_positions(w2c)

@@ -289,8 +289,21 @@ def run_3dgs_optim(
     if verbose:
         from tqdm import trange
         it_range = trange(iters)
+    # The kernels touch SH rows 0..3 only (sh_degree = 1, gs.py:81,86).  Read in place those 48 bytes sit at a 288-byte
+    # stride -- three streaming kernels (projection, its backward, Adam) then move ~2.7x the SH bytes they use --, so the loop
+    # trains a COMPACT copy [N, 4, 3] (sh_stride = 12) and writes it back into rows 0..3 of `shN` when it ends, and before
+    # every strategy hook that may look at the parameters (measured at 1 M Gaussians: projection 0.183 -> 0.157 ms, its
+    # backward 0.223 -> 0.203, Adam 0.148 -> 0.105; tools/experiments/ab_compact_sh.sh).
+    sh_c = [g["shN"].data[:, :4].contiguous()]
+
+    def sh_write_back():
+        g["shN"].data[:, :4].copy_(sh_c[0])
+
     def one_iteration(step):
-        P = {k: g[k].data for k in ("means", "quats", "scales", "opacities", "shN")}  # growth replaces the tensors
+        if sh_c[0].shape[0] != g["shN"].shape[0]:   # the set grew (a refinement step replaced the tensors)
+            sh_c[0] = g["shN"].data[:, :4].contiguous()
+        P = {k: g[k].data for k in ("means", "quats", "scales", "opacities")}  # growth replaces the tensors
+        P["shN"] = sh_c[0]
         if fused:   # the whole iteration is one C call (gradient all-reduce inside, over the ctx's communicator)
             # no host round trip in steady state (single rank; with a communicator the library sizes every step exactly)
             ops.train_step(ctx, P, w2c, Ks, campos, gt, width, height, loss_ssim_fac, loss_opacity_fac,
@@ -334,7 +347,15 @@ def run_3dgs_optim(
                     st.step += 1
                 one_iteration(step)
             if enable_pruning:
+                # our own strategy touches the SH rows on refinement steps only (relocation / growth copy whole rows); any
+                # other strategy object sees up-to-date parameters at every call
+                refine = getattr(scene.strategy, "is_refine_step", None)
+                touch = True if refine is None else bool(refine(step))
+                if touch:
+                    sh_write_back()
                 scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
+                if touch:
+                    sh_c[0] = g["shN"].data[:, :4].contiguous()
             step += 1
         if world == 1 and iters > 0:
             try:   # the last step's count is still in flight: settle it now so that an overflow cannot go unnoticed
@@ -344,6 +365,8 @@ def run_3dgs_optim(
                     raise
                 one_iteration(iters - 1)   # its update was skipped on the device: repeat it
     finally:
+        if sh_c[0].shape[0] == g["shN"].shape[0]:
+            sh_write_back()
         if restore_exchange is not None:   # (the moments stay complete on every rank: rs_ag goes on using its own piece)
             ops.set_exchange(ctx, restore_exchange)
     _dist.all_reduce_sum(losses)
