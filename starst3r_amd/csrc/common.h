@@ -107,7 +107,8 @@ struct st3r_ctx {
                       // 6: backward gathers rectangle and slot base separately; 7 (128): training forward on the quadrant
                       // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 11 (2048): under a communicator
                       // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip); 12 (4096): the fused
-                      // path drops the tiles of small rectangles that the exact ellipse test rejects (masked rectangles)
+                      // path drops the tiles of small rectangles that the exact ellipse test rejects (masked rectangles);
+                      // 13 (8192): EXPERIMENT, the fused backward on the cell-granular kernel (gs_blend_cells.hip; slower)
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     uint32_t scan_gen;   // single-pass scan (gs_isect.hip): generation of its status words
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back

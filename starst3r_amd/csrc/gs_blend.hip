@@ -704,6 +704,11 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
     }
 }
 
+int st3r_blend_bwd_cells_launch(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
+                                const int32_t* offsets, const int32_t* flat, const float* alpha, const int32_t* last_ids,
+                                const float* v_rgb, const uint64_t* cmask, int64_t words, const int32_t* tile_nb,
+                                const uint64_t* rectbase, float* vtile, int stamp, unsigned vt_cap);
+
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
@@ -730,7 +735,12 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
     const unsigned vt_cap = (unsigned)(ctx->slot_bytes[SLOT_VTILE] / (sizeof(float) * VT_STRIDE));
-    if (v_alpha)
+    if ((ctx->debug_flags & 8192) && !v_alpha && rectbase && end_in_offsets) {
+        // EXPERIMENT (round 5): the cell-granular walk (gs_blend_cells.hip: k_blend_bwd_cells), fused training calls only
+        rc = st3r_blend_bwd_cells_launch(s, C, W, H, tile_w, tile_h, splats, offsets, flat, alpha, last_ids, v_rgb, cmask,
+                                         words, tile_nb, rectbase, vtile, stamp, vt_cap);
+        if (rc) return rc;
+    } else if (v_alpha)
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
                            v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp, vt_cap);

@@ -425,6 +425,40 @@ def test_masked_rectangles_drop_only_dead_records(ctx, name):
 
 
 @pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
+def test_experimental_cell_backward_agrees_with_the_quadrant_backward(ctx, name):
+    """Debug flag 8192 (round 5 experiment, measured 0.86 ms SLOWER: tools/experiments/README.md): the blend backward with a
+    cell-granular phase 1 (gs_blend_cells.hip: k_blend_bwd_cells).  Same forward, same slots; the per-record sums are grouped
+    by cell instead of by 4-pixel runs of a quadrant, so the gradients agree to rounding -- and twice in a row bit for bit
+    (no atomics)."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make(name)
+    N = g["means"].shape[0]
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
+    torch.manual_seed(5)
+    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
+    out = []
+    try:
+        for flag in (0, 8192, 8192):
+            ops.set_debug(ctx, flag)
+            grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+            ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+            torch.cuda.synchronize()
+            out.append((grads, float(loss[0])))
+    finally:
+        ops.set_debug(ctx, 0)
+    (g0, l0), (g1, l1), (g2, l2) = out
+    assert l0 == l1 == l2
+    assert torch.equal(g1.view(torch.int32), g2.view(torch.int32))
+    scale = float(g0.abs().max())
+    print("cell-vs-quadrant", name, float((g1 - g0).abs().max()) / scale)
+    # the stress scenes' needle-shaped Gaussians sum terms far above the result (see the stage-path test above)
+    assert float((g1 - g0).abs().max()) <= (1e-2 if name.startswith("fuzz") else 2e-5) * scale
+
+
+@pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
 def test_cell_list_forward_equals_quadrant_forward(ctx, name):
     """The fused training path blends with 4x4-cell lists (gs_blend_cells.hip: four records per trip, one per 16-lane row,
     exec-masked tests); st3r_gs_render takes the same kernel under debug flag 512.  Same records per pixel in the same
