@@ -394,7 +394,7 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
 }
 
 template <bool HAS_VA>  // v_alpha is NULL in the train step (the reference's loss ignores render_alpha, gs.py:126)
-__global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
                                                    const int32_t* __restrict__ offsets,
                                                    const int32_t* __restrict__ flat, int n_isects,
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     __shared__ float sC[HB];    // b
     __shared__ float sAccW[4][HB * ACC_VALS];             // per wave: the sums of the records it met this round
     __shared__ float2 sPair[4][CHUNK * PAIR_STRIDE];      // per wave: (g_o, fac) of CHUNK records x 64 pixels
-    __shared__ uint64_t sClampW;                          // staged records whose opacity can reach the 0.999 clamp
+    __shared__ uint64_t sClampW;                          // staged records that need the full tests (see `hard` below)
     const TileGeom g = tile_geom(C, W, H, tile_w, tile_h, offsets, n_isects);
     const int nb = tile_nb[g.lb];
     if (nb == 0) return;
@@ -452,6 +452,10 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
     }
     const float qxf = (float)(g.tx0 + ((w & 1) << 3) + (pbase & 7)) + 0.5f;
     const float qyf_part = (float)(g.ty0 + ((w >> 1) << 3) + (pbase >> 3)) + 0.5f;
+    // constants of the easy rounds' alpha test, kept in vector registers (a VOP3 instruction takes no literal, and a scalar
+    // operand would cost the slot the form is there to save): 2^64 and -t' 2^64, t' = the float below 1/255
+    float k_big = 0x1p64f, k_neg_thr = -__int_as_float(0x3b808080) * 0x1p64f;   // (1.f / 255.f is 0x3b808081)
+    asm volatile("" : "+v"(k_big), "+v"(k_neg_thr));
     float T = T_final;
     // gsplat keeps buffer[k] = sum of the colours blended behind the current record; only its dot product
     // with the pixel's v_rgb is ever used, so one scalar replaces the three components
@@ -503,9 +507,17 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                 sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
                 sC[t] = c.x;
             }
-            // opacity * exp(-sigma) can only exceed the 0.999 clamp when the opacity does (sigma >= 0 for every included
-            // pixel): rounds whose records all stay below it skip the clamp handling
-            const uint64_t cw = __builtin_amdgcn_ballot_w64(a.z > 0.999f);
+            // Rounds whose records are all "easy" walk without two of the per-pixel tests (wave-uniform choice below):
+            //   * opacity * exp(-sigma) can only exceed the 0.999 clamp when the opacity does (sigma >= 0 for every
+            //     included pixel);
+            //   * the test P > 0 (gsplat's sigma < 0) can only fire for a conic that is not safely positive definite: with
+            //     rho = |b| / sqrt(a c), -Q >= (1 - rho) (|qa| dx^2 + |qc| dy^2) for the exact form Q, while the five
+            //     roundings of blend_power move P by less than 4 * 2^-24 of that sum; 1 - rho^2 >= 2e-3 leaves a factor
+            //     of several thousand.  (Such a conic has an axis ratio above ~30: needles.)
+            // Both are properties of the RECORD, decided here once instead of per pixel and trip.
+            const float det_ = a.w * b.y - b.x * b.x;
+            const bool hard = my_cb && !(a.z <= 0.999f && a.w > 0.f && b.y > 0.f && det_ >= 2e-3f * (a.w * b.y));
+            const uint64_t cw = __builtin_amdgcn_ballot_w64(hard);
             if (t == 0) sClampW = cw;
             if (my_cb && rectbase) {   // fused path: slot base and rectangle in one gathered word
                 const uint64_t r = rectbase[my_id];
@@ -550,8 +562,13 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
 #pragma unroll
                 for (int k = 0; k < CHUNK; ++k) {
                     if (m) {
+#ifdef BWD_ABL_CONST_T   // ablation (wrong records, timing only): no bit scan, no scalar -> vector address moves
+                        const int t = k;
+                        m &= m - 1;
+#else
                         const int t = 63 - __builtin_clzll(m);
                         m &= ~(1ull << t);
+#endif
                         const float4 a = sA[t];
                         const float4 q = sB[t];
                         const float cb_ = sC[t];
@@ -559,12 +576,24 @@ __global__ __launch_bounds__(BLK) void k_blend_bwd(int C, int W, int H, int tile
                         const float P = blend_power(dx, dy, a.w, q.x, q.y);
                         const float vis0 = __builtin_amdgcn_exp2f(P);
                         const float ov0 = a.z * vis0;
-                        const float al0 = CLAMP ? fminf(0.999f, ov0) : ov0;
-                        // same include test as the forward pass.  Branch-free: a lane that does not include this record
-                        // gets alpha = 0, hence 1/(1-alpha) = 1, fac = 0, g' = 0.
-                        uint64_t okm = mask_not_positive(P) & mask_not_less(al0, 1.f / 255.f);
-                        if (CHK) okm &= __builtin_amdgcn_ballot_w64(bs + t <= bin_final);
-                        const float alpha = zero_unless(okm, al0);
+                        float alpha;
+                        if (CLAMP) {
+                            const float al0 = fminf(0.999f, ov0);
+                            // same include test as the forward pass.  Branch-free: a lane that does not include this record
+                            // gets alpha = 0, hence 1/(1-alpha) = 1, fac = 0, g' = 0.
+                            uint64_t okm = mask_not_positive(P) & mask_not_less(al0, 1.f / 255.f);
+                            if (CHK) okm &= __builtin_amdgcn_ballot_w64(bs + t <= bin_final);
+                            alpha = zero_unless(okm, al0);
+                        } else {
+                            // easy round: P <= 0 and alpha <= 0.999 hold by construction; what remains is alpha >= 1/255 --
+                            // as arithmetic (a compare + select pair is two four-cycle instructions and two scalar-port
+                            // slots, a multiply-add + multiply are two two-cycle ones): step = clamp01((alpha - t') 2^64) with
+                            // t' the float below 1/255 is exactly 1 for alpha >= 1/255 and exactly 0 below
+                            float step;
+                            asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(step) : "v"(ov0), "v"(k_big), "v"(k_neg_thr));
+                            alpha = ov0 * step;
+                            if (CHK) alpha = zero_unless(__builtin_amdgcn_ballot_w64(bs + t <= bin_final), alpha);
+                        }
                         // a clamped alpha (opacity*vis > 0.999) passes no gradient to sigma / opacity
                         float alpha_u = alpha;
                         if (CLAMP) alpha_u = ov0 <= 0.999f ? alpha : 0.f;

@@ -166,6 +166,25 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
     }
 }
 
+
+// Round 5 (tools/probe/valu_issue.hip): a VALU instruction with an SGPR source takes a four-cycle slot of the CU's scalar
+// operand port, one with VGPR sources only takes two cycles of its SIMD -- and three of every four multiply-adds of these
+// kernels take a window weight.  The weights therefore live in VGPRs (the asm keeps hipcc from moving them back).
+struct WinV { float w[KS]; };
+__device__ __forceinline__ WinV window_in_vgprs(const Win& win) {
+    WinV v;
+#ifdef SSIM_W_SGPR
+#pragma unroll
+    for (int k = 0; k < KS; ++k) v.w[k] = win.w[k];
+#else
+#pragma unroll
+    for (int k = 0; k <= HALO; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(v.w[k]) : "s"(win.w[k]));
+#pragma unroll
+    for (int k = HALO + 1; k < KS; ++k) v.w[k] = v.w[KS - 1 - k];   // (the window is symmetric: six registers)
+#endif
+    return v;
+}
+
 // Forward and backward in one pass: the derivative maps D never leave the CU.  The strip's output columns need D on
 // 5 more columns each side, D needs x, y on 5 more again, so the workgroup stages 84-column row segments.
 // Wave specialisation: waves 0-3 (222 active threads) run the forward for 74 columns (same arithmetic, same order as
@@ -197,12 +216,13 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
 
 // (five waves per SIMD = two workgroups of 7 waves per CU: at most 96 VGPRs; the forward threads' five 12-row rings are 60)
 __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k_ssim_fused(int LH, int H, int W, const float* __restrict__ render,
-                                                    const float* __restrict__ gt, Win win, float k_l1, float k_ss,
+                                                    const float* __restrict__ gt, Win win_s, float k_l1, float k_ss,
                                                     double* __restrict__ sums, float* __restrict__ v_render) {
     __shared__ float sx[2][SEG2];
     __shared__ float sy[2][SEG2];
     __shared__ float sd[2][DCOLS * 9];
     __shared__ float red[2 * (FT1 / 64)];
+    const WinV win = window_in_vgprs(win_s);
     const int cam = blockIdx.z;
     const int j0 = blockIdx.x * FLW, i0 = blockIdx.y * LH;
     const float* xr = render + (int64_t)cam * H * W * 3;
@@ -405,6 +425,222 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the same fused loss with the forward's two passes in the other order -- VERTICAL first, on
+// the raw x, y.  A forward thread owns one element (column, channel) of the 84-column row segment and keeps the last twelve
+// rows of x and y of THAT element in registers (24 instead of the 60 of the five-moment rings above; the rows arrive from
+// HBM straight into the ring, the images are never staged in LDS).  Per row: eleven vertical taps give the five moments of
+// the element's column, they go to LDS (moment-major: conflict-free 4-byte reads), and one iteration later the threads of
+// the 74 D columns run the horizontal taps over them (55 LDS reads instead of 22), finish SSIM and leave the D row for the
+// backward waves exactly as k_ssim_fused does; the backward waves are unchanged but run two rows behind instead of one.
+// Same taps, same sums per pass; the passes commute in exact arithmetic, in float the moments differ from k_ssim_fwd's in
+// the last bits (parity bar: oracle, 1e-5).  What it buys is residency: <= 72 VGPRs = four workgroups per CU instead of two.
+#ifndef SSIM_V_WAVES
+#define SSIM_V_WAVES 7
+#endif
+#define VSEG (SEG2)                     // elements of a row segment = vertical-pass threads (252)
+#define VMS 256                         // stride of a moment plane in LDS (floats)
+__global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(SSIM_V_WAVES))) void k_ssim_fused_v(int LH, int H, int W, const float* __restrict__ render,
+                                                    const float* __restrict__ gt, Win win_s, float k_l1, float k_ss,
+                                                    double* __restrict__ sums, float* __restrict__ v_render) {
+    __shared__ float sm[2][5 * VMS];
+    __shared__ float sd[2][DCOLS * 9];
+    __shared__ float red[2 * (FT1 / 64)];
+    const WinV win = window_in_vgprs(win_s);
+    const int cam = blockIdx.z;
+    const int j0 = blockIdx.x * FLW, i0 = blockIdx.y * LH;
+    const float* xr = render + (int64_t)cam * H * W * 3;
+    const float* yr = gt + (int64_t)cam * H * W * 3;
+    const int rows_out = min(LH, H - i0);
+    const int nrows = rows_out + 2 * HALO2;  // input rows i0-10 .. i0+rows_out+9
+    float l1 = 0.f, ssim_acc = 0.f;
+
+    if (threadIdx.x < FT1) {
+        // ================= forward waves =================
+        const int t = threadIdx.x;
+        const int col = t / 3, ch = t - col * 3;
+        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+        // vertical role: element t of the segment = image column j0 - 10 + col
+        const int jx = j0 - HALO2 + col;
+        const unsigned eoff = (unsigned)(min(max(jx, 0), W - 1) * 3 + ch);   // (clamped, unconditional loads: see k_ssim_fused)
+        const bool l1_col = (col >= HALO2) && (col < HALO2 + FLW) && (jx < W) && (t < VSEG);
+        // horizontal role: D column `col` = image column j0 - 5 + col (threads 0 .. 221)
+        const bool hact = t < DCOLS * 3;
+        const int jd = j0 - HALO + col;
+        const bool own_col = (col >= HALO) && (col < HALO + FLW) && (jd < W);
+        float rx[SSIM_U], ry[SSIM_U];   // row q of this element in slot q % 12
+#ifdef SSIM_V_PRODUCTS
+        float rp[SSIM_U], rq[SSIM_U], rr[SSIM_U];   // x^2, y^2, xy of the same rows: once per element instead of once per tap
+#endif
+#pragma unroll
+        for (int s = 0; s < SSIM_U; ++s) {
+            rx[s] = 0.f; ry[s] = 0.f;
+#ifdef SSIM_V_PRODUCTS
+            rp[s] = 0.f; rq[s] = 0.f; rr[s] = 0.f;
+#endif
+        }
+        auto fetch_row = [&](int r, float& vx, float& vy) {
+            const int i = min(max(i0 - HALO2 + r, 0), H - 1);
+            vx = (xr + (int64_t)i * (W * 3))[eoff]; vy = (yr + (int64_t)i * (W * 3))[eoff];
+        };
+        fetch_row(0, rx[0], ry[0]);
+        for (int rb = 0; rb <= nrows + 1; rb += SSIM_U) {
+#pragma unroll
+            for (int s = 0; s < SSIM_U; ++s) {
+                const int r = rb + s;
+                if (r <= nrows + 1) {
+                    const int b = r & 1;
+                    // row r + 1 -> its ring slot (the one slot the window of row r does not use)
+                    fetch_row(r + 1, rx[(s + 1) % SSIM_U], ry[(s + 1) % SSIM_U]);
+                    if (r < nrows) {
+                        const int i = i0 - HALO2 + r;
+                        if (l1_col && i >= i0 && i < i0 + rows_out) l1 += fabsf(ry[s] - rx[s]);
+#ifdef SSIM_V_PRODUCTS
+                        rp[s] = rx[s] * rx[s]; rq[s] = ry[s] * ry[s]; rr[s] = rx[s] * ry[s];
+#endif
+                        if (r >= 2 * HALO) {
+                            // ---- vertical taps over rows r-10 .. r of this element
+                            float v0, v1, v2, v3, v4;
+#ifdef SSIM_V_PRODUCTS
+                            {
+                                const int slot = (s + SSIM_U - 10) % SSIM_U;
+                                const float w = win.w[0];
+                                v0 = w * rx[slot]; v1 = w * ry[slot]; v2 = w * rp[slot]; v3 = w * rq[slot]; v4 = w * rr[slot];
+                            }
+#pragma unroll
+                            for (int k = 1; k < KS; ++k) {
+                                const int slot = (s + SSIM_U - 10 + k) % SSIM_U;
+                                const float w = win.w[k];
+                                v0 += w * rx[slot]; v1 += w * ry[slot]; v2 += w * rp[slot]; v3 += w * rq[slot]; v4 += w * rr[slot];
+                            }
+#else
+                            {
+                                const int slot = (s + SSIM_U - 10) % SSIM_U;
+                                const float xx = rx[slot], yy = ry[slot], w = win.w[0];
+                                v0 = w * xx; v1 = w * yy; v2 = v0 * xx; v3 = v1 * yy; v4 = v0 * yy;
+                            }
+#pragma unroll
+                            for (int k = 1; k < KS; ++k) {
+                                const int slot = (s + SSIM_U - 10 + k) % SSIM_U;
+                                const float xx = rx[slot], yy = ry[slot], w = win.w[k];
+                                const float wx = w * xx, wy = w * yy;
+                                v0 += wx; v1 += wy; v2 += wx * xx; v3 += wy * yy; v4 += wx * yy;
+                            }
+#endif
+                            float* dst = &sm[b][t];
+                            dst[0] = v0; dst[VMS] = v1; dst[2 * VMS] = v2; dst[3 * VMS] = v3; dst[4 * VMS] = v4;
+                        }
+                    }
+                    // ---- horizontal taps over the moments of row r - 1 (written one iteration ago), SSIM, D row
+                    const int rp = r - 1;
+                    if (hact && rp >= 2 * HALO && rp < nrows) {
+                        const int id = i0 + rp - 3 * HALO;  // image row of the D row completed now
+                        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                        const bool interior = (id >= HALO) && (id < H - HALO) && (jd >= HALO) && (jd < W - HALO);
+                        if (interior) {
+                            const float* pm = &sm[b ^ 1][t];
+                            float mx = win.w[0] * pm[0], my = win.w[0] * pm[VMS], exx = win.w[0] * pm[2 * VMS],
+                                  eyy = win.w[0] * pm[3 * VMS], exy = win.w[0] * pm[4 * VMS];
+#pragma unroll
+                            for (int k = 1; k < KS; ++k) {
+                                const float w = win.w[k];
+                                mx += w * pm[3 * k]; my += w * pm[VMS + 3 * k]; exx += w * pm[2 * VMS + 3 * k];
+                                eyy += w * pm[3 * VMS + 3 * k]; exy += w * pm[4 * VMS + 3 * k];
+                            }
+                            const float sxx_raw = exx - mx * mx;
+                            const float sxx = fmaxf(sxx_raw, 0.f), syy = fmaxf(eyy - my * my, 0.f), sxy = exy - mx * my;
+                            const float n1 = 2.f * mx * my + c1, n2 = 2.f * sxy + c2;
+                            const float dd1 = mx * mx + my * my + c1, dd2 = sxx + syy + c2;
+                            const float inv1 = __builtin_amdgcn_rcpf(dd1), inv2 = __builtin_amdgcn_rcpf(dd2);
+                            const float inv = inv1 * inv2;
+                            const float ssim = n1 * n2 * inv;
+                            if (own_col && id >= i0 && id < i0 + rows_out) ssim_acc += ssim;  // one strip counts it
+                            const float dn1 = n2 * inv, dn2 = n1 * inv;
+                            const float g1 = -ssim * inv1, g2 = sxx_raw < 0.f ? 0.f : -ssim * inv2;
+                            d0 = 2.f * my * (dn1 - dn2) + 2.f * mx * (g1 - g2);  // dS/dmu_x
+                            d1 = g2;                                             // dS/dE[x^2]
+                            d2 = 2.f * dn2;                                      // dS/dE[xy]
+                        }
+                        float* dst = &sd[b ^ 1][col * 9 + ch * 3];
+                        dst[0] = d0; dst[1] = d1; dst[2] = d2;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        // ================= backward waves: output column j0 + col, two rows behind the vertical pass =================
+        const int t = threadIdx.x - FT1;
+        const int col = t / 3, ch = t - col * 3;
+        const int j = t < FLW * 3 ? j0 + col : W;   // threads past the strip (whole-wave padding) only keep the barriers
+        float ring[SSIM_U][3];
+#pragma unroll
+        for (int s = 0; s < SSIM_U; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
+        // x, y of this thread's output pixel: iteration r writes image row i0 + r - 22; requested one iteration ahead
+        float bx, by;
+        const unsigned jc = (unsigned)(min(j, W - 1) * 3 + ch);
+        auto fetch_px = [&](int r_use, float& vx, float& vy) {
+            const int ion = min(max(i0 + r_use - 2 - 2 * HALO2, 0), H - 1);
+            vx = (xr + (int64_t)ion * (W * 3))[jc]; vy = (yr + (int64_t)ion * (W * 3))[jc];
+        };
+        fetch_px(0, bx, by);
+        for (int rb = 0; rb <= nrows + 1; rb += SSIM_U) {
+#pragma unroll
+            for (int s = 0; s < SSIM_U; ++s) {
+                const int r = rb + s;
+                if (r <= nrows + 1) {
+                    const int rp = r - 2;                 // the input row whose D row (finished last iteration) is consumed now
+                    const int sp = (s + SSIM_U - 2) % SSIM_U;     // its ring slot (compile time)
+                    const float x = bx, y = by;
+                    fetch_px(r + 1, bx, by);
+                    if (rp >= 2 * HALO && j < W) {
+                        const float* pd = &sd[rp & 1][col * 9 + ch * 3];
+                        float h0 = win.w[0] * pd[0], h1 = win.w[0] * pd[1], h2 = win.w[0] * pd[2];
+#pragma unroll
+                        for (int k = 1; k < KS; ++k) {
+                            const float w = win.w[k];
+                            h0 += w * pd[k * 9]; h1 += w * pd[k * 9 + 1]; h2 += w * pd[k * 9 + 2];
+                        }
+                        ring[sp][0] = h0; ring[sp][1] = h1; ring[sp][2] = h2;
+                        if (rp >= 2 * HALO2) {
+                            const int io = i0 + rp - 2 * HALO2;
+                            if (io < H && j < W) {
+                                float a0, a1, a2;
+                                {
+                                    const int slot = (sp + SSIM_U - 10) % SSIM_U;
+                                    a0 = win.w[0] * ring[slot][0]; a1 = win.w[0] * ring[slot][1]; a2 = win.w[0] * ring[slot][2];
+                                }
+#pragma unroll
+                                for (int k = 1; k < KS; ++k) {
+                                    const int slot = (sp + SSIM_U - 10 + k) % SSIM_U;
+                                    const float w = win.w[k];
+                                    a0 += w * ring[slot][0]; a1 += w * ring[slot][1]; a2 += w * ring[slot][2];
+                                }
+                                float* vrow = v_render + ((int64_t)cam * H + io) * (W * 3);   // (uniform row pointer)
+                                const float sgn = (x > y) ? 1.0f : ((x < y) ? -1.0f : 0.0f);
+                                vrow[(unsigned)(j * 3 + ch)] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_down(l1, off); ssim_acc += __shfl_down(ssim_acc, off); }
+    constexpr int FW = FT1 / 64;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < FT1) { red[threadIdx.x >> 6] = l1; red[FW + (threadIdx.x >> 6)] = ssim_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < FW; ++i) { a += red[i]; b += red[FW + i]; }
+        atomicAdd(&sums[2 * cam + 0], (double)a);
+        atomicAdd(&sums[2 * cam + 1], (double)b);
+    }
+}
+
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render, bool sums_cleared) {
     static const Win win = make_window();
@@ -430,7 +666,11 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
     const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
     const float k_l1 = (float)((double)w_l1 / ((double)H * W * 3));
     const float k_ss = cnt > 0 ? (float)(-(double)w_ssim / cnt) : 0.f;
+#ifdef SSIM_VERTICAL_FIRST
+    hipLaunchKernelGGL(k_ssim_fused_v, grid, dim3(FT2), 0, s, LH, H, W, render, gt, win, k_l1, k_ss, sums, v_render);
+#else
     hipLaunchKernelGGL(k_ssim_fused, grid, dim3(FT2), 0, s, LH, H, W, render, gt, win, k_l1, k_ss, sums, v_render);
+#endif
     LAUNCH_CHECK();
     return ST3R_OK;
 }
