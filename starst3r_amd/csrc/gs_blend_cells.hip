@@ -33,6 +33,7 @@
 // staging thread of a record turns its four flag bytes into four ballots.  (First attempt: every blending lane stored
 // the flag byte itself -- sixteen lanes, one address: the LDS serialises such stores, +0.15 ms.)
 #include "blend_common.h"
+#include <type_traits>
 
 #define CB 256                  // records per batch (= the quadrant forward's: the contribution words line up)
 #define CL_CAP 264              // list capacity per cell in entries (256 + the read-ahead of the trip loop)
@@ -97,12 +98,18 @@ struct CellPx {
 // operation, as the quadrant kernel (blend_power / explicit fma: the images are bit-identical, tests), but exec-masked:
 // lanes that fail the alpha test skip the updates, a trip that no lane passes skips the body.  The saturation
 // bookkeeping sits behind a wave-uniform branch that is almost never taken.
+// LEAN (round 5): the batch holds only records whose conic is safely positive definite and whose opacity is <= 0.999 (decided
+// per record while staging, see `hard` in the kernel): P <= 0 holds for every pixel and opacity * exp2(P) cannot reach the clamp,
+// so the trip drops gsplat's `sigma < 0` test and the min -- two four-cycle instructions of ~25 (tools/probe/valu_issue.hip);
+// the values are bit-identical to the full trip's.
+template <bool LEAN>
 __device__ __forceinline__ void cell_trip(const float4 a, const float4 q, const float cb, int off, int bs, CellPx& s,
                                           unsigned& cbits, unsigned bit) {
     const float dx = a.x - s.px, dy = a.y - s.py;
     const float P = blend_power(dx, dy, a.w, q.x, q.y);
-    const float al = fminf(0.999f, a.z * __builtin_amdgcn_exp2f(P));
-    if (!(P > 0.f) && !(al < s.thr)) {
+    const float ov = a.z * __builtin_amdgcn_exp2f(P);
+    const float al = LEAN ? ov : fminf(0.999f, ov);
+    if ((LEAN || !(P > 0.f)) && !(al < s.thr)) {
         const float nT = s.T * (1.0f - al);
         float vis = al * s.T, Tn = nT;
         const bool stop = nT <= 1e-4f;
@@ -147,7 +154,7 @@ __device__ __forceinline__ CellTile cell_tile(int C, int W, int H, int tile_w, i
     return g;
 }
 
-__global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, int tile_w, int tile_h,
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(7))) void k_blend_fwd_cells(int C, int W, int H, int tile_w, int tile_h,
                                                          const float4* __restrict__ splats,
                                                          const int32_t* __restrict__ offsets,
                                                          const int32_t* __restrict__ flat,
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
     __shared__ uint16_t sList[16][CL_CAP];          // per cell: LDS byte offsets of its records, front to back
     __shared__ uint16_t sCm[BLK];                   // the staged records' cell masks
     __shared__ unsigned sFlag[CB];                  // per staged record: byte w != 0 <=> wave w contributed to it
+    __shared__ int sHard[2];                        // batch nb holds a record that needs the full trip (slot nb & 1)
     const CellTile g = cell_tile(C, W, H, tile_w, tile_h, offsets);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     CellPx s;
@@ -166,6 +174,7 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
     s.thr = g.inside ? 1.f / 255.f : __builtin_inff();
     s.T = 1.0f; s.r = s.g = s.b = 0.f; s.cur = 0x7fffffff;
     if (threadIdx.x < SLOT / 16) sR[CB * (SLOT / 16) + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 2) sHard[threadIdx.x] = 0;
     char* sRb = reinterpret_cast<char*>(sR);
     uint16_t* lp = sList[g.cell];
     unsigned char* my_flags = reinterpret_cast<unsigned char*>(sFlag) + w;
@@ -191,8 +200,16 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
         unsigned cm = 0;
         const int64_t id = id_next;
         if (idx + CB < g.end) id_next = flat[idx + CB];
+        bool hard = false;
         if (have) {
             ra = splats[id * 3 + 0]; rb = splats[id * 3 + 1]; rc = splats[id * 3 + 2];
+            // (same record-level test as the backward's staging, gs_blend.hip: conic safely positive definite, opacity below
+            // the clamp; anything else -- NaNs included -- takes the full trip)
+#ifdef CELLS_ABL_NEVER_HARD
+            hard = false;
+#else
+            hard = !(ra.z <= 0.999f && ra.w > 0.f && rb.y > 0.f && (ra.w * rb.y - rb.x * rb.x) >= 2e-3f * (ra.w * rb.y));
+#endif
 #ifdef CELLS_NO_TEST
             cm = 0xFFFFu;
 #else
@@ -212,6 +229,8 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
         }
         sCm[threadIdx.x] = (uint16_t)cm;
         sFlag[threadIdx.x] = 0u;
+        if (__builtin_amdgcn_ballot_w64(hard) != 0 && lane == 0) sHard[nb & 1] = 1;
+        if (threadIdx.x == 0) sHard[(nb + 1) & 1] = 0;   // (last read before this batch's first barrier)
         __syncthreads();
         // ---- trips: every row walks its own list; the wave runs until its longest list is done
         if (__builtin_amdgcn_ballot_w64(s.thr < 1.0f) != 0) {
@@ -223,6 +242,8 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
             const int l0 = lens.x & 0xFFFF, l1 = lens.x >> 16, l2 = lens.y & 0xFFFF, l3 = lens.y >> 16;
             // Windows of 32 list positions; inside a window four trips per iteration: the four list entries arrive as one
             // 8-byte read issued an iteration ahead, the record reads run two trips ahead of the bodies.
+            auto windows = [&](auto lean_tag) {
+            constexpr bool LEAN = decltype(lean_tag)::value;
             uint2 e = *reinterpret_cast<const uint2*>(lp);
             for (int k0 = 0;; k0 += 32) {
                 // the trips still needed: the longest list among the rows that still have a live pixel (checked once per
@@ -252,12 +273,12 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
                     // two records in flight: all twelve reads up front cost 12 more registers and a wave per SIMD (measured
                     // slower: 1.14 vs 1.07 ms on the frozen scene)
                     ST3R_LD(o0, a0, q0, c0) ST3R_LD(o1, a1, q1, c1)
-                    asm volatile("" ::"v"(c0)); cell_trip(a0, q0, c0, o0, bs, s, cbits, sb);
+                    asm volatile("" ::"v"(c0)); cell_trip<LEAN>(a0, q0, c0, o0, bs, s, cbits, sb);
                     ST3R_LD(o2, a2, q2, c2)
-                    asm volatile("" ::"v"(c1)); cell_trip(a1, q1, c1, o1, bs, s, cbits, sb << 1);
+                    asm volatile("" ::"v"(c1)); cell_trip<LEAN>(a1, q1, c1, o1, bs, s, cbits, sb << 1);
                     ST3R_LD(o3, a3, q3, c3)
-                    asm volatile("" ::"v"(c2)); cell_trip(a2, q2, c2, o2, bs, s, cbits, sb << 2);
-                    asm volatile("" ::"v"(c3)); cell_trip(a3, q3, c3, o3, bs, s, cbits, sb << 3);
+                    asm volatile("" ::"v"(c2)); cell_trip<LEAN>(a2, q2, c2, o2, bs, s, cbits, sb << 2);
+                    asm volatile("" ::"v"(c3)); cell_trip<LEAN>(a3, q3, c3, o3, bs, s, cbits, sb << 3);
 #undef ST3R_LD
                     e = en;
                 }
@@ -281,6 +302,8 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd_cells(int C, int W, int H, in
                     }
                 }
             }
+            };
+            if (__builtin_amdgcn_readfirstlane(sHard[nb & 1]) == 0) windows(std::true_type{}); else windows(std::false_type{});
         }
     }
     // the last batch that ran: its flags are complete once every wave is past its trips
