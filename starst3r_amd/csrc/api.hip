@@ -210,12 +210,13 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
                         const int32_t* cum, const uint64_t* rects, const uint64_t* rectbase, int tight, int64_t n_pairs,
                         float* v_splats,
-                        bool end_in_offsets);
+                        bool end_in_offsets, st3r_vtile_ref* defer);
 int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, const float* quats, const float* scales,
                              const float* opacities, const float* sh, int sh_stride, const float* viewmats,
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
-                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end, bool range_major);
+                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end, bool range_major,
+                             const st3r_vtile_ref* slots);
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render, bool sums_cleared);
 
@@ -472,7 +473,12 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     GET(SLOT_ALPHA, float, n_px, alpha);
     GET(SLOT_LAST, int32_t, n_px, last);
     GET(SLOT_VRENDER, float, n_px * 3, v_rgb);
-    GET(SLOT_VSPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, v_splats);
+    // Round 5: the per-pair sums of the backward's (record, tile) slots are taken inside the projection backward; the 48-byte
+    // per-pair gradient records (and k_gather_vtile's launch) exist only under debug flag 16384
+    const bool two_kernels = (ctx->debug_flags & 16384) != 0;
+    float* v_splats = nullptr;
+    if (two_kernels) { GET(SLOT_VSPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, vs_); v_splats = vs_; }
+    st3r_vtile_ref slots_{}; st3r_vtile_ref* slots = two_kernels ? nullptr : &slots_;
     st3r_prof_begin(ctx, s, STG_BLEND_FWD);
     rc = st3r_blend_fwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb,
                              alpha, last, true, eio);
@@ -486,7 +492,7 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
                              last, v_rgb, nullptr, ro.cum, (ctx->debug_flags & 2) ? nullptr : ro.rects,
                              (ctx->debug_flags & 2) ? nullptr : ro.rectbase, 1, n_pairs, v_splats,
-                             eio);
+                             eio, slots);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_PROJECT_BWD);
@@ -507,14 +513,14 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
             const int g0 = (int)((int64_t)N * j / K), g1 = (int)((int64_t)N * (j + 1) / K);
             rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W,
                                           H, 0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, gstage, accumulate, g0,
-                                          g1, true);
+                                          g1, true, slots);
             if (!rc) HIP_TRY(hipEventRecord(ctx->ev_range_bwd[j], s));
         }
         if (!rc) ctx->ranges_recorded = K;
     } else {
         rc = st3r_project_sh_bwd_impl(s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, W, H,
                                       0.3f, ro.splats, v_splats, (float)C, opac_fac, scale_fac, grads, accumulate, 0, -1,
-                                      false);
+                                      false, slots);
     }
     st3r_prof_end(ctx, s, STG_PROJECT_BWD);
     *ro_out = ro;
@@ -626,7 +632,7 @@ ST3R_EXPORT int st3r_gs_raster_train(st3r_ctx* ctx, void* stream, int N, int C, 
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_BLEND_BWD);
     rc = st3r_blend_bwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, alpha,
-                             last, v_rgb, nullptr, ro.cum, ro.rects, ro.rectbase, 1, n_pairs, v_records, true);
+                             last, v_rgb, nullptr, ro.cum, ro.rects, ro.rectbase, 1, n_pairs, v_records, true, nullptr);
     st3r_prof_end(ctx, s, STG_BLEND_BWD);
     if (rc) return rc;
     const int Hi = H - 10, Wi = W - 10;

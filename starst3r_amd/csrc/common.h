@@ -96,6 +96,9 @@ enum Stage {
 
 #define ST3R_SPLIT_VIEWS 1000   // internal: more than 2^31 tile intersections, the caller may retry with fewer views
 
+// the backward's stamped (record, tile) slots, handed to the kernel that sums them per pair (gs_blend.hip -> gs_project_bwd.hip)
+struct st3r_vtile_ref { const int32_t* cum; const float* vtile; int stamp; unsigned vt_cap; };
+
 struct st3r_ctx {
     int device;
     void* slot_ptr[SLOT_COUNT];
@@ -108,7 +111,9 @@ struct st3r_ctx {
                       // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 11 (2048): under a communicator
                       // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip); 12 (4096): the fused
                       // path drops the tiles of small rectangles that the exact ellipse test rejects (masked rectangles);
-                      // 13 (8192): EXPERIMENT, the fused backward on the cell-granular kernel (gs_blend_cells.hip; slower)
+                      // 13 (8192): EXPERIMENT, the fused backward on the cell-granular kernel (gs_blend_cells.hip; slower);
+                      // 14 (16384): the training calls sum the backward's slots in k_gather_vtile (a launch and a 48-byte
+                      // record per pair of their own, as before round 5) instead of inside the projection backward
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     uint32_t scan_gen;   // single-pass scan (gs_isect.hip): generation of its status words
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back

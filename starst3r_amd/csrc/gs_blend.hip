@@ -742,10 +742,12 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
                         const int32_t* cum, const uint64_t* rects, const uint64_t* rectbase, int tight, int64_t n_pairs,
-                        float* v_splats, bool end_in_offsets) {
+                        float* v_splats, bool end_in_offsets, st3r_vtile_ref* defer) {
+    // defer != NULL: the caller's next kernel sums the slots per pair itself (gs_project_bwd.hip); v_splats is not written
+    if (defer) *defer = st3r_vtile_ref{cum, nullptr, 0, 0u};
     if (n_isects == 0) {
-        HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
-        return ST3R_OK;
+        if (!defer) HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
+        return ST3R_OK;   // (defer: every pair's slot range is empty -- `cum` is all zeros -- and vt_cap = 0 guards the rest)
     }
     uint64_t* cmask; int64_t words; int32_t* tile_nb;
     int rc = hand_off_buffers(ctx, C, tile_w, tile_h, n_isects, &cmask, &words, &tile_nb);
@@ -778,6 +780,7 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
                            v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp, vt_cap);
     LAUNCH_CHECK();
+    if (defer) { *defer = st3r_vtile_ref{cum, vtile, stamp, vt_cap}; return ST3R_OK; }
     hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp, vt_cap,
                        (float4*)v_splats);
     LAUNCH_CHECK();
@@ -795,5 +798,5 @@ ST3R_EXPORT int st3r_gs_blend_bwd(st3r_ctx* ctx, void* stream, int C, int width,
     ARG_CHECK(n_isects >= 0 && n_isects < 2147483647LL && (n_isects == 0 || flatten_ids));
     return st3r_blend_bwd_impl(ctx, (hipStream_t)stream, C, width, height, tile_w, tile_h, splats, offsets,
                                flatten_ids, n_isects, alpha, last_ids, v_rgb, v_alpha, cum_tiles, nullptr, nullptr, 0, n_pairs,
-                               v_splats, false);
+                               v_splats, false, nullptr);
 }

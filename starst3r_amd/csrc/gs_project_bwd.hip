@@ -6,20 +6,33 @@
 // Replaces gsplat fully_fused_projection_packed_bwd + spherical_harmonics bwd (autograd
 // through starster/gs.py:76-87 from loss.backward(), starster/gs.py:153) and folds in the
 // gradients of the two regularisers of starster/gs.py:132-134.
+//
+// Round 5, GATHER = true (the fused training calls): the kernel also does what k_gather_vtile (gs_blend.hip) did in a launch
+// of its own -- summing a (camera, Gaussian) pair's stamped (record, tile) slots in slot order.  A workgroup's 256 Gaussians
+// are, for one camera, 256 consecutive pairs, i.e. ONE contiguous slot range: the same cooperative pattern (lane = slot
+// through LDS, then lane = pair adds its own rows, next 256 slots in flight), once per camera, and the nine sums go straight
+// into the chain rule instead of through 48 bytes per pair of HBM each way (0.58 GB per step at SYNTH-1M).  Same sums in the
+// same order: bit-identical gradients.
 #include "common.h"
+#include "blend_common.h"
 
 #define CAM_STRIDE 32
 #define SH_C0 0.2820947917738781f
 #define SH_C1 0.48860251190292f
 
-__global__ __launch_bounds__(256) void k_project_sh_bwd(
+template <bool GATHER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_project_sh_bwd(
     int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ sh,
     int sh_stride, const float* __restrict__ viewmats, const float* __restrict__ Ks,
     const float* __restrict__ campos, int W, int H, float eps2d, const float4* __restrict__ splats,
     const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads, int accumulate,
-    int g_begin, int g_end, int range_major) {
+    int g_begin, int g_end, int range_major, const int32_t* __restrict__ cum, const float* __restrict__ vtile, int stamp,
+    unsigned vt_cap) {
     extern __shared__ float cam[];
+    constexpr int ROW = ACC_VALS;   // odd stride: rows of neighbouring slots fall into different banks
+    __shared__ int sCum[GATHER ? 257 : 1];
+    __shared__ float sVal[GATHER ? 256 * ROW : 1];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float* o = cam + c * CAM_STRIDE;
         const float* V = viewmats + 16 * c;
@@ -36,8 +49,10 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
         o[20] = campos[3 * c]; o[21] = campos[3 * c + 1]; o[22] = campos[3 * c + 2];
     }
     __syncthreads();
-    const int g = g_begin + blockIdx.x * blockDim.x + threadIdx.x;   // one launch per Gaussian range (see comm.hip)
-    if (g >= g_end) return;
+    const int gbase = g_begin + blockIdx.x * blockDim.x;   // one launch per Gaussian range (see comm.hip)
+    const bool valid = gbase + (int)threadIdx.x < g_end;
+    if (!GATHER && !valid) return;
+    const int g = valid ? gbase + (int)threadIdx.x : g_end - 1;   // (GATHER: every thread stays for the barriers)
 
     const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
     const float opac = opacities[g];
@@ -49,27 +64,32 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
     for (int i = 0; i < 12; ++i) k[i] = kp[i];
     const float inv_norm = 1.0f / sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
     qw *= inv_norm; qx *= inv_norm; qy *= inv_norm; qz *= inv_norm;
-    float Rq[9];
-    {
+    // rotation and M = Rq diag(s): needed for the covariance here and for the quaternion / scale chain rule after the camera
+    // loop -- computed twice rather than kept in 18 registers across the loop (the fused kernel is short of them)
+    const float sc[3] = {s0, s1, s2};
+    auto rot_and_m = [&](float (&Rq)[9], float (&M)[9]) {
         float x2 = qx * qx, y2 = qy * qy, z2 = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz;
         float wx = qw * qx, wy = qw * qy, wz = qw * qz;
         Rq[0] = 1.0f - 2.0f * (y2 + z2); Rq[1] = 2.0f * (xy - wz); Rq[2] = 2.0f * (xz + wy);
         Rq[3] = 2.0f * (xy + wz); Rq[4] = 1.0f - 2.0f * (x2 + z2); Rq[5] = 2.0f * (yz - wx);
         Rq[6] = 2.0f * (xz - wy); Rq[7] = 2.0f * (yz + wx); Rq[8] = 1.0f - 2.0f * (x2 + y2);
-    }
-    const float sc[3] = {s0, s1, s2};
-    float M[9];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) M[i * 3 + j] = Rq[i * 3 + j] * sc[j];
+            for (int j = 0; j < 3; ++j) M[i * 3 + j] = Rq[i * 3 + j] * sc[j];
+    };
     float cov[6];
-    cov[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
-    cov[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
-    cov[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
-    cov[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
-    cov[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
-    cov[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    {
+        float Rq[9], M[9];
+        rot_and_m(Rq, M);
+        cov[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+        cov[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+        cov[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+        cov[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+        cov[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+        cov[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+        asm volatile("" : "+v"(cov[0]), "+v"(cov[1]), "+v"(cov[2]), "+v"(cov[3]), "+v"(cov[4]), "+v"(cov[5]));
+    }
 
     float v_mean[3] = {0, 0, 0};
     float vSw[6] = {0, 0, 0, 0, 0, 0};  // symmetric world-covariance gradient: 00 01 02 11 12 22
@@ -80,13 +100,60 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
 
     for (int c = 0; c < C; ++c) {
         const int64_t pid = (int64_t)c * N + g;
+        float4 g0, g1, g2;
+        if (GATHER) {
+            // ---- the pair sums of this camera's 256 pairs (k_gather_vtile's loop, see gs_blend.hip)
+            const int tid = threadIdx.x;
+            const int64_t p0 = (int64_t)c * N + gbase;
+            const int np = min(256, g_end - gbase);
+            __syncthreads();   // the previous camera's readers of sCum / sVal are done
+            if (tid == 0) sCum[0] = p0 == 0 ? 0 : cum[p0 - 1];
+            sCum[tid + 1] = cum[p0 + min(tid, np - 1)];
+            __syncthreads();
+            const int s0 = sCum[0], s1 = sCum[np];
+            const int my_start = sCum[tid], my_end = tid < np ? sCum[tid + 1] : sCum[tid];
+            float acc[ACC_VALS];
+#pragma unroll
+            for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] = 0.f;
+            float2 q0, q1, q2, q3, q4;
+            auto fetch = [&](int u) {
+                q0 = q1 = q2 = q3 = q4 = make_float2(0.f, 0.f);   // stamp 0 = never written
+                if (u < s1 && (unsigned)u < vt_cap) {   // (vt_cap: see the flush of k_blend_bwd)
+                    const float2* src = reinterpret_cast<const float2*>(vtile + (int64_t)u * VT_STRIDE);
+                    q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; q4 = src[4];
+                }
+            };
+            if (s1 > s0) fetch(s0 + tid);
+            for (int base = s0; base < s1; base += 256) {
+                const bool live = __float_as_int(q4.y) == stamp;
+                float* row = sVal + tid * ROW;
+                row[0] = live ? q0.x : 0.f; row[1] = live ? q0.y : 0.f; row[2] = live ? q1.x : 0.f;
+                row[3] = live ? q1.y : 0.f; row[4] = live ? q2.x : 0.f; row[5] = live ? q2.y : 0.f;
+                row[6] = live ? q3.x : 0.f; row[7] = live ? q3.y : 0.f; row[8] = live ? q4.x : 0.f;
+                __syncthreads();
+                fetch(base + 256 + tid);
+                const int lo = max(my_start, base) - base, hi = min(my_end, base + 256) - base;
+                for (int r = lo; r < hi; ++r) {
+                    const float* src = sVal + r * ROW;
+#pragma unroll
+                    for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] += src[k2];
+                }
+                __syncthreads();
+            }
+            g0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            g1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            g2 = make_float4(acc[8], 0.f, 0.f, 0.f);
+            if (!valid) continue;
+        }
         const float4 r2 = splats[pid * 3 + 2];
         if (__float_as_int(r2.z) <= 0) continue;  // culled pair
         const float4 r0 = splats[pid * 3 + 0];
         const float4 r1 = splats[pid * 3 + 1];
-        const float4 g0 = v_splats[pid * 3 + 0];
-        const float4 g1 = v_splats[pid * 3 + 1];
-        const float4 g2 = v_splats[pid * 3 + 2];
+        if (!GATHER) {
+            g0 = v_splats[pid * 3 + 0];
+            g1 = v_splats[pid * 3 + 1];
+            g2 = v_splats[pid * 3 + 2];
+        }
         const float* o = cam + c * CAM_STRIDE;
         const float R[9] = {o[0], o[1], o[2], o[4], o[5], o[6], o[8], o[9], o[10]};
         v_opac += g0.z;
@@ -191,8 +258,12 @@ __global__ __launch_bounds__(256) void k_project_sh_bwd(
         vSw[5] += R[2] * U[2] + R[5] * U[5] + R[8] * U[8];
     }
 
+    if (GATHER && !valid) return;   // (past the last barrier)
     // ---- covariance -> (quat, scale), once per Gaussian ----
     // S_w = M M^T, M = Rq diag(s):  v_M = 2 vSw M
+    float Rq[9], M[9];
+    asm volatile("" : "+v"(qw), "+v"(qx), "+v"(qy), "+v"(qz));   // (keeps hipcc from carrying the first evaluation across the loop)
+    rot_and_m(Rq, M);
     const float W9[9] = {vSw[0], vSw[1], vSw[2], vSw[1], vSw[3], vSw[4], vSw[2], vSw[4], vSw[5]};
     float vM[9];
 #pragma unroll
@@ -251,16 +322,23 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
                              const float* opacities, const float* sh, int sh_stride, const float* viewmats,
                              const float* Ks, const float* campos, int width, int height, float eps2d,
                              const float* splats, const float* v_splats, float reg_views, float opac_fac,
-                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end, bool range_major) {
+                             float scale_fac, float* grads, bool accumulate, int g_begin, int g_end, bool range_major,
+                             const st3r_vtile_ref* slots) {
     if (g_end < 0) g_end = N;
     if (N == 0 || g_end <= g_begin) return ST3R_OK;
     float reg_o_k = reg_views * opac_fac / (float)N;
     float reg_s_k = reg_views * scale_fac / (3.0f * (float)N);
     size_t shmem = (size_t)C * CAM_STRIDE * sizeof(float);
-    hipLaunchKernelGGL(k_project_sh_bwd, dim3(ceil_div(g_end - g_begin, 256)), dim3(256), shmem, s, N, C, means, quats,
-                       scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d, (const float4*)splats,
-                       (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin, g_end,
-                       range_major ? 1 : 0);
+    if (slots)   // fused training calls: the pair sums are gathered from the backward's slots in this kernel
+        hipLaunchKernelGGL(k_project_sh_bwd<true>, dim3(ceil_div(g_end - g_begin, 256)), dim3(256), shmem, s, N, C, means,
+                           quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d,
+                           (const float4*)splats, (const float4*)nullptr, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin,
+                           g_end, range_major ? 1 : 0, slots->cum, slots->vtile, slots->stamp, slots->vt_cap);
+    else
+        hipLaunchKernelGGL(k_project_sh_bwd<false>, dim3(ceil_div(g_end - g_begin, 256)), dim3(256), shmem, s, N, C, means,
+                           quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d,
+                           (const float4*)splats, (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin,
+                           g_end, range_major ? 1 : 0, (const int32_t*)nullptr, (const float*)nullptr, 0, 0u);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
@@ -275,5 +353,5 @@ ST3R_EXPORT int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && v_splats && grads);
     return st3r_project_sh_bwd_impl((hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats,
                                     Ks, campos, width, height, eps2d, splats, v_splats, reg_views, opac_fac, scale_fac,
-                                    grads, false, 0, -1, false);
+                                    grads, false, 0, -1, false, nullptr);
 }

@@ -424,6 +424,35 @@ def test_masked_rectangles_drop_only_dead_records(ctx, name):
     assert float((g1 - g0).abs().max()) <= (2e-3 if name.startswith("fuzz") else 2e-5) * scale
 
 
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "many", "one"] + FUZZ[:4])
+def test_pair_sums_inside_the_projection_backward_are_bit_identical(ctx, name):
+    """Round 5: the fused training calls sum a pair's (record, tile) slots inside the projection backward
+    (gs_project_bwd.hip, GATHER) instead of in k_gather_vtile + a 48-byte record per pair (debug flag 16384 keeps the two
+    kernels): the same sums in the same order, so the 23 N gradients and the loss are the same bits."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make(name)
+    N = g["means"].shape[0]
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
+    torch.manual_seed(5)
+    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
+    out = []
+    try:
+        for flag in (16384, 0):
+            ops.set_debug(ctx, flag)
+            grads = torch.full((23 * N,), float("nan"), device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+            ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+            torch.cuda.synchronize()
+            out.append((grads, float(loss[0])))
+    finally:
+        ops.set_debug(ctx, 0)
+    (g0, l0), (g1, l1) = out
+    assert l0 == l1 and bool(torch.isfinite(g1).all())
+    assert torch.equal(g0.view(torch.int32), g1.view(torch.int32))
+
+
 @pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
 def test_experimental_cell_backward_agrees_with_the_quadrant_backward(ctx, name):
     """Debug flag 8192 (round 5 experiment, measured 0.86 ms SLOWER: tools/experiments/README.md): the blend backward with a
