@@ -295,7 +295,7 @@ def valu_issue(per_stage_ms, N, views, W, H, world):
     mix_ns = {"blend_bwd": 1.17}
     out = {"source": f"profiles/pmc_traffic.json (commit {rec.get('commit')}): SQ_INSTS_VALU per launch of k_blend_fwd_cells / "
                      "k_blend_bwd; kernel time = this run's stage time (HIP events) x the kernel's share of the stage in the "
-                     "same profile (the backward stage also holds k_gather_vtile); 1024 SIMDs at 2.4 GHz",
+                     "same profile; 1024 SIMDs at 2.4 GHz",
            "opcode_mix_source": "tools/probe/valu_cost.hip issue costs (add / mul / fmac 1.0-1.1 ns, 3-source fma 1.47, compares / "
                                 "selects / min / max / DPP 1.7-1.8, exp / rcp 3.4 ns per instruction and SIMD) x the "
                                 "instruction budget of DESIGN.md section 4"}

@@ -19,7 +19,7 @@ with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
             "SYNTH-1M (1 M Gaussians, 8 x 1920x1080), 1 MI355X; the run also executes the alignment, matching and condensation benches.\n"
             f"Command: `cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_{tag}/trace -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline` (tools/profile_round.sh <tag>).\n"
             f"bench.py's own line in the same (profiled) run: {line['value']:.2f} iters/s; stage_ms (HIP events inside bench.py): {stage}\n"
-            "(blend_bwd stage = k_blend_bwd + k_gather_vtile; loss = k_ssim_fused; sort / sort_depth = k_rs_hist + k_rs_scan_hist + k_rs_pass of radix_sort.hip; scan = k_scan_chained; emit = k_isect_gather + k_isect_wg_scan + k_isect_emit_d.)\n"
+            "(blend_bwd stage = k_blend_bwd -- the per-pair sums of its slots are taken by k_project_sh_bwd since round 5 --; loss = k_ssim_fused; sort / sort_depth = k_rs_hist + k_rs_scan_hist + k_rs_pass of radix_sort.hip; scan = k_scan_chained; emit = k_isect_gather + k_isect_wg_scan + k_isect_emit_d.)\n"
             f"(the bench line of the same build without the profiler is {tag}_bench_default.json.)\n\n")
     f.write("\n".join(body[2:44]) + "\n")
 shutil.copy(glob.glob(f"{T}/trace/runc/*_kernel_stats.csv")[0], f"profiles/{tag}_rocprof_kernel_stats.csv")
