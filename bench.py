@@ -748,6 +748,13 @@ def main():
                     "kernel_bytes": ab_ref.get(dom), "kernel_equiv_GBps": (ab_ref[dom] / (dom_ms * 1e-3) / 1e9) if dom in ab_ref and dom_ms > 0 else None,
                     "whole_iter_bytes": sum(ab_ref.values()),
                     "whole_iter_equiv_GBps": sum(ab_ref.values()) / (ms_per_step * 1e-3) / 1e9},
+                # Since round 5 the per-pair sums of the backward's (record, tile) slots are taken inside the projection backward
+                # (k_gather_vtile's 0.25 ms left the blend_bwd stage, project_bwd grew by 0.12): the two backward stages together,
+                # comparable across rounds (round 4: 3.97 GB / 2.47 ms = 0.20)
+                "backward_stages_combined": (lambda b, t: {"stages": "blend_bwd + project_bwd", "algorithmic_bytes": b, "ms": t,
+                                                            "achieved": b / (t * 1e-3) / 1e9 if t > 0 else None,
+                                                            "frac": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS if t > 0 else None})(
+                    ab["blend_bwd"] + ab["project_bwd"], per_stage.get("blend_bwd", 0.0) + per_stage.get("project_bwd", 0.0)),
                 "algorithmic_bytes_by_stage": ab,
                 "stage_ms": per_stage,
                 "stage_ms_samples_in_timed_region": timed_samples,
@@ -759,6 +766,7 @@ def main():
         out["roofline"].update({f"ms_{k}": v for k, v in per_stage.items()})
         out["roofline"]["whole_iter_GBps"] = out["roofline"]["whole_iter"]["achieved"]
         out["roofline"]["whole_iter_frac"] = out["roofline"]["whole_iter"]["frac"]
+        out["roofline"]["backward_stages_frac"] = out["roofline"]["backward_stages_combined"]["frac"]
         if drift and "steps_180_200" in drift:   # SURVEY 8(d)'s >= 200-step regime next to the driver's 20-step headline
             out["value_steps_180_200"] = 1e3 / drift["steps_180_200"]
         out["roofline"]["valu_issue"] = valu_issue(per_stage, N, args.views, W, H, world)

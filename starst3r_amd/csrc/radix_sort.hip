@@ -5,7 +5,7 @@
 // Structure ("onesweep", Adinets & Merrill 2022, restated for wave64 and 160 KB of LDS):
 //   k_rs_hist        one pass over the keys: 256-bin histograms of ALL digits at once (LDS atomics; a wave whose
 //                    lanes agree on a digit -- the rule for the high digits of depth / tile keys -- adds once);
-//   k_rs_scan_hist   exclusive scan of each histogram = global base of every bin;
+//   (the exclusive scan of each histogram = global base of every bin is taken inside k_rs_pass, by every workgroup)
 //   k_rs_pass        one launch per 8-bit digit.  A workgroup (16 waves; 8 for small inputs) owns a tile of 16384 (32-bit keys) or 8192
 //                    (64-bit keys) consecutive items.  Ranking is wave-local and stable: wave w holds items
 //                    [w*64*IPT, (w+1)*64*IPT) of the tile as IPT rows of 64 consecutive items; per row the lanes
@@ -111,25 +111,6 @@ __global__ __launch_bounds__(HIST_THREADS) void k_rs_hist(const K* __restrict__ 
     }
 }
 
-// hist[p][d] <- exclusive prefix over d of the sum of the HIST_COPIES partial histograms (one workgroup of 256 threads)
-__global__ __launch_bounds__(RADIX) void k_rs_scan_hist(uint32_t* __restrict__ hist, int passes) {
-    __shared__ uint32_t wsum[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int p = 0; p < passes; ++p) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int c = 0; c < HIST_COPIES; ++c) v += hist[c * (MAX_PASSES * RADIX) + p * RADIX + threadIdx.x];
-        const uint32_t inc = wave_incl_scan_u32(v, lane);
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) base += i < w ? wsum[i] : 0u;
-        hist[p * RADIX + threadIdx.x] = base + inc - v;
-        __syncthreads();
-    }
-}
-
 template <typename K, int THREADS, int IPT>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, const int32_t* __restrict__ vin,
                                                      K* __restrict__ kout, int32_t* __restrict__ vout, int64_t n,
@@ -146,6 +127,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     __shared__ u64 gexc[RADIX];
     __shared__ long long gofs[RADIX];
     __shared__ uint32_t wsum[4];
+    __shared__ uint32_t hsum[4];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
@@ -165,6 +147,15 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     for (int i = 0; i < IPT; ++i) {
         const int li = wbase + i * 64;
         key[i] = li < tcount ? kin[tbase + li] : K(0);
+    }
+    // this pass's global digit counts (the HIST_COPIES partial histograms of k_rs_hist; in flight while the keys are ranked).
+    // Their exclusive scan -- the global base of every bin -- is taken by every workgroup for itself further down, next to
+    // the tile-local one (round 5: it used to be a launch of one workgroup, k_rs_scan_hist, between the histogram and the
+    // first pass: 4.6 us twice per step).
+    uint32_t hv = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int c = 0; c < HIST_COPIES; ++c) hv += hist_base[c * (MAX_PASSES * RADIX) + tid];
     }
     if (vin) {   // in flight while the keys are ranked
 #pragma unroll
@@ -209,13 +200,16 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     }
     // tile-local exclusive scan of the digit counts
     const uint32_t inc = wave_incl_scan_u32(cnt, lane);
-    if (tid < RADIX && lane == 63) wsum[w] = inc;
+    const uint32_t hinc = wave_incl_scan_u32(hv, lane);
+    if (tid < RADIX && lane == 63) { wsum[w] = inc; hsum[w] = hinc; }
     __syncthreads();
+    uint32_t hexc = 0;   // global base of bin `tid` (threads below RADIX)
     if (tid < RADIX) {
-        uint32_t base = 0;
+        uint32_t base = 0, hb = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) base += i < w ? wsum[i] : 0u;
+        for (int i = 0; i < 4; ++i) { base += i < w ? wsum[i] : 0u; hb += i < w ? hsum[i] : 0u; }
         lbase[tid] = base + inc - cnt;
+        hexc = hb + hinc - hv;
     }
     // chained scan over the tiles, LB lanes per digit: lane j of a digit's group reads the status word of the
     // (j+1)-th predecessor, then the next LB ...; the group adds aggregates up to the nearest inclusive prefix.
@@ -259,7 +253,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
         }
     }
     __syncthreads();
-    if (tid < RADIX) gofs[tid] = (long long)((u64)hist_base[tid] + gexc[tid]) - (long long)lbase[tid];
+    if (tid < RADIX) gofs[tid] = (long long)((u64)hexc + gexc[tid]) - (long long)lbase[tid];
     __syncthreads();
 
     // regroup by digit in LDS, then leave in runs that are contiguous in the destination
@@ -318,7 +312,6 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
     const int hist_blocks = (int)min((int64_t)1024, (n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
     hipLaunchKernelGGL(k_rs_hist<K>, dim3(hist_blocks), dim3(HIST_THREADS), 0, s, keys_in, n, begin_bit, end_bit, passes,
                        hist, n_dev);
-    hipLaunchKernelGGL(k_rs_scan_hist, dim3(1), dim3(RADIX), 0, s, hist, passes);
     const K* kin = keys_in;
     const int32_t* vin = vals_in;
     for (int ps = 0; ps < passes; ++ps) {
