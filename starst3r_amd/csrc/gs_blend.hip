@@ -516,7 +516,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
             //     of several thousand.  (Such a conic has an axis ratio above ~30: needles.)
             // Both are properties of the RECORD, decided here once instead of per pixel and trip.
             const float det_ = a.w * b.y - b.x * b.x;
-            const bool hard = my_cb && !(a.z <= 0.999f && a.w > 0.f && b.y > 0.f && det_ >= 2e-3f * (a.w * b.y));
+            // (0.998, not 0.999: v_exp_f32 is good to an ulp, and opacity * exp2(P) must stay below the clamp whatever it returns)
+            const bool hard = my_cb && !(a.z <= 0.998f && a.w > 0.f && b.y > 0.f && det_ >= 2e-3f * (a.w * b.y));
             const uint64_t cw = __builtin_amdgcn_ballot_w64(hard);
             if (t == 0) sClampW = cw;
             if (my_cb && rectbase) {   // fused path: slot base and rectangle in one gathered word

@@ -98,7 +98,7 @@ struct CellPx {
 // operation, as the quadrant kernel (blend_power / explicit fma: the images are bit-identical, tests), but exec-masked:
 // lanes that fail the alpha test skip the updates, a trip that no lane passes skips the body.  The saturation
 // bookkeeping sits behind a wave-uniform branch that is almost never taken.
-// LEAN (round 5): the batch holds only records whose conic is safely positive definite and whose opacity is <= 0.999 (decided
+// LEAN (round 5): the batch holds only records whose conic is safely positive definite and whose opacity is <= 0.998 (decided
 // per record while staging, see `hard` in the kernel): P <= 0 holds for every pixel and opacity * exp2(P) cannot reach the clamp,
 // so the trip drops gsplat's `sigma < 0` test and the min -- two four-cycle instructions of ~25 (tools/probe/valu_issue.hip);
 // the values are bit-identical to the full trip's.
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(7))) void k
 #ifdef CELLS_ABL_NEVER_HARD
             hard = false;
 #else
-            hard = !(ra.z <= 0.999f && ra.w > 0.f && rb.y > 0.f && (ra.w * rb.y - rb.x * rb.x) >= 2e-3f * (ra.w * rb.y));
+            hard = !(ra.z <= 0.998f && ra.w > 0.f && rb.y > 0.f && (ra.w * rb.y - rb.x * rb.x) >= 2e-3f * (ra.w * rb.y));
 #endif
 #ifdef CELLS_NO_TEST
             cm = 0xFFFFu;
