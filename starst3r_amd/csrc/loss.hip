@@ -425,6 +425,7 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k
     }
 }
 
+#ifdef SSIM_VERTICAL_FIRST   // (measured alternative, tools/experiments/README.md: not compiled into the product library)
 // ------------------------------------------------------------------------------------------------------------------
 // Round 5: the same fused loss with the forward's two passes in the other order -- VERTICAL first, on
 // the raw x, y.  A forward thread owns one element (column, channel) of the 84-column row segment and keeps the last twelve
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(SSIM_V_WAVE
         atomicAdd(&sums[2 * cam + 1], (double)b);
     }
 }
+#endif   // SSIM_VERTICAL_FIRST
 
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render, bool sums_cleared) {

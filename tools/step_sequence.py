@@ -1,3 +1,6 @@
+"""Kernel sequence of ONE training step from a rocprofv3 kernel trace (the launches between the last two k_adam4 calls but one):
+name, duration, gap to the previous kernel; totals.  usage: python tools/step_sequence.py <rocprofv3 output dir>
+(e.g. after `rocprofv3 --kernel-trace -f csv -d gpurun_out/seq -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-only`)."""
 import csv, glob, sys
 fn = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(fn)), key=lambda r: int(r["Start_Timestamp"]))
