@@ -9,8 +9,8 @@
 //
 // Round 5, GATHER = true (the fused training calls): the kernel also does what k_gather_vtile (gs_blend.hip) did in a launch
 // of its own -- summing a (camera, Gaussian) pair's stamped (record, tile) slots in slot order.  A workgroup's 256 Gaussians
-// are, for one camera, 256 consecutive pairs, i.e. ONE contiguous slot range: the same cooperative pattern (lane = slot
-// through LDS, then lane = pair adds its own rows, next 256 slots in flight), once per camera, and the nine sums go straight
+// are, for one camera, 256 consecutive pairs -- a wave's 64 one contiguous slot range: the same cooperative pattern (lane = slot
+// through LDS, then lane = pair adds its own rows, the next slots in flight), per wave and camera, and the nine sums go straight
 // into the chain rule instead of through 48 bytes per pair of HBM each way (0.58 GB per step at SYNTH-1M).  Same sums in the
 // same order: bit-identical gradients.
 #include "common.h"
@@ -31,7 +31,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     unsigned vt_cap) {
     extern __shared__ float cam[];
     constexpr int ROW = ACC_VALS;   // odd stride: rows of neighbouring slots fall into different banks
-    __shared__ int sCum[GATHER ? 257 : 1];
     __shared__ float sVal[GATHER ? 256 * ROW : 1];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float* o = cam + c * CAM_STRIDE;
@@ -52,7 +51,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int gbase = g_begin + blockIdx.x * blockDim.x;   // one launch per Gaussian range (see comm.hip)
     const bool valid = gbase + (int)threadIdx.x < g_end;
     if (!GATHER && !valid) return;
-    const int g = valid ? gbase + (int)threadIdx.x : g_end - 1;   // (GATHER: every thread stays for the barriers)
+    const int g = valid ? gbase + (int)threadIdx.x : g_end - 1;   // (GATHER: every lane of a wave takes part in its gather)
 
     const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
     const float opac = opacities[g];
@@ -102,16 +101,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const int64_t pid = (int64_t)c * N + g;
         float4 g0, g1, g2;
         if (GATHER) {
-            // ---- the pair sums of this camera's 256 pairs (k_gather_vtile's loop, see gs_blend.hip)
-            const int tid = threadIdx.x;
-            const int64_t p0 = (int64_t)c * N + gbase;
-            const int np = min(256, g_end - gbase);
-            __syncthreads();   // the previous camera's readers of sCum / sVal are done
-            if (tid == 0) sCum[0] = p0 == 0 ? 0 : cum[p0 - 1];
-            sCum[tid + 1] = cum[p0 + min(tid, np - 1)];
-            __syncthreads();
-            const int s0 = sCum[0], s1 = sCum[np];
-            const int my_start = sCum[tid], my_end = tid < np ? sCum[tid + 1] : sCum[tid];
+            // ---- the pair sums of this camera's pairs, WAVE by wave: a wave's 64 Gaussians are 64 consecutive pairs, i.e. one
+            // contiguous slot range of its own -- lane = slot through the wave's LDS rows (coalesced, the next 64 slots in
+            // flight), then lane = pair adds the rows of its own slots in slot order.  No workgroup barrier: the four waves of
+            // a workgroup walk their ranges independently (with 256-slot chunks behind __syncthreads the kernel took 0.31 ms
+            // at four waves per SIMD; the sums and their order are the same).
+            const int lane = threadIdx.x & 63;
+            float* wval = sVal + (threadIdx.x >> 6) * (64 * ROW);
+            // (a thread past g_end sits on the last pair: its range is the empty one BEHIND that pair, so that lane 63 still
+            // closes the wave's range)
+            const int my_end = cum[pid];
+            const int my_start = !valid ? my_end : (pid == 0 ? 0 : cum[pid - 1]);
+            const int s0 = __builtin_amdgcn_readfirstlane(my_start);
+            const int s1 = __builtin_amdgcn_readlane(my_end, 63);
             float acc[ACC_VALS];
 #pragma unroll
             for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] = 0.f;
@@ -123,22 +125,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                     q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; q4 = src[4];
                 }
             };
-            if (s1 > s0) fetch(s0 + tid);
-            for (int base = s0; base < s1; base += 256) {
+            if (s1 > s0) fetch(s0 + lane);
+            for (int base = s0; base < s1; base += 64) {
                 const bool live = __float_as_int(q4.y) == stamp;
-                float* row = sVal + tid * ROW;
+                float* row = wval + lane * ROW;
                 row[0] = live ? q0.x : 0.f; row[1] = live ? q0.y : 0.f; row[2] = live ? q1.x : 0.f;
                 row[3] = live ? q1.y : 0.f; row[4] = live ? q2.x : 0.f; row[5] = live ? q2.y : 0.f;
                 row[6] = live ? q3.x : 0.f; row[7] = live ? q3.y : 0.f; row[8] = live ? q4.x : 0.f;
-                __syncthreads();
-                fetch(base + 256 + tid);
-                const int lo = max(my_start, base) - base, hi = min(my_end, base + 256) - base;
+                wave_lds_sync();
+                fetch(base + 64 + lane);
+                const int lo = max(my_start, base) - base, hi = min(my_end, base + 64) - base;
                 for (int r = lo; r < hi; ++r) {
-                    const float* src = sVal + r * ROW;
+                    const float* src = wval + r * ROW;
 #pragma unroll
                     for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] += src[k2];
                 }
-                __syncthreads();
+                wave_lds_sync();
             }
             g0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
             g1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
