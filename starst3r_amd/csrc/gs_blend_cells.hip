@@ -214,6 +214,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(7))) void k
             cm = 0xFFFFu;
 #else
             cm = no_cull ? 0xFFFFu : cell_mask16(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, g.tx0, g.ty0);
+#ifdef CELLS_ABL_TEST_TWICE   // ablation: what one evaluation of the cell test costs (the second one on opaque copies)
+            { float x2 = ra.x, y2 = ra.y; asm volatile("" : "+v"(x2), "+v"(y2)); cm &= cell_mask16(x2, y2, ra.z, ra.w, rb.x, rb.y, g.tx0, g.ty0); }
+#endif
 #endif
         }
         // every pixel of the tile saturated?  (this barrier also ends the previous batch's trips: sR / sCm are free)

@@ -219,6 +219,7 @@ __device__ __forceinline__ unsigned cell_mask16(float mx, float my, float opac, 
         const float e0 = fmaxf(ry + (float)(4 * cy), -ey), e1 = fminf(ry + (float)(4 * cy + 3), ey);
         // (for e0 > e1 the strip misses the ellipse and the result is discarded below)
         const float yu = __builtin_amdgcn_fmed3f(-dys, e0, e1), yl = __builtin_amdgcn_fmed3f(dys, e0, e1);
+#ifdef CELL_MASK_ROUND4   // the arithmetic of rounds 3 - 4 (same masks)
         const float hu = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-det * yu, yu, t2A), 0.0f)), hA, 0.01f);
         const float hl = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-det * yl, yl, t2A), 0.0f)), hA, 0.01f);
         const float xhi = __builtin_fmaf(-bA, yu, hu), xlo = -__builtin_fmaf(bA, yl, hl);
@@ -228,6 +229,25 @@ __device__ __forceinline__ unsigned cell_mask16(float mx, float my, float opac, 
             const int il = (int)lo, n = (int)hi - il + 1;
             m |= (((1u << n) - 1u) << il) << (4 * cy);
         }
+#else
+        // Round 5 (issue classes, tools/probe/valu_issue.hip: min / max / floor / convert / shift are four-cycle instructions,
+        // and one evaluation of this test costs the forward ~0.1 ms): |.| under the root instead of max(., 0) -- a slightly
+        // negative radicand at the very tips of the ellipse becomes a slightly positive one, i.e. a superset --, floor and
+        // convert in one instruction (v_cvt_flr_i32_f32; ceil(x) = -floor(-x)), the run of cell bits from v_bfm_b32.
+        const float hu = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fabsf(__builtin_fmaf(-det * yu, yu, t2A))), hA, 0.01f);
+        const float hl = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fabsf(__builtin_fmaf(-det * yl, yl, t2A))), hA, 0.01f);
+        const float xhi = __builtin_fmaf(-bA, yu, hu), nxlo = __builtin_fmaf(bA, yl, hl);   // nxlo = -xlo
+        // cells with  rx + 4 cx <= xhi  and  rx + 4 cx + 3 >= xlo:  cx in [ceil(xlo / 4 + kl), floor(xhi / 4 + kh)] within 0 .. 3
+        int ih, nil;
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ih) : "v"(__builtin_fmaf(xhi, 0.25f, kh)));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(nil) : "v"(__builtin_fmaf(nxlo, 0.25f, -kl)));   // -ceil(xlo / 4 + kl)
+        const int il = max(-nil, 0);
+        int n = min(ih, 3) - il + 1;
+        n = (e0 <= e1) ? n : 0;
+        unsigned bits;
+        asm("v_bfm_b32 %0, %1, %2" : "=v"(bits) : "v"(max(n, 0)), "v"(il + 4 * cy));   // ((1 << n) - 1) << (il + 4 cy)
+        m |= bits;
+#endif
     }
     return m;
 }
