@@ -170,6 +170,18 @@ int st3r_gs_project_sh_bwd(st3r_ctx* ctx, void* stream, int N, int C, const floa
 int st3r_loss_l1_ssim(st3r_ctx* ctx, void* stream, int C, int height, int width, const float* render,
                       const float* gt, float w_l1, float w_ssim, double* sums, float* v_render);
 
+/* Two of SSIM's five windowed moments -- conv(gt) and conv(gt^2) -- depend on the ground truth alone, and the ground
+ * truth is the same in every iteration of a training call (starster/gs.py:149-152 passes scene.imgs; torchmetrics
+ * recomputes them every call, starster/gs.py:129).  st3r_loss_gt_moments writes them once: moments [C,H,W,3,2] =
+ * (conv(gt), conv(gt^2)) per pixel and channel, zeros outside the interior (H-10) x (W-10).
+ * st3r_ctx_set_gt_moments registers such a buffer for the images at `gt` [C,H,W,3]: from then on st3r_loss_l1_ssim,
+ * st3r_gs_train_fwd_bwd / _step and st3r_gs_raster_train read the moments instead of convolving gt whenever their
+ * ground-truth pointer is `gt` or a whole-view offset into it (view shards, view chunks) with the same height and
+ * width -- bit-identical sums and gradients (same taps in the same order).  Both buffers stay the CALLER's and must
+ * stay unchanged while registered; gt = NULL or moments = NULL clears the registration. */
+int st3r_loss_gt_moments(st3r_ctx* ctx, void* stream, int C, int height, int width, const float* gt, float* moments);
+int st3r_ctx_set_gt_moments(st3r_ctx* ctx, const float* gt, const float* moments, int C, int height, int width);
+
 /* fused Adam over the 23 active scalars per gaussian (replaces the 6 torch.optim.Adam of
  * starster/gs.py:37,159-161; sh0 and SH rows 4..23 never receive gradient and are
  * left untouched, their Adam update is exactly 0).  `step` is 1-based. */

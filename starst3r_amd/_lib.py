@@ -40,6 +40,8 @@ SIGNATURES = {
     "st3r_gs_project_sh_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32,
                                f32, vp],
     "st3r_loss_l1_ssim": [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp],
+    "st3r_loss_gt_moments": [vp, vp, i32, i32, i32, vp, vp],
+    "st3r_ctx_set_gt_moments": [vp, vp, vp, i32, i32, i32],
     "st3r_adam_step": [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, f64, f64, f64, f64, i32],
     "st3r_adam_step_range": [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, f64, f64, f64, f64, i32, i64, i64, vp],
     "st3r_params_from_stage": [vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, i64, i64, i64],

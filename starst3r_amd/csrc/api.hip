@@ -189,8 +189,7 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32,
                       int reg_overwrite, double* zero_ptr, int zero_n);
 int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
-                               int rect32, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* vals, int64_t cap,
-                               int32_t* rec_count);
+                               int rect32, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* vals, int64_t cap);
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
                               int tight, int32_t* tiles, uint64_t* depth_keys, int32_t* depth_vals, uint32_t key_base,
                               void* rects, int rect32);
@@ -334,11 +333,8 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_DVALS_B, int32_t, n_sort, perm);
     // packed tile rectangle of every pair (pair-id order; the tile count of a pair is the area of its rectangle, no
     // array of its own): 32-bit entries for tile grids up to 255 x 255 (tile_rect.h), 64-bit beyond -- and under debug
-    // flag 64, whose backward reads the 64-bit form.  rect32 = 2 (debug flag 4096, training calls, grids up to 255 x 127):
-    // small rectangles also carry the exact tile mask -- 6 % fewer records on SYNTH-1M, measured NOT faster: the mask costs
-    // the projection what the record-proportional stages save (tools/experiments/README.md); off by default
-    int rect32 = (tile_w <= 255 && tile_h <= 255 && !(ctx->debug_flags & 64)) ? 1 : 0;
-    if (rect32 && tight && !records_in && (ctx->debug_flags & 4096) && tile_h <= 127) rect32 = 2;
+    // flag 64, whose backward reads the 64-bit form
+    const int rect32 = (tile_w <= 255 && tile_h <= 255 && !(ctx->debug_flags & 64)) ? 1 : 0;
     GET(SLOT_RECTS, uint64_t, rect32 ? (n_pairs + 1) / 2 : n_pairs, rects);
     st3r_prof_begin(ctx, s, STG_PROJECT);
     const uint32_t key_base = key32 ? near_bits : 0u;
@@ -378,7 +374,6 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     const bool async = allow_async && ctx->isect_hint > 0 && ctx->hint_sig == sig;
     int32_t* counts = nullptr;
     { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
-    int32_t* const rec_count = counts + 8;   // the records the emission writes (<= the scan's total: masked rectangles)
     int32_t* total_dev = nullptr;
     rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev,
                               async ? counts : nullptr);
@@ -410,24 +405,14 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     GET(SLOT_KEYS_B, uint32_t, n_isects, tkeys_b);
     GET(SLOT_VALS_A, int32_t, n_isects, vals_a);
     GET(SLOT_VALS_B, int32_t, n_isects, vals_b);
-    // the sort and the offsets read the record count from device memory in both paths: the emission leaves it there
-    n_dev = rec_count;
-    o->n_records = -1;
-    if (n_isects == 0) {   // nothing visible: no emission runs, the count word is set here
-        HIP_TRY(hipMemsetAsync(rec_count, 0, sizeof(int32_t), s));
-        o->n_records = 0;
-    }
+    // the sort and the offsets read the record count from device memory in both paths: the pair-order scan's total
+    n_dev = total_dev;
+    o->n_records = async ? -1 : n_isects;
     if (n_isects > 0) {
         st3r_prof_begin(ctx, s, STG_EMIT);
-        rc = st3r_isect_emit_chain_impl(ctx, s, N, C, perm, rects, rect32, tile_w, tile_h, tkeys_a, vals_a, n_isects,
-                                        rec_count);
+        rc = st3r_isect_emit_chain_impl(ctx, s, N, C, perm, rects, rect32, tile_w, tile_h, tkeys_a, vals_a, n_isects);
         st3r_prof_end(ctx, s, STG_EMIT);
         if (rc) return rc;
-        if (!async) {   // exact statistics for the caller of the synchronous path (one more 4-byte round trip)
-            HIP_TRY(hipMemcpyAsync(ctx->pinned, rec_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            o->n_records = (int64_t)((int32_t*)ctx->pinned)[0];
-        }
         const int end_bit = bit_length_u32((uint32_t)((int64_t)C * tile_w * tile_h - 1));
         st3r_prof_begin(ctx, s, STG_SORT);
         rc = st3r_sort_tile_impl(ctx, s, n_isects, end_bit, tkeys_a, vals_a, tkeys_b, vals_b, n_dev);
@@ -473,12 +458,11 @@ static int train_views(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* 
     GET(SLOT_ALPHA, float, n_px, alpha);
     GET(SLOT_LAST, int32_t, n_px, last);
     GET(SLOT_VRENDER, float, n_px * 3, v_rgb);
-    // Round 5: the per-pair sums of the backward's (record, tile) slots are taken inside the projection backward; the 48-byte
-    // per-pair gradient records (and k_gather_vtile's launch) exist only under debug flag 16384
-    const bool two_kernels = (ctx->debug_flags & 16384) != 0;
-    float* v_splats = nullptr;
-    if (two_kernels) { GET(SLOT_VSPLATS, float, n_pairs * ST3R_SPLAT_STRIDE, vs_); v_splats = vs_; }
-    st3r_vtile_ref slots_{}; st3r_vtile_ref* slots = two_kernels ? nullptr : &slots_;
+    // Round 5: the per-pair sums of the backward's (record, tile) slots are taken inside the projection backward: no
+    // 48-byte per-pair gradient records, no k_gather_vtile launch (that kernel serves the stand-alone st3r_gs_blend_bwd and
+    // st3r_gs_raster_train)
+    float* const v_splats = nullptr;
+    st3r_vtile_ref slots_{}; st3r_vtile_ref* const slots = &slots_;
     st3r_prof_begin(ctx, s, STG_BLEND_FWD);
     rc = st3r_blend_fwd_impl(ctx, s, C, W, H, ro.tile_w, ro.tile_h, ro.splats, ro.offsets, ro.flat, ro.n_isects, rgb,
                              alpha, last, true, eio);

@@ -68,36 +68,6 @@ __device__ __forceinline__ float zero_unless(uint64_t m, float x) {     // m ? x
     return r;
 }
 
-// (a, b) -> a + b after exchanging halves: lanes 0-31 end up with sum_{l, l+32} a, lanes 32-63 with that of b.
-// Inline asm on purpose: with hipcc 7.2 the second element returned by
-// __builtin_amdgcn_permlane32_swap / permlane16_swap came back equal to the first (measured, see
-// tools/probe/swap_probe.hip); the instruction itself behaves as documented.  "s_nop 1" = the two
-// wait states a VALU-written operand needs before v_permlane*_swap reads it.
-// The swaps of one butterfly level are independent of each other, so they are issued as one asm block
-// behind a single "s_nop 1".
-//
-// reduce9: sums g[0..8] over the 64 lanes.  On return, in every 16-lane row r:
-//   k0 holds the total of g[{0,2,1,3}[r]], k1 that of g[{4,6,5,7}[r]], k2 (row 0 only) that of g[8].
-__device__ __forceinline__ void reduce9(float g0, float g1, float g2, float g3, float g4, float g5, float g6,
-                                        float g7, float g8, float& k0, float& k1, float& k2) {
-    float z0 = 0.f, z1 = 0.f;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %1\n\t"
-        "v_permlane32_swap_b32 %2, %3\n\t"
-        "v_permlane32_swap_b32 %4, %5\n\t"
-        "v_permlane32_swap_b32 %6, %7\n\t"
-        "v_permlane32_swap_b32 %8, %9"
-        : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7), "+v"(g8), "+v"(z0));
-    float h0 = g0 + g1, h1 = g2 + g3, h2 = g4 + g5, h3 = g6 + g7, h4 = g8 + z0;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %0, %1\n\t"
-        "v_permlane16_swap_b32 %2, %3\n\t"
-        "v_permlane16_swap_b32 %4, %5"
-        : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(z1));
-    k0 = h0 + h1; k1 = h2 + h3; k2 = h4 + z1;
-}
 // reduce9_rows: sums g[0..8] over the 16 lanes of every DPP row (row = one record of the chunk) with DPP adds only:
 //   level 1 (lanes l, l ^ 8)   two values per register -- lanes 0-7 keep the first, lanes 8-15 the second (the writes are
 //                              restricted with bank_mask; a bank = four consecutive lanes), 9 instructions -> 5 registers;
@@ -154,31 +124,14 @@ static_assert(HB == 64, "the backward walks one mask word per round");
 #ifndef CHUNK
 #define CHUNK 4         // records per transposition chunk (4 or 8); a lane of phase 2 owns CHUNK pixels of one row
 #endif
-#ifdef BWD_SWAP_LAYOUT
-#define PAIR_STRIDE 65  // float2 per record row of the chunk buffer (64 pixels + 1: conflict-free both ways)
-#define PAIR_AT(pix) (pix)
-#else
 // row layout of phase 2 (lane = part + 16 x record): a record row is 32 + 1 + 32 + 1 float2 -- pixel p sits at p + (p >> 5),
 // rows 66 apart -- so that the 32 lanes of a read group (two records x 16 parts, 32-byte stride inside a row) meet in
 // 32 different bank pairs
 #define PAIR_STRIDE 66
 #define PAIR_AT(pix) ((pix) + ((pix) >> 5))
-#endif
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wave complete in order; this only stops the compiler from moving them across
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-
-__device__ __forceinline__ float row_ror8_add(float v) {
-    float r;
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    return r;
-}
-__device__ __forceinline__ float row_ror4_add(float v) {
-    float r;
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    return r;
-}
-

@@ -109,11 +109,11 @@ struct st3r_ctx {
                       // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks;
                       // 6: backward gathers rectangle and slot base separately; 7 (128): training forward on the quadrant
                       // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 11 (2048): under a communicator
-                      // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip); 12 (4096): the fused
-                      // path drops the tiles of small rectangles that the exact ellipse test rejects (masked rectangles);
-                      // 13 (8192): EXPERIMENT, the fused backward on the cell-granular kernel (gs_blend_cells.hip; slower);
-                      // 14 (16384): the training calls sum the backward's slots in k_gather_vtile (a launch and a 48-byte
-                      // record per pair of their own, as before round 5) instead of inside the projection backward
+                      // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip)
+                      // (round 5's experiment switches -- 4096 masked rectangles, 8192 cell-granular backward, 16384 slot sums
+                      // in a kernel of their own -- left the library in round 6: tools/experiments/README.md)
+    // ground-truth moments registered by the caller (st3r_ctx_set_gt_moments, loss.hip): caller-owned, valid until cleared
+    const float* gtm_gt; const float* gtm_mom; int gtm_c, gtm_h, gtm_w;
     int bwd_stamp;  // generation stamp of the per-(record, tile) partial-gradient slots
     uint32_t scan_gen;   // single-pass scan (gs_isect.hip): generation of its status words
     // record count of the fused steps without a host round trip: sizing hint from the last known count, the read-back

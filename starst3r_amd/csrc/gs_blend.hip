@@ -56,29 +56,7 @@
 #include "tile_rect.h"
 #include "blend_common.h"
 
-#ifdef BWD_PROFILE
-// Where a round of k_blend_bwd spends its time (tools/bwd_profile.py; -DBWD_PROFILE builds only): shader-clock cycles
-// summed over all waves, wave 0 (staging + flush) and waves 1-3 apart:
-//   [0..3] wave 0: staging incl. the barrier behind it | walk (phases 1 + 2) | wait at the barrier behind the walk | flush
-//   [4..7] waves 1-3: the same four
-//   [8] rounds x waves   [9] record trips   [10] phase-2 passes
-__device__ unsigned long long g_bwd_prof[16];
-ST3R_EXPORT int st3r_debug_bwd_profile(unsigned long long* out_host, int reset) {
-    if (out_host) (void)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_prof), z, sizeof(z)); }
-    return 0;
-}
-#define PROF_T() ((long long)__builtin_readcyclecounter())
-#endif
 
-#ifdef ST3R_STATS
-__device__ unsigned long long g_blend_stats[8];
-ST3R_EXPORT int st3r_debug_blend_stats(unsigned long long* out_host, int reset) {
-    if (out_host) (void)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_blend_stats), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, sizeof(z)); }
-    return 0;
-}
-#endif
 
 struct TileGeom {
     int lb, cam, i, j, start, end, tx0, ty0;
@@ -158,9 +136,6 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
     float T = 1.0f, r = 0.f, gg = 0.f, b = 0.f;
     int cur = TRAIN ? 0x7fffffff : 0;
     int nb = 0;
-#ifdef ST3R_STATS
-    unsigned long long st_rel = 0, st_any = 0, st_con = 0, st_lanes = 0, st_take = 0;
-#endif
     const int64_t mbase = mask_base(g.lb, g.start);
     for (int bs = g.start; bs < g.end; bs += BLK, ++nb) {
         if (__syncthreads_and(thr > 1.0f)) break;
@@ -172,9 +147,6 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
         }
         const uint64_t m0 = __ballot(rel & 1), m1 = __ballot(rel & 2), m2 = __ballot(rel & 4), m3 = __ballot(rel & 8);
         if (lane == 0) { sMask[0][w] = m0; sMask[1][w] = m1; sMask[2][w] = m2; sMask[3][w] = m3; }
-#ifdef ST3R_STATS
-        if (lane == 0) atomicAdd(&g_blend_stats[7], (unsigned long long)__popcll(m0 | m1 | m2 | m3));
-#endif
         __syncthreads();
 #pragma unroll 1
         for (int jj = 0; jj < 4; ++jj) {
@@ -237,9 +209,6 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
                 }
                 r = __builtin_fmaf(q.z, vis, r); gg = __builtin_fmaf(q.w, vis, gg); b = __builtin_fmaf(cb, vis, b);
                 cont32 |= tm ? (1u << bit) : 0u;
-#ifdef ST3R_STATS
-                st_rel++; st_con += tm ? 1 : 0; st_take += __popcll(tm); st_any += tm ? 1 : 0; st_lanes += __popcll(tm);
-#endif
             }
             contributed |= (uint64_t)cont32 << (32 * hh);
             }
@@ -253,15 +222,6 @@ __global__ __launch_bounds__(BLK) void k_blend_fwd(int C, int W, int H, int tile
         last_ids[p] = TRAIN ? (cur == 0x7fffffff ? cur : cur - 1) : cur;
     }
     if (tile_nb && threadIdx.x == 0) tile_nb[g.lb] = nb;
-#ifdef ST3R_STATS
-    if (lane == 0) {
-        atomicAdd(&g_blend_stats[0], (unsigned long long)(w == 0 ? nb : 0));
-        atomicAdd(&g_blend_stats[1], st_rel); atomicAdd(&g_blend_stats[2], st_any);
-        atomicAdd(&g_blend_stats[3], st_con); atomicAdd(&g_blend_stats[4], st_lanes);
-        atomicAdd(&g_blend_stats[5], st_take);
-        atomicAdd(&g_blend_stats[6], (unsigned long long)(w == 0 ? (g.end - g.start) : 0));
-    }
-#endif
 }
 
 // scratch for the forward->backward hand-off lives in the ctx
@@ -337,12 +297,8 @@ ST3R_EXPORT int st3r_gs_blend_fwd(st3r_ctx* ctx, void* stream, int C, int width,
 __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsigned tpack, int cnt, int lane, const float4* sA, float* accw, float qxf_lane, float qyf_lane,
                                            const float (&pvr)[CHUNK], const float (&pvg)[CHUNK],
                                            const float (&pvb)[CHUNK]) {
-#ifdef BWD_SWAP_LAYOUT   // rounds 1-2: lane = record + CHUNK * part, the 16 parts of a record meet through lane swaps
-    const int r = lane & (CHUNK - 1), part = lane / CHUNK;
-#else                    // round 3: lane = part + 16 * record: a record's 16 parts are one DPP row (reduce9_rows)
     static_assert(CHUNK == 4, "one DPP row per record of the chunk");
     const int r = lane >> 4, part = lane & 15;
-#endif
     wave_lds_sync();
     const int t = (tpack >> (8 * r)) & 0xFF;  // rows >= cnt read index 0 (valid); their sums are dropped below
     const float2 mean = *reinterpret_cast<const float2*>(&sA[t]);
@@ -365,20 +321,6 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
     const float So = W0, Sx = fmaf(d0, W0, -W1), Sxx = fmaf(d0, Sx - W1, W2);
     const float Sy = So * dy, Sxy = Sx * dy, Syy = Sy * dy;  // dy is the same for the lane's pixels
     float k0, k1, k2;
-#ifdef BWD_SWAP_LAYOUT
-    reduce9(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);            // lane bits 5, 4
-    k0 = row_ror8_add(k0); k1 = row_ror8_add(k1); k2 = row_ror8_add(k2);  // lane bit 3
-    if (CHUNK == 4) { k0 = row_ror4_add(k0); k1 = row_ror4_add(k1); k2 = row_ror4_add(k2); }  // lane bit 2
-    if (r < cnt && (lane & 15) < CHUNK) {
-        // 16-lane row -> slots: k0 -> {0,2,1,3}[row], k1 -> {4,6,5,7}[row], k2 -> 8 (row 0)
-        const int row = lane >> 4;
-        const int slot0 = ((row & 1) << 1) | (row >> 1);
-        float* acc = accw + t * ACC_VALS;
-        acc[slot0] = k0;
-        acc[4 + slot0] = k1;
-        if (row == 0) acc[8] = k2;
-    }
-#else
     reduce9_rows(Sx, Sy, So, Sxx, Sxy, Syy, Sr, Sg, Sb, k0, k1, k2);
     if (r < cnt && (lane & 3) == 0) {
         // bank b of the record's row -> slots: k0 -> {0,2,1,3}[b], k1 -> {4,6,5,7}[b], k2 -> 8 (bank 0)
@@ -389,7 +331,6 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
         acc[4 + slot0] = k1;
         if (b == 0) acc[8] = k2;
     }
-#endif
     wave_lds_sync();
 }
 
@@ -437,11 +378,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
     float2* pr = sPair[w];
     float* accw = sAccW[w];
     float pvr[CHUNK], pvg[CHUNK], pvb[CHUNK];
-#ifdef BWD_SWAP_LAYOUT
-    const int pbase = (lane / CHUNK) * CHUNK;   // first of this lane's phase-2 pixels (quadrant-local index y*8 + x)
-#else
     const int pbase = (lane & 15) * CHUNK;      // (phase-2 lane = part + 16 * record: see bwd_phase2)
-#endif
     {
         float* px = reinterpret_cast<float*>(pr);
         px[lane] = vr; px[64 + lane] = vg; px[128 + lane] = vb;
@@ -464,9 +401,6 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
     // wave-uniform pointer (scalar loads); the mask word of a round is fetched one round ahead so that no dependent
     // load sits at the head of a round
     const uint64_t* wmask = cmask + (int64_t)__builtin_amdgcn_readfirstlane(w) * cmask_words + mbase;
-#ifdef BWD_PROFILE
-    long long prof[4] = {0, 0, 0, 0}; long long prof_rounds = 0, prof_trips = 0, prof_p2 = 0;
-#endif
     uint64_t m_next = wmask[(BLK / HB) * nb - 1];
     for (int hb = (BLK / HB) * nb - 1; hb >= 0; --hb) {
         const int bs = g.start + hb * HB;
@@ -474,9 +408,6 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
         const uint64_t m_cur = m_next;
         if (hb > 0) m_next = wmask[hb - 1];
         if (bsz <= 0) continue;   // the tail of the last forward batch may be empty (uniform over the workgroup)
-#ifdef BWD_PROFILE
-        const long long pt0 = PROF_T();
-#endif
         __syncthreads();
         // ---- staging: one record per thread (threads 0..HB-1).  A record some wave contributed to also fixes its
         // output slot now, so that the flush below is loads-free:  u = cum_excl[pid] + index of this tile inside the
@@ -485,20 +416,14 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
         float my_op = 0.f, my_ca = 0.f, my_cbb = 0.f, my_cc = 0.f;
         if ((int)threadIdx.x < bsz) {
             const int t = threadIdx.x;
-#ifdef BWD_ABL_SEQ_STAGE   // ablation: no dependent gather (wrong records, same instructions)
-            const int64_t my_id = (bs + t) >> 2;
-#else
             const int64_t my_id = flat[bs + t];
-#endif
             const int64_t word = mbase + hb;   // HB = 64: one (wave-uniform) mask word per round and wave
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
             // only a record some wave contributed to is ever read from the staging arrays: the others' 48 bytes are not
             // fetched (their slots of sA / sB / sC keep whatever an earlier round left there)
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
-#ifndef BWD_STAGE_ALL
             if (my_cb)
-#endif
             {
                 a = splats[my_id * 3 + 0];   // x y opacity conic.a
                 b = splats[my_id * 3 + 1];   // conic.b conic.c r g
@@ -542,9 +467,6 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
             }
         }
         __syncthreads();
-#ifdef BWD_PROFILE
-        const long long pt1 = PROF_T();
-#endif
         // ---- phase 1: lanes are pixels; up to CHUNK records, back to front (unrolled: the chunk row is an immediate
         // offset, the records' staged indices travel to phase 2 in one scalar, 8 bits each).  Compares and selects cost
         // 1.7 ns each on this chip against 1.1 ns for an add or multiply (tools/probe/valu_cost.hip), so the two tests
@@ -563,13 +485,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
 #pragma unroll
                 for (int k = 0; k < CHUNK; ++k) {
                     if (m) {
-#ifdef BWD_ABL_CONST_T   // ablation (wrong records, timing only): no bit scan, no scalar -> vector address moves
-                        const int t = k;
-                        m &= m - 1;
-#else
                         const int t = 63 - __builtin_clzll(m);
                         m &= ~(1ull << t);
-#endif
                         const float4 a = sA[t];
                         const float4 q = sB[t];
                         const float cb_ = sC[t];
@@ -610,38 +527,20 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
                         cnt = k + 1;
                     }
                 }
-#ifdef BWD_PROFILE
-                prof_trips += cnt; prof_p2 += 1;
-#endif
-#ifndef BWD_NO_P2
                 bwd_phase2(pr, tpack, cnt, lane, sA, accw, qxf, qyf_part, pvr, pvg, pvb);
-#endif
             }
         };
         const bool clamp_round = (uniform_u64(sClampW) & m_cur) != 0;
-#ifdef BWD_NO_WALK
-        if (tight < 0)
-#endif
         if (chk_index) {
             if (clamp_round) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{});
         } else {
             if (clamp_round) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{});
         }
-#ifdef BWD_PROFILE
-        const long long pt2 = PROF_T();
-#endif
         __syncthreads();
-#ifdef BWD_PROFILE
-        const long long pt3 = PROF_T();
-#endif
         // ---- flush: the (at most four) wave sums of a record -> its stamped slot in HBM.  Slot indices come from the
         // scan over the TRUE tile counts; in an asynchronous step that outgrew its capacity they can exceed the slots the
         // buffer has (that step is discarded anyway): such a record is not written (unsigned: a wrapped index too)
-#ifdef BWD_NO_FLUSH
-        if (my_cb && (unsigned)my_u < vt_cap && tight < 0) {
-#else
         if (my_cb && (unsigned)my_u < vt_cap) {
-#endif
             float acc[ACC_VALS];
 #pragma unroll
             for (int k = 0; k < ACC_VALS; ++k) acc[k] = 0.f;
@@ -663,20 +562,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
             dst[3] = make_float2(acc[6], acc[7]);
             dst[4] = make_float2(acc[8], __int_as_float(stamp));
         }
-#ifdef BWD_PROFILE
-        const long long pt4 = PROF_T();
-        prof[0] += pt1 - pt0; prof[1] += pt2 - pt1; prof[2] += pt3 - pt2; prof[3] += pt4 - pt3; prof_rounds += 1;
-#endif
     }
-#ifdef BWD_PROFILE
-    if (lane == 0) {
-        const int o = w == 0 ? 0 : 4;
-        for (int k = 0; k < 4; ++k) atomicAdd(&g_bwd_prof[o + k], (unsigned long long)prof[k]);
-        atomicAdd(&g_bwd_prof[8], (unsigned long long)prof_rounds);
-        atomicAdd(&g_bwd_prof[9], (unsigned long long)prof_trips);
-        atomicAdd(&g_bwd_prof[10], (unsigned long long)prof_p2);
-    }
-#endif
 }
 
 // v_splats[pid] = sum over the pair's tiles of the slots stamped by this backward call, in slot order (deterministic
@@ -734,11 +620,6 @@ __global__ __launch_bounds__(256) void k_gather_vtile(int64_t n_pairs, const int
     }
 }
 
-int st3r_blend_bwd_cells_launch(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
-                                const int32_t* offsets, const int32_t* flat, const float* alpha, const int32_t* last_ids,
-                                const float* v_rgb, const uint64_t* cmask, int64_t words, const int32_t* tile_nb,
-                                const uint64_t* rectbase, float* vtile, int stamp, unsigned vt_cap);
-
 int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int tile_w, int tile_h,
                         const float* splats, const int32_t* offsets, const int32_t* flat, int64_t n_isects,
                         const float* alpha, const int32_t* last_ids, const float* v_rgb, const float* v_alpha,
@@ -767,12 +648,7 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
     const unsigned vt_cap = (unsigned)(ctx->slot_bytes[SLOT_VTILE] / (sizeof(float) * VT_STRIDE));
-    if ((ctx->debug_flags & 8192) && !v_alpha && rectbase && end_in_offsets) {
-        // EXPERIMENT (round 5): the cell-granular walk (gs_blend_cells.hip: k_blend_bwd_cells), fused training calls only
-        rc = st3r_blend_bwd_cells_launch(s, C, W, H, tile_w, tile_h, splats, offsets, flat, alpha, last_ids, v_rgb, cmask,
-                                         words, tile_nb, rectbase, vtile, stamp, vt_cap);
-        if (rc) return rc;
-    } else if (v_alpha)
+    if (v_alpha)
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
                            v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp, vt_cap);

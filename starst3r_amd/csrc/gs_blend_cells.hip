@@ -205,19 +205,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(7))) void k
             ra = splats[id * 3 + 0]; rb = splats[id * 3 + 1]; rc = splats[id * 3 + 2];
             // (same record-level test as the backward's staging, gs_blend.hip: conic safely positive definite, opacity below
             // the clamp; anything else -- NaNs included -- takes the full trip)
-#ifdef CELLS_ABL_NEVER_HARD
-            hard = false;
-#else
             hard = !(ra.z <= 0.998f && ra.w > 0.f && rb.y > 0.f && (ra.w * rb.y - rb.x * rb.x) >= 2e-3f * (ra.w * rb.y));
-#endif
-#ifdef CELLS_NO_TEST
-            cm = 0xFFFFu;
-#else
             cm = no_cull ? 0xFFFFu : cell_mask16(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, g.tx0, g.ty0);
-#ifdef CELLS_ABL_TEST_TWICE   // ablation: what one evaluation of the cell test costs (the second one on opaque copies)
-            { float x2 = ra.x, y2 = ra.y; asm volatile("" : "+v"(x2), "+v"(y2)); cm &= cell_mask16(x2, y2, ra.z, ra.w, rb.x, rb.y, g.tx0, g.ty0); }
-#endif
-#endif
         }
         // every pixel of the tile saturated?  (this barrier also ends the previous batch's trips: sR / sCm are free)
         if (__syncthreads_and(s.thr > 1.0f)) break;
@@ -237,11 +226,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(7))) void k
         __syncthreads();
         // ---- trips: every row walks its own list; the wave runs until its longest list is done
         if (__builtin_amdgcn_ballot_w64(s.thr < 1.0f) != 0) {
-#ifdef CELLS_NO_LISTS
-            const uint2 lens = make_uint2(0u, 0u);
-#else
             const uint2 lens = build_wave_lists(sCm, lp, g.cell, lane);
-#endif
             const int l0 = lens.x & 0xFFFF, l1 = lens.x >> 16, l2 = lens.y & 0xFFFF, l3 = lens.y >> 16;
             // Windows of 32 list positions; inside a window four trips per iteration: the four list entries arrive as one
             // 8-byte read issued an iteration ahead, the record reads run two trips ahead of the bodies.
@@ -258,11 +243,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(7))) void k
                 need = max(need, (live & 0xFFFF00000000ull) ? l2 : 0);
                 need = max(need, (live & 0xFFFF000000000000ull) ? l3 : 0);
                 const int n4 = (need + 3) & ~3;
-#ifdef CELLS_NO_TRIPS
-                if (k0 >= (n4 & no_cull)) break;   // ablation: staging and list building only
-#else
                 if (k0 >= n4) break;
-#endif
                 unsigned cbits = 0;
                 const int kend = min(k0 + 32, n4);
                 unsigned sb = 1u;
@@ -286,11 +267,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(7))) void k
                     e = en;
                 }
                 // the window's contribution bits: OR over the row, then lane idx flags the records of positions 2 idx, 2 idx + 1
-#ifdef CELLS_NO_CONTRIB
-                if (cmask && no_cull) {
-#else
                 if (cmask) {
-#endif
                     asm volatile("s_nop 1\n\tv_or_b32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
                                  "s_nop 1\n\tv_or_b32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
                                  "s_nop 1\n\tv_or_b32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
@@ -327,286 +304,6 @@ int st3r_blend_fwd_cells_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H,
     const int total = C * tile_w * tile_h;
     hipLaunchKernelGGL(k_blend_fwd_cells, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h, (const float4*)splats,
                        offsets, flat, rgb, alpha, last_ids, cmask, cmask_words, tile_nb, ctx->debug_flags & 1);
-    LAUNCH_CHECK();
-    return ST3R_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 5; debug flag 8192; NOT the default): the blend backward with a CELL-granular
-// phase 1 -- every 16-lane row walks the record list of its own 4x4-pixel cell back to front, four different records per
-// trip -- on the same cell test the forward uses.  Everything around the walk is k_blend_bwd's (gs_blend.hip): rounds of 64
-// staged records, contribution words from the forward, per-wave accumulator rows, one stamped 40-byte slot per
-// contributing (record, tile).  What changes:
-//   lists     per round every wave builds the four lists of its cells from the records' 16-bit cell masks (recomputed by
-//             the staging thread with the forward's cell_mask16) ANDed with the wave's contribution word: four ballots,
-//             a lane's list position is the number of set bits above it (back to front);
-//   trips     a row whose list has run out walks a sentinel record of opacity 0;
-//   phase 2   every four trips the lanes regroup as (trip, cell, pixel row): 16 (record, cell) pairs x 4 runs of 4 pixels;
-//             the four runs of a pair meet in two quad_perm DPP levels (18 adds: 4-lane groups instead of today's
-//             16-lane rows), and the pair's nine sums are ADDED into the record's row -- two cells of one record can sit
-//             in the same chunk, so the plain stores of the quadrant formulation do not carry over: one read-modify-write
-//             pass per cell (-DXB_ATOMIC: LDS float atomics instead, 2.5 ms slower and not reproducible run to run).
-// Costs it cannot avoid: 180 instructions of cell test per staged record, list building, 1 KB of lists + 128 B of masks
-// (21.6 KB of LDS: seven workgroups per CU instead of eight), accumulator rows cleared every round.
-// Measured: tools/experiments/README.md.
-// ------------------------------------------------------------------------------------------------------------------
-#define XB_PAIR (4 * 68 + 8)      // float2 per wave: four trips x 64 lanes, padded (see the offsets below)
-
-__global__ __launch_bounds__(BLK) void k_blend_bwd_cells(int C, int W, int H, int tile_w, int tile_h,
-                                                         const float4* __restrict__ splats,
-                                                         const int32_t* __restrict__ offsets,
-                                                         const int32_t* __restrict__ flat,
-                                                         const float* __restrict__ out_alpha,
-                                                         const int32_t* __restrict__ last_ids,
-                                                         const float* __restrict__ v_rgb,
-                                                         const uint64_t* __restrict__ cmask, int64_t cmask_words,
-                                                         const int32_t* __restrict__ tile_nb,
-                                                         const uint64_t* __restrict__ rectbase,
-                                                         float* __restrict__ vtile, int stamp, unsigned vt_cap) {
-    __shared__ float4 sA[HB + 1];   // x y opacity qa   (+ the sentinel: opacity 0)
-    __shared__ float4 sB[HB + 1];   // qb qc r g
-    __shared__ float sC[HB + 1];    // b
-    __shared__ uint16_t sCm[HB];    // cell masks of the staged records (0: no wave contributed)
-    __shared__ float sAccW[4][(HB + 1) * ACC_VALS];
-    __shared__ __attribute__((aligned(16))) float2 sPair[4][XB_PAIR];
-    __shared__ unsigned char sList[4][4][HB];
-    const CellTile g = cell_tile(C, W, H, tile_w, tile_h, offsets);
-    const int nb = tile_nb[g.lb];
-    if (nb == 0) return;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, rho = lane >> 4;
-    const int64_t p = ((int64_t)g.cam * H + g.i) * W + g.j;
-    const float ppx = (float)g.j + 0.5f, ppy = (float)g.i + 0.5f;
-    float T_final = 1.0f, vr = 0.f, vg = 0.f, vb = 0.f;
-    int bin_final = -1;
-    if (g.inside) {
-        T_final = 1.0f - out_alpha[p];
-        vr = v_rgb[3 * p]; vg = v_rgb[3 * p + 1]; vb = v_rgb[3 * p + 2];
-        bin_final = last_ids[p];
-    }
-    if (threadIdx.x == 0) { sA[HB] = make_float4(0.f, 0.f, 0.f, 0.f); sB[HB] = make_float4(0.f, 0.f, 0.f, 0.f); sC[HB] = 0.f; }
-    float2* pr = sPair[w];
-    float* accw = sAccW[w];
-    // phase-2 view: lane l = 16 * trip + 4 * cell + pixel row u of the cell; its four pixels are the lanes
-    // 16 * cell + 4 * u + i of phase 1: their v_rgb through the (still unused) pair buffer into registers, once per tile
-    const int p2_trip = lane >> 4, p2_cell = (lane >> 2) & 3, p2_u = lane & 3;
-    float pvr[4], pvg[4], pvb[4];
-    {
-        float* px = reinterpret_cast<float*>(pr);
-        px[lane] = vr; px[64 + lane] = vg; px[128 + lane] = vb;
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int src = 16 * p2_cell + 4 * p2_u + i;
-            pvr[i] = px[src]; pvg[i] = px[64 + src]; pvb[i] = px[128 + src];
-        }
-        wave_lds_sync();
-    }
-    // first pixel centre of this lane's phase-2 run: cell (cx, cy) of the tile as in cell_tile, pixel row u
-    const int p2cx = ((w & 1) << 1) | (p2_cell & 1), p2cy = ((w >> 1) << 1) | (p2_cell >> 1);
-    const float qxf = (float)(g.tx0 + 4 * p2cx) + 0.5f, qyf = (float)(g.ty0 + 4 * p2cy + p2_u) + 0.5f;
-    // the bit of this lane's OWN cell (phase 1) in a record's 16-bit cell mask
-    const int cbit[4] = {(((w >> 1) << 1) | 0) * 4 + (((w & 1) << 1) | 0), (((w >> 1) << 1) | 0) * 4 + (((w & 1) << 1) | 1),
-                         (((w >> 1) << 1) | 1) * 4 + (((w & 1) << 1) | 0), (((w >> 1) << 1) | 1) * 4 + (((w & 1) << 1) | 1)};
-    float T = T_final, bv = 0.f;
-    const int64_t mbase = mask_base(g.lb, g.start);
-    const uint64_t* wmask = cmask + (int64_t)__builtin_amdgcn_readfirstlane(w) * cmask_words + mbase;
-    for (int hb = (BLK / HB) * nb - 1; hb >= 0; --hb) {
-        const int bs = g.start + hb * HB;
-        const int bsz = min(HB, g.end - bs);
-        if (bsz <= 0) continue;
-        const uint64_t m_cur = wmask[hb];
-        __syncthreads();
-        // ---- staging (threads 0 .. bsz-1), as in k_blend_bwd, plus the record's cell mask
-        int my_u = -1, my_cb = 0;
-        float my_op = 0.f, my_ca = 0.f, my_cbb = 0.f, my_cc = 0.f;
-        if ((int)threadIdx.x < HB) {
-            const int t = threadIdx.x;
-            unsigned cm = 0;
-            if (t < bsz) {
-                const int64_t my_id = flat[bs + t];
-                const int64_t word = mbase + hb;
-#pragma unroll
-                for (int ww = 0; ww < 4; ++ww) my_cb |= (int)((cmask[ww * cmask_words + word] >> (t & 63)) & 1ull) << ww;
-                if (my_cb) {
-                    const float4 a = splats[my_id * 3 + 0], b = splats[my_id * 3 + 1], c = splats[my_id * 3 + 2];
-                    sA[t] = make_float4(a.x, a.y, a.z, -0.5f * LOG2E * a.w);
-                    sB[t] = make_float4(-LOG2E * b.x, -0.5f * LOG2E * b.y, b.z, b.w);
-                    sC[t] = c.x;
-#ifdef XB_NO_CM
-                    cm = 0xFFFFu;
-#else
-                    cm = cell_mask16(a.x, a.y, a.z, a.w, b.x, b.y, g.tx0, g.ty0);
-#endif
-                    const uint64_t r = rectbase[my_id];
-                    const int x0 = (int)(r & 0x3FF), y0 = (int)((r >> 10) & 0x3FF), rw = (int)((r >> 20) & 0x3FF);
-                    my_u = (int)(r >> 32) + ((g.ty0 >> 4) - y0) * rw + ((g.tx0 >> 4) - x0);
-                    my_op = a.z; my_ca = a.w; my_cbb = b.x; my_cc = b.y;
-                }
-            }
-            sCm[t] = (uint16_t)cm;
-        }
-        // the wave's accumulator rows start the round at zero (phase 2 ADDS into them)
-#pragma unroll
-        for (int k = 0; k < ACC_VALS; ++k) accw[k * 64 + lane] = 0.f;
-        __syncthreads();
-        // ---- lists: lane t = record t; cell rho2's list holds the records whose ellipse reaches the cell AND that this wave
-        // contributed to, in descending record order
-        int len[4];
-        {
-            const unsigned cmv = sCm[lane];
-            const bool mine = (m_cur >> lane) & 1ull;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const bool in = mine && ((cmv >> cbit[c4]) & 1u);
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(in);
-                len[c4] = __builtin_popcountll(bal);
-                if (in) sList[w][c4][__builtin_popcountll(bal & ~((2ull << lane) - 1ull))] = (unsigned char)lane;
-            }
-        }
-        wave_lds_sync();
-#ifdef XB_NO_TRIPS
-        const int ntr = 0;
-#else
-        const int ntr = max(max(len[0], len[1]), max(len[2], len[3]));
-#endif
-        const int my_len = rho == 0 ? len[0] : rho == 1 ? len[1] : rho == 2 ? len[2] : len[3];
-        const int p2_len = p2_cell == 0 ? len[0] : p2_cell == 1 ? len[1] : p2_cell == 2 ? len[2] : len[3];
-        for (int k0 = 0; k0 < ntr; k0 += 4) {
-            const int cnt = min(4, ntr - k0);
-            // ---- phase 1: lanes are pixels, each row on the record of its own list
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk < cnt) {
-                    const int k = k0 + kk;
-                    const int t = k < my_len ? (int)sList[w][rho][k] : HB;
-                    const float4 a = sA[t];
-                    const float4 q = sB[t];
-                    const float cb_ = sC[t];
-                    const float dx = a.x - ppx, dy = a.y - ppy;
-                    const float P = blend_power(dx, dy, a.w, q.x, q.y);
-                    const float ov0 = a.z * __builtin_amdgcn_exp2f(P);
-                    const float al0 = fminf(0.999f, ov0);
-                    const bool ok = !(P > 0.f) && !(al0 < 1.f / 255.f) && (bs + t <= bin_final);
-                    const float alpha = ok ? al0 : 0.f;
-                    const float alpha_u = ov0 <= 0.999f ? alpha : 0.f;
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    const float cv = q.z * vr + q.w * vg + cb_ * vb;
-                    T *= ra;
-                    const float fac = alpha * T;
-                    const float v_al = cv * T - bv * ra;
-                    bv += cv * fac;
-                    pr[68 * kk + lane + 2 * (lane >> 5)] = make_float2(alpha_u * v_al, fac);
-                }
-            }
-            wave_lds_sync();
-            // ---- phase 2: lane = (trip, cell, pixel row)
-#ifndef XB_NO_P2
-            {
-                const int kpos = k0 + p2_trip;
-                const bool valid = p2_trip < cnt && kpos < p2_len;
-                const int t = valid ? (int)sList[w][p2_cell][kpos] : HB;
-                const float2 mean = *reinterpret_cast<const float2*>(&sA[t]);
-                const float4 v01 = *reinterpret_cast<const float4*>(pr + 4 * lane + 2 * (lane >> 3));
-                const float4 v23 = *reinterpret_cast<const float4*>(pr + 4 * lane + 2 * (lane >> 3) + 2);
-                const float gx[4] = {v01.x, v01.z, v23.x, v23.z}, fc[4] = {v01.y, v01.w, v23.y, v23.w};
-                float W0 = 0.f, W1 = 0.f, W2 = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    W0 += gx[i];
-                    if (i == 1) { W1 = gx[i]; W2 = gx[i]; }
-                    if (i > 1) { W1 = fmaf((float)i, gx[i], W1); W2 = fmaf((float)(i * i), gx[i], W2); }
-                    Sr = fmaf(fc[i], pvr[i], Sr); Sg = fmaf(fc[i], pvg[i], Sg); Sb = fmaf(fc[i], pvb[i], Sb);
-                }
-                const float d0 = mean.x - qxf, dyl = mean.y - qyf;
-                float s[9];
-                s[2] = W0; s[0] = fmaf(d0, W0, -W1); s[3] = fmaf(d0, s[0] - W1, W2);
-                s[1] = s[2] * dyl; s[4] = s[0] * dyl; s[5] = s[1] * dyl;
-                s[6] = Sr; s[7] = Sg; s[8] = Sb;
-                asm volatile(
-                    "s_nop 1\n\t"
-                    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "s_nop 1\n\t"
-                    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                    : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]), "+v"(s[8]));
-                // every lane of a quad now holds the pair's nine sums; lane u adds sums u and u + 4 (lane 0: also the
-                // ninth) into the record's row.  Two CELLS of a wave can hold the same record in one chunk, the four trips of
-                // one cell cannot: one read-modify-write pass per cell, in cell order (LDS operations of a wave execute in
-                // order), keeps the sums exact and the order fixed.
-#ifdef XB_ATOMIC
-                if (valid && p2_u == 0) {
-#pragma unroll
-                    for (int j = 0; j < 9; ++j)
-                        __hip_atomic_fetch_add(&accw[j * 64 + t], s[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-#else
-                const float a0 = p2_u == 0 ? s[0] : p2_u == 1 ? s[1] : p2_u == 2 ? s[2] : s[3];
-                const float a1 = p2_u == 0 ? s[4] : p2_u == 1 ? s[5] : p2_u == 2 ? s[6] : s[7];
-                float* row = accw + p2_u * 64 + t;
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    if (valid && p2_cell == c4) {
-#ifdef XB_NO_ATOM
-                        row[0] = a0; row[256] = a1;
-                        if (p2_u == 0) row[512] = s[8];
-#else
-                        row[0] += a0; row[256] += a1;
-                        if (p2_u == 0) row[512] += s[8];
-#endif
-                    }
-                    wave_lds_sync();
-                }
-#endif
-            }
-#endif
-            wave_lds_sync();
-        }
-        __syncthreads();
-        // ---- flush, as in k_blend_bwd (accumulator layout here: value-major, accw[k * 64 + t])
-        if (my_cb && (unsigned)my_u < vt_cap) {
-            float acc[ACC_VALS];
-#pragma unroll
-            for (int k = 0; k < ACC_VALS; ++k) acc[k] = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                if (my_cb & (1 << ww)) {
-#pragma unroll
-                    for (int k = 0; k < ACC_VALS; ++k) acc[k] += sAccW[ww][k * 64 + threadIdx.x];
-                }
-            }
-            const float sx = -acc[0], sy = -acc[1];
-            float2* dst = reinterpret_cast<float2*>(vtile + (int64_t)my_u * VT_STRIDE);
-            dst[0] = make_float2(my_ca * sx + my_cbb * sy, my_cbb * sx + my_cc * sy);
-            dst[1] = make_float2(my_op != 0.f ? acc[2] / my_op : 0.f, -0.5f * acc[3]);
-            dst[2] = make_float2(-acc[4], -0.5f * acc[5]);
-            dst[3] = make_float2(acc[6], acc[7]);
-            dst[4] = make_float2(acc[8], __int_as_float(stamp));
-        }
-    }
-}
-
-int st3r_blend_bwd_cells_launch(hipStream_t s, int C, int W, int H, int tile_w, int tile_h, const float* splats,
-                                const int32_t* offsets, const int32_t* flat, const float* alpha, const int32_t* last_ids,
-                                const float* v_rgb, const uint64_t* cmask, int64_t words, const int32_t* tile_nb,
-                                const uint64_t* rectbase, float* vtile, int stamp, unsigned vt_cap) {
-    hipLaunchKernelGGL(k_blend_bwd_cells, dim3(C * tile_w * tile_h), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
-                       (const float4*)splats, offsets, flat, alpha, last_ids, v_rgb, cmask, words, tile_nb, rectbase, vtile,
-                       stamp, vt_cap);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

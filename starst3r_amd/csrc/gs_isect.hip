@@ -453,16 +453,16 @@ int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, 
 
 // Emission of the fused path: records leave in (camera, depth) order, so that the stable (camera, tile) sort behind
 // these kernels keeps depth order inside every tile.  Two launches (round 3: four -- a depth-order scan made of gather +
-// reduce, tile sums and downsweep, then the emission):
+// reduce, tile sums and downsweep, then the emission; rounds 4-5: three):
 //   k_isect_gather   a workgroup owns EP consecutive pairs of ONE camera in depth order (perm[] from the level-1 sort)
 //                    and gathers their packed rectangles by pair id -- the only random access of the front end -- into
 //                    depth order, plus the workgroup's tile count.  With eight views (or a multiple) the workgroups of
 //                    a camera run on one XCD (workgroup b runs on XCD b % 8), whose L2 then serves that camera's
 //                    rectangles: 4 MB at 1 M Gaussians in the 32-bit form;
-//   k_isect_emit     the same workgroup shape: scans its pairs' tile counts (rectangle areas, or the set bits of a masked
-//                    rectangle), finds its first output position as the tile counts of all earlier workgroups,
-//                    camera-major (k_isect_wg_scan: one tiny launch between the two; it also leaves the record count),
-//                    and emits.  Work is dealt by OUTPUT element, not by pair:
+//   k_isect_emit_d   the same workgroup shape: scans its pairs' tile counts (rectangle areas), finds its first output
+//                    position as the tile counts of all earlier workgroups, camera-major (summed by the workgroup itself;
+//                    k_isect_wg_scan, a launch between the two, only for very large grids), and emits.  The record count
+//                    is the pair-order scan's total.  Work is dealt by OUTPUT element, not by pair:
 //                    every pair with tiles marks its first output with its index, a prefix maximum over the chunk
 //                    spreads the marks to the right (thread t scans 16 consecutive entries in registers, the thread
 //                    maxima meet in one workgroup scan), then the outputs are dealt to the threads with a stride of 256
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_isect_gather(int N, int C, int bpc, con
             if (rect32) {
                 const uint32_t r = reinterpret_cast<const uint32_t*>(rects)[pid[j]];
                 reinterpret_cast<uint32_t*>(rects_d)[dst] = r;
-                sum += rect32_count(r, rect32);   // (a masked entry emits fewer tiles than its rectangle holds)
+                sum += (int)((r >> 16) & 0xFFu) * (int)(r >> 24);
             } else {
                 const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[pid[j]];
                 reinterpret_cast<uint64_t*>(rects_d)[dst] = r;
@@ -521,12 +521,13 @@ __global__ __launch_bounds__(256) void k_isect_gather(int N, int C, int bpc, con
     if (t == 0) wg_tiles[c * bpc + k] = total;   // < 2^30: 1024 rectangles of < 2^20 tiles
 }
 
-// Exclusive prefix of the workgroup tile counts over ALL cameras, camera-major (one workgroup walks the C * bpc entries
-// 256 at a time; 7816 entries at 1 M Gaussians and 8 views) -- the emission then reads ONE absolute base per workgroup,
-// whatever the number of Gaussians -- and the number of records emitted (*rec_count).  Round 4 took a camera's base from
-// the pair-order scan (cum[c N - 1]); with masked rectangles (tile_rect.h) that scan counts SLOTS, not records.
+// Exclusive prefix of the workgroup tile counts over ALL cameras, camera-major, as a launch of its own: only for grids of
+// more than EMIT_SELF_BASE_MAX workgroups (5 M Gaussians x 8 views: 39 k).  Below that every emission workgroup adds up
+// the counts of its predecessors itself (k_isect_emit_d with wg_base = NULL: at most 64 KB of L2 reads per workgroup) and
+// this launch -- one workgroup, 13 us with the whole GPU drained around it -- does not exist (round 6).
+#define EMIT_SELF_BASE_MAX 16384
 __global__ __launch_bounds__(1024) void k_isect_wg_scan(int n, const int32_t* __restrict__ wg_tiles,
-                                                        long long* __restrict__ wg_base, int32_t* __restrict__ rec_count) {
+                                                        long long* __restrict__ wg_base) {
     // thread t owns the consecutive entries [t per, (t + 1) per): their sum, one scan over the 1024 sums, then the
     // entries again (a loop of block scans over 256 entries at a time took 45 us here: 31 dependent rounds)
     __shared__ long long s_wave[16];
@@ -543,29 +544,40 @@ __global__ __launch_bounds__(1024) void k_isect_wg_scan(int n, const int32_t* __
     }
     if (lane == 63) s_wave[w] = inc;
     __syncthreads();
-    long long base = 0, total = 0;
+    long long base = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { base += i < w ? s_wave[i] : 0; total += s_wave[i]; }
+    for (int i = 0; i < 16; ++i) base += i < w ? s_wave[i] : 0;
     long long run = base + inc - sum;
     for (int e = e0; e < e1; ++e) { wg_base[e] = run; run += wg_tiles[e]; }
-    // (past 2^31 - 1 the count is reported as -1, like the pair-order scan's total)
-    if (t == 0 && rec_count) rec_count[0] = total > 2147483647LL ? -1 : (int32_t)total;
 }
 
 __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, const int32_t* __restrict__ perm,
                                                       const void* __restrict__ rects_d, int rect32,
-                                                      const long long* __restrict__ wg_base, int tile_w, int tile_h,
+                                                      const long long* __restrict__ wg_base,
+                                                      const int32_t* __restrict__ wg_tiles, int tile_w, int tile_h,
                                                       uint32_t* __restrict__ tile_keys, int32_t* __restrict__ vals,
                                                       int64_t cap) {
     __shared__ int s_end[EP];         // inclusive scan of the workgroup's tile counts
     __shared__ uint32_t s_org[EP];    // x0 | y0 << 16
-    __shared__ uint32_t s_w[EP];      // rectangle width | tile mask << 16 (0: every tile of the rectangle)
+    __shared__ uint32_t s_w[EP];      // rectangle width
     __shared__ int32_t s_pid[EP];
     __shared__ uint16_t s_own[ECH];   // owner (pair index + 1) of every output of the current emission chunk
     __shared__ unsigned s_wmax[4];
+    __shared__ long long s_bsum[4];
     int c, k;
     emit_item(C, bpc, &c, &k);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // first output position: the tile counts of all earlier workgroups, camera-major.  Summed here (the loads travel
+    // under the rectangle loads and the scan below) unless the grid is large enough for a scan launch to pay.
+    long long bsum = 0;
+    if (!wg_base) {
+        const int nb4 = (c * bpc + k) >> 2;   // whole 16-byte groups in front of this workgroup's entry
+        for (int i = t; i < nb4; i += 256) {
+            const int4 v = reinterpret_cast<const int4*>(wg_tiles)[i];
+            bsum += ((long long)v.x + v.y) + ((long long)v.z + v.w);
+        }
+        if (t < ((c * bpc + k) & 3)) bsum += wg_tiles[4 * nb4 + t];
+    }
     const int64_t first = (int64_t)c * N + (int64_t)k * EP;
     const int np = (int)min((int64_t)EP, (int64_t)(c + 1) * N - first);
     int cnt[EPT];
@@ -573,13 +585,13 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     for (int j = 0; j < EPT; ++j) {
         const int e = j * 256 + t;
         int32_t pid = 0;
-        uint32_t org = 0, rw = 0, rh = 0, msk = 0;
+        uint32_t org = 0, rw = 0, rh = 0;
         if (e < np) {
             pid = perm[first + e];
-            rect_load(rects_d, rect32, first + e, &org, &rw, &rh, &msk);
+            rect_load(rects_d, rect32, first + e, &org, &rw, &rh);
         }
-        s_pid[e] = pid; s_org[e] = org; s_w[e] = rw | (msk << 16);
-        cnt[j] = msk ? __popc(msk) : (int)(rw * rh);
+        s_pid[e] = pid; s_org[e] = org; s_w[e] = rw;
+        cnt[j] = (int)(rw * rh);
     }
     // scan in pair order: EPT block scans of 256 consecutive pairs, the carry in a register
     int carry = 0;
@@ -593,8 +605,15 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     const int total = carry;
     __syncthreads();
     // (a true count above 2^31 wraps the int32 pair-order scan: the position test below keeps such writes out)
-    // first output position: the tile counts of all earlier workgroups, camera-major (k_isect_wg_scan)
-    const long long base = wg_base[c * bpc + k];
+    long long base;
+    if (wg_base) base = wg_base[c * bpc + k];
+    else {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bsum += __shfl_down(bsum, off);
+        if (lane == 0) s_bsum[w] = bsum;
+        __syncthreads();
+        base = (s_bsum[0] + s_bsum[1]) + (s_bsum[2] + s_bsum[3]);
+    }
     const uint32_t key0 = (uint32_t)c * (uint32_t)(tile_w * tile_h);
     int carry_owner = 0;   // owner (+1) of the last output of the previous chunk (uniform)
     for (int c0 = 0; c0 < total; c0 += ECH) {
@@ -647,19 +666,12 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
             const int p = (int)s_own[i] - 1;
             const int o = c0 + i;
             const int kk = o - (p == 0 ? 0 : s_end[p - 1]);   // index among the pair's emitted tiles, row major
-            const uint32_t wm = s_w[p], org = s_org[p];
-            const uint32_t w_ = wm & 0xFFFFu, msk = wm >> 16;
-            int qq, rem;
-            if (msk) {   // masked rectangle (<= 3 x 3): the kk-th set bit is tile dy * 3 + dx
-                const int b = mask9_nth(msk, kk);
-                qq = b >= 6 ? 2 : (b >= 3 ? 1 : 0); rem = b - 3 * qq;
-            } else {
-                // kk / w with kk < w * h <= 2^20 and w < 2^10: float estimate, corrected by one either way
-                qq = (int)((float)kk * __builtin_amdgcn_rcpf((float)w_));
-                rem = kk - qq * (int)w_;
-                if (rem < 0) { --qq; rem += (int)w_; }
-                if (rem >= (int)w_) { ++qq; rem -= (int)w_; }
-            }
+            const uint32_t w_ = s_w[p], org = s_org[p];
+            // kk / w with kk < w * h <= 2^20 and w < 2^10: float estimate, corrected by one either way
+            int qq = (int)((float)kk * __builtin_amdgcn_rcpf((float)w_));
+            int rem = kk - qq * (int)w_;
+            if (rem < 0) { --qq; rem += (int)w_; }
+            if (rem >= (int)w_) { ++qq; rem -= (int)w_; }
             const uint32_t tx = (org & 0xFFFF) + (uint32_t)rem, ty = (org >> 16) + (uint32_t)qq;
             const long long pos = base + o;
             if (pos >= 0 && pos < cap) {
@@ -671,11 +683,8 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
     }
 }
 
-// rec_count (device, may be NULL): receives the number of records emitted -- with masked rectangles fewer than the
-// pair-order scan's total, which counts rectangle areas
 int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
-                               int rect32, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* vals, int64_t cap,
-                               int32_t* rec_count) {
+                               int rect32, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* vals, int64_t cap) {
     const int64_t n_pairs = (int64_t)N * C;
     if (n_pairs == 0) return ST3R_OK;
     const int bpc = ceil_div(N, EP);
@@ -684,14 +693,16 @@ int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const
     int rc = st3r_arena_get(ctx, SLOT_RECTS_D, (rect32 ? sizeof(uint32_t) : sizeof(uint64_t)) * (size_t)n_pairs, &p);
     if (rc) return rc;
     void* rects_d = p;
-    rc = st3r_arena_get(ctx, SLOT_CUM_D, (sizeof(long long) + sizeof(int32_t)) * (size_t)grid, &p);
+    rc = st3r_arena_get(ctx, SLOT_CUM_D, (sizeof(long long) + sizeof(int32_t)) * (size_t)grid + 16, &p);
     if (rc) return rc;
     long long* wg_base = (long long*)p;
-    int32_t* wg_tiles = (int32_t*)(wg_base + grid);
+    int32_t* wg_tiles = (int32_t*)(wg_base + grid);   // (8-byte entries in front: 16-byte aligned for even grids -- see below)
+    if (((uintptr_t)wg_tiles & 15) != 0) wg_tiles += 2;
     hipLaunchKernelGGL(k_isect_gather, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects, rect32, rects_d, wg_tiles);
-    hipLaunchKernelGGL(k_isect_wg_scan, dim3(1), dim3(1024), 0, s, grid, wg_tiles, wg_base, rec_count);
-    hipLaunchKernelGGL(k_isect_emit_d, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects_d, rect32, wg_base, tile_w,
-                       tile_h, tile_keys, vals, cap);
+    const bool self_base = grid <= EMIT_SELF_BASE_MAX;
+    if (!self_base) hipLaunchKernelGGL(k_isect_wg_scan, dim3(1), dim3(1024), 0, s, grid, wg_tiles, wg_base);
+    hipLaunchKernelGGL(k_isect_emit_d, dim3(grid), dim3(256), 0, s, N, C, bpc, perm, rects_d, rect32,
+                       self_base ? (const long long*)nullptr : wg_base, wg_tiles, tile_w, tile_h, tile_keys, vals, cap);
     LAUNCH_CHECK();
     return ST3R_OK;
 }

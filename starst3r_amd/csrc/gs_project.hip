@@ -159,7 +159,6 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         }
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
         int ntiles = 0;
-        unsigned tmask = 0u;   // tiles of a small rectangle the exact ellipse test keeps (0: all of them)
         TileRect tr = {0, 0, 0, 0};
         if (valid) {
             // SH colour (degree 1) + clamp_min(c + 0.5, 0)
@@ -179,7 +178,6 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
             n_ref += (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
             if (tight) tr = tight_tile_rect(tr, m2x, m2y, opac, ca, cb, cc);  // fused train path only
             ntiles = (tr.y1 - tr.y0) * (tr.x1 - tr.x0);
-            if (rect32 == 2) tmask = exact_tile_mask9(tr, m2x, m2y, opac, ca, cb, cc);   // (masked rectangles: opt-in)
             r0 = make_float4(m2x, m2y, opac, ca);
             r1 = make_float4(cb, cc, col[0], col[1]);
             r2 = make_float4(col[2], z, __int_as_float((int)radius), 0.0f);
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         splats[pid * 3 + 1] = r1;
         splats[pid * 3 + 2] = r2;
         if (tiles_per_gauss) tiles_per_gauss[pid] = ntiles;
-        if (rects) rect_store(rects, rect32, pid, tr, tmask);
+        if (rects) rect_store(rects, rect32, pid, tr);
         if (depth_keys) {  // (camera | depth bits) key of the two-level sort; culled pairs sort last
             const uint32_t dbits = valid ? (uint32_t)__float_as_int(z) : 0xFFFFFFFFu;
             if (key_base)   // packed 32-bit key: camera (<= 8) | depth bits above those of the near plane (29 bits)

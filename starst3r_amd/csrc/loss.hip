@@ -173,16 +173,88 @@ __global__ __launch_bounds__(LT) void k_ssim_fwd(int LH, int H, int W, const flo
 struct WinV { float w[KS]; };
 __device__ __forceinline__ WinV window_in_vgprs(const Win& win) {
     WinV v;
-#ifdef SSIM_W_SGPR
-#pragma unroll
-    for (int k = 0; k < KS; ++k) v.w[k] = win.w[k];
-#else
 #pragma unroll
     for (int k = 0; k <= HALO; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(v.w[k]) : "s"(win.w[k]));
 #pragma unroll
     for (int k = HALO + 1; k < KS; ++k) v.w[k] = v.w[KS - 1 - k];   // (the window is symmetric: six registers)
-#endif
     return v;
+}
+
+// ---- moments of the ground-truth image, once per training call (round 6) ----
+// Two of the five windowed moments, conv(y) and conv(y^2), depend on the ground truth alone, and the ground truth does
+// not change inside a run_3dgs_optim call (starster/gs.py:149-152 passes the same scene.imgs every iteration).
+// st3r_loss_gt_moments computes them once, [C,H,W,3,2] floats = (conv(y), conv(y^2)) per (pixel, channel), zeros outside
+// the interior; k_ssim_fused<true> reads them instead of convolving y: 3 instead of 5 moment maps in its forward waves
+// (33 + 22 of ~275 VALU instructions per thread and row, 36 instead of 60 ring registers), 8 more bytes read per pixel and
+// channel.  Both kernels take the y taps through the macros below -- one association, no contraction left to the
+// compiler -- so the moments are the same bits whichever kernel computes them (tests/test_gpu_gs.py).
+#define YMOM_FIRST(h1, h3, w, yy) { _Pragma("clang fp contract(off)") const float wy_ = (w) * (yy); h1 = wy_; h3 = wy_ * (yy); }
+#define YMOM_TAP(h1, h3, w, yy) { _Pragma("clang fp contract(off)") const float wy_ = (w) * (yy); h1 = __builtin_fmaf((w), (yy), h1); h3 = __builtin_fmaf(wy_, (yy), h3); }
+#define VMOM_FIRST(acc, w, v) { _Pragma("clang fp contract(off)") acc = (w) * (v); }
+#define VMOM_TAP(acc, w, v) { acc = __builtin_fmaf((w), (v), acc); }
+
+// One thread per (column, channel) of a 64-column strip, rows streamed through LDS, the last eleven horizontal results in
+// a register ring -- k_ssim_fwd's structure with y alone.  Runs once per training call: not tuned.
+__global__ __launch_bounds__(LT) void k_gt_moments(int LH, int H, int W, const float* __restrict__ gt, Win win_s,
+                                                   float2* __restrict__ mom) {
+    __shared__ float sy[2][SEG];
+    const WinV win = window_in_vgprs(win_s);
+    const int cam = blockIdx.z;
+    const int j0 = blockIdx.x * LW, i0 = blockIdx.y * LH;
+    const int t = threadIdx.x;
+    const int col = t / 3, ch = t - col * 3;
+    const int j = j0 + col;
+    const float* yr = gt + (int64_t)cam * H * W * 3;
+    const int nrows = min(LH, H - i0) + 2 * HALO;  // input rows i0-5 .. i0+rows+4
+    constexpr int NPF = (SEG + LT - 1) / LT;
+    auto stage = [&](int r, int b) {
+        const int i = min(max(i0 - HALO + r, 0), H - 1);   // (clamped: a window of an interior pixel never leaves the image)
+#pragma unroll
+        for (int n = 0; n < NPF; ++n) {
+            const int e = t + n * LT;
+            if (e < SEG) {
+                const int jj = min(max(j0 - HALO + e / 3, 0), W - 1);
+                sy[b][e] = yr[((int64_t)i * W + jj) * 3 + (e - (e / 3) * 3)];
+            }
+        }
+    };
+    float ring[KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; }
+    stage(0, 0);
+    __syncthreads();
+    for (int rb = 0; rb < nrows; rb += KS) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int r = rb + s;
+            if (r < nrows) {
+                const int b = r & 1;
+                if (r + 1 < nrows) stage(r + 1, b ^ 1);
+                const float* py = &sy[b][col * 3 + ch];
+                float h1, h3;
+                YMOM_FIRST(h1, h3, win.w[0], py[0])
+#pragma unroll
+                for (int k = 1; k < KS; ++k) YMOM_TAP(h1, h3, win.w[k], py[k * 3])
+                ring[s][0] = h1; ring[s][1] = h3;
+                if (r >= 2 * HALO) {
+                    const int io = i0 + r - 2 * HALO;  // output row
+                    float my = 0.f, eyy = 0.f;
+                    if ((io >= HALO) && (io < H - HALO) && (j >= HALO) && (j < W - HALO)) {
+                        VMOM_FIRST(my, win.w[0], ring[(s + 1) % KS][0])
+                        VMOM_FIRST(eyy, win.w[0], ring[(s + 1) % KS][1])
+#pragma unroll
+                        for (int k = 1; k < KS; ++k) {
+                            const int slot = (s + 1 + k) % KS;  // input row r-10+k
+                            VMOM_TAP(my, win.w[k], ring[slot][0])
+                            VMOM_TAP(eyy, win.w[k], ring[slot][1])
+                        }
+                    }
+                    if (io < H && j < W) mom[(((int64_t)cam * H + io) * W + j) * 3 + ch] = make_float2(my, eyy);
+                }
+                __syncthreads();
+            }
+        }
+    }
 }
 
 // Forward and backward in one pass: the derivative maps D never leave the CU.  The strip's output columns need D on
@@ -215,8 +287,14 @@ __device__ __forceinline__ WinV window_in_vgprs(const Win& win) {
 #define NPF2 ((SEG2 + FT1 - 1) / FT1) // staged elements per forward thread and row
 
 // (five waves per SIMD = two workgroups of 7 waves per CU: at most 96 VGPRs; the forward threads' five 12-row rings are 60)
-__global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k_ssim_fused(int LH, int H, int W, const float* __restrict__ render,
-                                                    const float* __restrict__ gt, Win win_s, float k_l1, float k_ss,
+// GTM: conv(y), conv(y^2) come from `gtm` (st3r_loss_gt_moments) instead of being convolved here
+#ifndef SSIM_GTM_WAVES
+#define SSIM_GTM_WAVES 5
+#endif
+template <bool GTM>
+__global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(GTM ? SSIM_GTM_WAVES : 5))) void k_ssim_fused(int LH, int H, int W, const float* __restrict__ render,
+                                                    const float* __restrict__ gt, const float2* __restrict__ gtm,
+                                                    Win win_s, float k_l1, float k_ss,
                                                     double* __restrict__ sums, float* __restrict__ v_render) {
     __shared__ float sx[2][SEG2];
     __shared__ float sy[2][SEG2];
@@ -265,12 +343,22 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k
                 if (e < SEG2) { sx[b][e] = vxs[n]; sy[b][e] = vys[n]; }
             }
         };
-        float ring[SSIM_U][5];
+        constexpr int NM = GTM ? 3 : 5;   // ring entries per row: x, x^2, xy (and y, y^2)
+        float ring[SSIM_U][NM];
 #pragma unroll
         for (int s = 0; s < SSIM_U; ++s)
 #pragma unroll
-            for (int m = 0; m < 5; ++m) ring[s][m] = 0.f;
+            for (int m = 0; m < NM; ++m) ring[s][m] = 0.f;
         const bool own_col = (col >= HALO) && (col < HALO + FLW) && (jd < W);
+        // GTM: (conv(y), conv(y^2)) of the D row a later iteration completes, requested one iteration ahead like the image
+        // rows (clamped, unconditional: see below); iteration r completes image row i0 + r - 15
+        const float2* gcol = gtm + ((int64_t)cam * H * W + min(max(jd, 0), W - 1)) * 3 + ch;
+        auto fetch_gtm = [&](int r) -> float2 {
+            const int i = min(max(i0 + r - 3 * HALO, 0), H - 1);
+            return gcol[(int64_t)i * (W * 3)];
+        };
+        float2 gq = make_float2(0.f, 0.f);
+        if (GTM) gq = fetch_gtm(0);
         fetch_row(0, qx[0], qy[0]);
         commit_from(0, qx[0], qy[0]);
 #pragma unroll
@@ -285,23 +373,28 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k
                         const int b = r & 1;
                         commit_from(b ^ 1, qx[(s + 1) % SSIM_PD], qy[(s + 1) % SSIM_PD]);   // row r+1, requested SSIM_PD iterations ago
                         fetch_row(r + 1 + SSIM_PD, qx[(s + 1) % SSIM_PD], qy[(s + 1) % SSIM_PD]);
+                        const float2 gcur = gq;
+                        if (GTM) gq = fetch_gtm(r + 1);
                         if (active) {
                             const float* px = &sx[b][col * 3 + ch];
                             const float* py = &sy[b][col * 3 + ch];
                             // (the first tap initialises the sums: "0 + w x" would cost a move and a multiply-add where a
                             // multiply does -- sixteen instructions per image row over the four convolutions of this kernel)
-                            float h0, h1, h2, h3, h4;
+                            float h0, h1 = 0.f, h2, h3 = 0.f, h4;
                             {
                                 const float xx = px[0], yy = py[0], w = win.w[0];
-                                h0 = w * xx; h1 = w * yy; h2 = h0 * xx; h3 = h1 * yy; h4 = h0 * yy;
+                                h0 = w * xx; h2 = h0 * xx; h4 = h0 * yy;
+                                if (!GTM) YMOM_FIRST(h1, h3, w, yy)
                             }
 #pragma unroll
                             for (int k = 1; k < KS; ++k) {
                                 const float xx = px[k * 3], yy = py[k * 3], w = win.w[k];
-                                const float wx = w * xx, wy = w * yy;
-                                h0 += wx; h1 += wy; h2 += wx * xx; h3 += wy * yy; h4 += wx * yy;
+                                const float wx = w * xx;
+                                h0 += wx; h2 += wx * xx; h4 += wx * yy;
+                                if (!GTM) YMOM_TAP(h1, h3, w, yy)
                             }
-                            ring[s][0] = h0; ring[s][1] = h1; ring[s][2] = h2; ring[s][3] = h3; ring[s][4] = h4;
+                            ring[s][0] = h0; ring[s][1] = h2; ring[s][2] = h4;
+                            if (!GTM) { ring[s][NM - 2] = h1; ring[s][NM - 1] = h3; }
                             const int i = i0 - HALO2 + r;  // image row just staged
                             if (own_col && i >= i0 && i < i0 + rows_out) l1 += fabsf(py[HALO * 3] - px[HALO * 3]);
                             if (r >= 2 * HALO) {
@@ -309,19 +402,19 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k
                                 float d0 = 0.f, d1 = 0.f, d2 = 0.f;
                                 const bool interior = (id >= HALO) && (id < H - HALO) && (jd >= HALO) && (jd < W - HALO);
                                 if (interior) {
-                                    float mx, my, exx, eyy, exy;
+                                    float mx, my = gcur.x, exx, eyy = gcur.y, exy;
                                     {
                                         const int slot = (s + SSIM_U - 10) % SSIM_U;
                                         const float w = win.w[0];
-                                        mx = w * ring[slot][0]; my = w * ring[slot][1]; exx = w * ring[slot][2];
-                                        eyy = w * ring[slot][3]; exy = w * ring[slot][4];
+                                        mx = w * ring[slot][0]; exx = w * ring[slot][1]; exy = w * ring[slot][2];
+                                        if (!GTM) { VMOM_FIRST(my, w, ring[slot][NM - 2]) VMOM_FIRST(eyy, w, ring[slot][NM - 1]) }
                                     }
 #pragma unroll
                                     for (int k = 1; k < KS; ++k) {
                                         const int slot = (s + SSIM_U - 10 + k) % SSIM_U;  // input row r-10+k
                                         const float w = win.w[k];
-                                        mx += w * ring[slot][0]; my += w * ring[slot][1]; exx += w * ring[slot][2];
-                                        eyy += w * ring[slot][3]; exy += w * ring[slot][4];
+                                        mx += w * ring[slot][0]; exx += w * ring[slot][1]; exy += w * ring[slot][2];
+                                        if (!GTM) { VMOM_TAP(my, w, ring[slot][NM - 2]) VMOM_TAP(eyy, w, ring[slot][NM - 1]) }
                                     }
                                     // variances clamped at 0 like torchmetrics (torch.clamp(E[x^2] - mu^2, min=0)): float cancellation on flat
                         // regions would otherwise leave them slightly negative; a clamped sigma_x^2 passes no gradient
@@ -425,223 +518,15 @@ __global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(5))) void k
     }
 }
 
-#ifdef SSIM_VERTICAL_FIRST   // (measured alternative, tools/experiments/README.md: not compiled into the product library)
-// ------------------------------------------------------------------------------------------------------------------
-// Round 5: the same fused loss with the forward's two passes in the other order -- VERTICAL first, on
-// the raw x, y.  A forward thread owns one element (column, channel) of the 84-column row segment and keeps the last twelve
-// rows of x and y of THAT element in registers (24 instead of the 60 of the five-moment rings above; the rows arrive from
-// HBM straight into the ring, the images are never staged in LDS).  Per row: eleven vertical taps give the five moments of
-// the element's column, they go to LDS (moment-major: conflict-free 4-byte reads), and one iteration later the threads of
-// the 74 D columns run the horizontal taps over them (55 LDS reads instead of 22), finish SSIM and leave the D row for the
-// backward waves exactly as k_ssim_fused does; the backward waves are unchanged but run two rows behind instead of one.
-// Same taps, same sums per pass; the passes commute in exact arithmetic, in float the moments differ from k_ssim_fwd's in
-// the last bits (parity bar: oracle, 1e-5).  What it buys is residency: <= 72 VGPRs = four workgroups per CU instead of two.
-#ifndef SSIM_V_WAVES
-#define SSIM_V_WAVES 7
-#endif
-#define VSEG (SEG2)                     // elements of a row segment = vertical-pass threads (252)
-#define VMS 256                         // stride of a moment plane in LDS (floats)
-__global__ __launch_bounds__(FT2) __attribute__((amdgpu_waves_per_eu(SSIM_V_WAVES))) void k_ssim_fused_v(int LH, int H, int W, const float* __restrict__ render,
-                                                    const float* __restrict__ gt, Win win_s, float k_l1, float k_ss,
-                                                    double* __restrict__ sums, float* __restrict__ v_render) {
-    __shared__ float sm[2][5 * VMS];
-    __shared__ float sd[2][DCOLS * 9];
-    __shared__ float red[2 * (FT1 / 64)];
-    const WinV win = window_in_vgprs(win_s);
-    const int cam = blockIdx.z;
-    const int j0 = blockIdx.x * FLW, i0 = blockIdx.y * LH;
-    const float* xr = render + (int64_t)cam * H * W * 3;
-    const float* yr = gt + (int64_t)cam * H * W * 3;
-    const int rows_out = min(LH, H - i0);
-    const int nrows = rows_out + 2 * HALO2;  // input rows i0-10 .. i0+rows_out+9
-    float l1 = 0.f, ssim_acc = 0.f;
-
-    if (threadIdx.x < FT1) {
-        // ================= forward waves =================
-        const int t = threadIdx.x;
-        const int col = t / 3, ch = t - col * 3;
-        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
-        // vertical role: element t of the segment = image column j0 - 10 + col
-        const int jx = j0 - HALO2 + col;
-        const unsigned eoff = (unsigned)(min(max(jx, 0), W - 1) * 3 + ch);   // (clamped, unconditional loads: see k_ssim_fused)
-        const bool l1_col = (col >= HALO2) && (col < HALO2 + FLW) && (jx < W) && (t < VSEG);
-        // horizontal role: D column `col` = image column j0 - 5 + col (threads 0 .. 221)
-        const bool hact = t < DCOLS * 3;
-        const int jd = j0 - HALO + col;
-        const bool own_col = (col >= HALO) && (col < HALO + FLW) && (jd < W);
-        float rx[SSIM_U], ry[SSIM_U];   // row q of this element in slot q % 12
-#ifdef SSIM_V_PRODUCTS
-        float rp[SSIM_U], rq[SSIM_U], rr[SSIM_U];   // x^2, y^2, xy of the same rows: once per element instead of once per tap
-#endif
-#pragma unroll
-        for (int s = 0; s < SSIM_U; ++s) {
-            rx[s] = 0.f; ry[s] = 0.f;
-#ifdef SSIM_V_PRODUCTS
-            rp[s] = 0.f; rq[s] = 0.f; rr[s] = 0.f;
-#endif
-        }
-        auto fetch_row = [&](int r, float& vx, float& vy) {
-            const int i = min(max(i0 - HALO2 + r, 0), H - 1);
-            vx = (xr + (int64_t)i * (W * 3))[eoff]; vy = (yr + (int64_t)i * (W * 3))[eoff];
-        };
-        fetch_row(0, rx[0], ry[0]);
-        for (int rb = 0; rb <= nrows + 1; rb += SSIM_U) {
-#pragma unroll
-            for (int s = 0; s < SSIM_U; ++s) {
-                const int r = rb + s;
-                if (r <= nrows + 1) {
-                    const int b = r & 1;
-                    // row r + 1 -> its ring slot (the one slot the window of row r does not use)
-                    fetch_row(r + 1, rx[(s + 1) % SSIM_U], ry[(s + 1) % SSIM_U]);
-                    if (r < nrows) {
-                        const int i = i0 - HALO2 + r;
-                        if (l1_col && i >= i0 && i < i0 + rows_out) l1 += fabsf(ry[s] - rx[s]);
-#ifdef SSIM_V_PRODUCTS
-                        rp[s] = rx[s] * rx[s]; rq[s] = ry[s] * ry[s]; rr[s] = rx[s] * ry[s];
-#endif
-                        if (r >= 2 * HALO) {
-                            // ---- vertical taps over rows r-10 .. r of this element
-                            float v0, v1, v2, v3, v4;
-#ifdef SSIM_V_PRODUCTS
-                            {
-                                const int slot = (s + SSIM_U - 10) % SSIM_U;
-                                const float w = win.w[0];
-                                v0 = w * rx[slot]; v1 = w * ry[slot]; v2 = w * rp[slot]; v3 = w * rq[slot]; v4 = w * rr[slot];
-                            }
-#pragma unroll
-                            for (int k = 1; k < KS; ++k) {
-                                const int slot = (s + SSIM_U - 10 + k) % SSIM_U;
-                                const float w = win.w[k];
-                                v0 += w * rx[slot]; v1 += w * ry[slot]; v2 += w * rp[slot]; v3 += w * rq[slot]; v4 += w * rr[slot];
-                            }
-#else
-                            {
-                                const int slot = (s + SSIM_U - 10) % SSIM_U;
-                                const float xx = rx[slot], yy = ry[slot], w = win.w[0];
-                                v0 = w * xx; v1 = w * yy; v2 = v0 * xx; v3 = v1 * yy; v4 = v0 * yy;
-                            }
-#pragma unroll
-                            for (int k = 1; k < KS; ++k) {
-                                const int slot = (s + SSIM_U - 10 + k) % SSIM_U;
-                                const float xx = rx[slot], yy = ry[slot], w = win.w[k];
-                                const float wx = w * xx, wy = w * yy;
-                                v0 += wx; v1 += wy; v2 += wx * xx; v3 += wy * yy; v4 += wx * yy;
-                            }
-#endif
-                            float* dst = &sm[b][t];
-                            dst[0] = v0; dst[VMS] = v1; dst[2 * VMS] = v2; dst[3 * VMS] = v3; dst[4 * VMS] = v4;
-                        }
-                    }
-                    // ---- horizontal taps over the moments of row r - 1 (written one iteration ago), SSIM, D row
-                    const int rp = r - 1;
-                    if (hact && rp >= 2 * HALO && rp < nrows) {
-                        const int id = i0 + rp - 3 * HALO;  // image row of the D row completed now
-                        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-                        const bool interior = (id >= HALO) && (id < H - HALO) && (jd >= HALO) && (jd < W - HALO);
-                        if (interior) {
-                            const float* pm = &sm[b ^ 1][t];
-                            float mx = win.w[0] * pm[0], my = win.w[0] * pm[VMS], exx = win.w[0] * pm[2 * VMS],
-                                  eyy = win.w[0] * pm[3 * VMS], exy = win.w[0] * pm[4 * VMS];
-#pragma unroll
-                            for (int k = 1; k < KS; ++k) {
-                                const float w = win.w[k];
-                                mx += w * pm[3 * k]; my += w * pm[VMS + 3 * k]; exx += w * pm[2 * VMS + 3 * k];
-                                eyy += w * pm[3 * VMS + 3 * k]; exy += w * pm[4 * VMS + 3 * k];
-                            }
-                            const float sxx_raw = exx - mx * mx;
-                            const float sxx = fmaxf(sxx_raw, 0.f), syy = fmaxf(eyy - my * my, 0.f), sxy = exy - mx * my;
-                            const float n1 = 2.f * mx * my + c1, n2 = 2.f * sxy + c2;
-                            const float dd1 = mx * mx + my * my + c1, dd2 = sxx + syy + c2;
-                            const float inv1 = __builtin_amdgcn_rcpf(dd1), inv2 = __builtin_amdgcn_rcpf(dd2);
-                            const float inv = inv1 * inv2;
-                            const float ssim = n1 * n2 * inv;
-                            if (own_col && id >= i0 && id < i0 + rows_out) ssim_acc += ssim;  // one strip counts it
-                            const float dn1 = n2 * inv, dn2 = n1 * inv;
-                            const float g1 = -ssim * inv1, g2 = sxx_raw < 0.f ? 0.f : -ssim * inv2;
-                            d0 = 2.f * my * (dn1 - dn2) + 2.f * mx * (g1 - g2);  // dS/dmu_x
-                            d1 = g2;                                             // dS/dE[x^2]
-                            d2 = 2.f * dn2;                                      // dS/dE[xy]
-                        }
-                        float* dst = &sd[b ^ 1][col * 9 + ch * 3];
-                        dst[0] = d0; dst[1] = d1; dst[2] = d2;
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-    } else {
-        // ================= backward waves: output column j0 + col, two rows behind the vertical pass =================
-        const int t = threadIdx.x - FT1;
-        const int col = t / 3, ch = t - col * 3;
-        const int j = t < FLW * 3 ? j0 + col : W;   // threads past the strip (whole-wave padding) only keep the barriers
-        float ring[SSIM_U][3];
-#pragma unroll
-        for (int s = 0; s < SSIM_U; ++s) { ring[s][0] = 0.f; ring[s][1] = 0.f; ring[s][2] = 0.f; }
-        // x, y of this thread's output pixel: iteration r writes image row i0 + r - 22; requested one iteration ahead
-        float bx, by;
-        const unsigned jc = (unsigned)(min(j, W - 1) * 3 + ch);
-        auto fetch_px = [&](int r_use, float& vx, float& vy) {
-            const int ion = min(max(i0 + r_use - 2 - 2 * HALO2, 0), H - 1);
-            vx = (xr + (int64_t)ion * (W * 3))[jc]; vy = (yr + (int64_t)ion * (W * 3))[jc];
-        };
-        fetch_px(0, bx, by);
-        for (int rb = 0; rb <= nrows + 1; rb += SSIM_U) {
-#pragma unroll
-            for (int s = 0; s < SSIM_U; ++s) {
-                const int r = rb + s;
-                if (r <= nrows + 1) {
-                    const int rp = r - 2;                 // the input row whose D row (finished last iteration) is consumed now
-                    const int sp = (s + SSIM_U - 2) % SSIM_U;     // its ring slot (compile time)
-                    const float x = bx, y = by;
-                    fetch_px(r + 1, bx, by);
-                    if (rp >= 2 * HALO && j < W) {
-                        const float* pd = &sd[rp & 1][col * 9 + ch * 3];
-                        float h0 = win.w[0] * pd[0], h1 = win.w[0] * pd[1], h2 = win.w[0] * pd[2];
-#pragma unroll
-                        for (int k = 1; k < KS; ++k) {
-                            const float w = win.w[k];
-                            h0 += w * pd[k * 9]; h1 += w * pd[k * 9 + 1]; h2 += w * pd[k * 9 + 2];
-                        }
-                        ring[sp][0] = h0; ring[sp][1] = h1; ring[sp][2] = h2;
-                        if (rp >= 2 * HALO2) {
-                            const int io = i0 + rp - 2 * HALO2;
-                            if (io < H && j < W) {
-                                float a0, a1, a2;
-                                {
-                                    const int slot = (sp + SSIM_U - 10) % SSIM_U;
-                                    a0 = win.w[0] * ring[slot][0]; a1 = win.w[0] * ring[slot][1]; a2 = win.w[0] * ring[slot][2];
-                                }
-#pragma unroll
-                                for (int k = 1; k < KS; ++k) {
-                                    const int slot = (sp + SSIM_U - 10 + k) % SSIM_U;
-                                    const float w = win.w[k];
-                                    a0 += w * ring[slot][0]; a1 += w * ring[slot][1]; a2 += w * ring[slot][2];
-                                }
-                                float* vrow = v_render + ((int64_t)cam * H + io) * (W * 3);   // (uniform row pointer)
-                                const float sgn = (x > y) ? 1.0f : ((x < y) ? -1.0f : 0.0f);
-                                vrow[(unsigned)(j * 3 + ch)] = k_l1 * sgn + k_ss * (a0 + 2.f * x * a1 + y * a2);
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_down(l1, off); ssim_acc += __shfl_down(ssim_acc, off); }
-    constexpr int FW = FT1 / 64;
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < FT1) { red[threadIdx.x >> 6] = l1; red[FW + (threadIdx.x >> 6)] = ssim_acc; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int i = 0; i < FW; ++i) { a += red[i]; b += red[FW + i]; }
-        atomicAdd(&sums[2 * cam + 0], (double)a);
-        atomicAdd(&sums[2 * cam + 1], (double)b);
-    }
+// the registered ground-truth moments that belong to the images at `gt` (NULL: none -- the kernel convolves y itself)
+static const float2* gt_moments_for(const st3r_ctx* ctx, const float* gt, int C, int H, int W) {
+    if (!ctx->gtm_mom || H != ctx->gtm_h || W != ctx->gtm_w) return nullptr;
+    const int64_t img = (int64_t)H * W * 3;
+    if (gt < ctx->gtm_gt || (gt - ctx->gtm_gt) % img != 0) return nullptr;
+    const int64_t c0 = (gt - ctx->gtm_gt) / img;
+    if (c0 + C > ctx->gtm_c) return nullptr;
+    return reinterpret_cast<const float2*>(ctx->gtm_mom) + c0 * img;
 }
-#endif   // SSIM_VERTICAL_FIRST
 
 int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const float* render, const float* gt,
                    float w_l1, float w_ssim, double* sums, float* v_render, bool sums_cleared) {
@@ -668,12 +553,34 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
     const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
     const float k_l1 = (float)((double)w_l1 / ((double)H * W * 3));
     const float k_ss = cnt > 0 ? (float)(-(double)w_ssim / cnt) : 0.f;
-#ifdef SSIM_VERTICAL_FIRST
-    hipLaunchKernelGGL(k_ssim_fused_v, grid, dim3(FT2), 0, s, LH, H, W, render, gt, win, k_l1, k_ss, sums, v_render);
-#else
-    hipLaunchKernelGGL(k_ssim_fused, grid, dim3(FT2), 0, s, LH, H, W, render, gt, win, k_l1, k_ss, sums, v_render);
-#endif
+    const float2* gtm = gt_moments_for(ctx, gt, C, H, W);
+    if (gtm)
+        hipLaunchKernelGGL(k_ssim_fused<true>, grid, dim3(FT2), 0, s, LH, H, W, render, gt, gtm, win, k_l1, k_ss, sums, v_render);
+    else
+        hipLaunchKernelGGL(k_ssim_fused<false>, grid, dim3(FT2), 0, s, LH, H, W, render, gt, gtm, win, k_l1, k_ss, sums, v_render);
     LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_loss_gt_moments(st3r_ctx* ctx, void* stream, int C, int height, int width, const float* gt,
+                                     float* moments) {
+    ARG_CHECK(ctx && C > 0 && height > 0 && width > 0 && gt && moments);
+    static const Win win = make_window();
+    const int H = height, W = width;
+    const int bands = std::max(1, std::min(ceil_div(1020, ceil_div(W, LW) * C), std::max(1, H / 64)));
+    const int LH = ceil_div(H, bands);
+    hipLaunchKernelGGL(k_gt_moments, dim3(ceil_div(W, LW), ceil_div(H, LH), C), dim3(LT), 0, (hipStream_t)stream, LH, H, W, gt,
+                       win, reinterpret_cast<float2*>(moments));
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
+ST3R_EXPORT int st3r_ctx_set_gt_moments(st3r_ctx* ctx, const float* gt, const float* moments, int C, int height,
+                                        int width) {
+    ARG_CHECK(ctx);
+    if (!gt || !moments) { ctx->gtm_gt = nullptr; ctx->gtm_mom = nullptr; ctx->gtm_c = ctx->gtm_h = ctx->gtm_w = 0; return ST3R_OK; }
+    ARG_CHECK(C > 0 && height > 0 && width > 0);
+    ctx->gtm_gt = gt; ctx->gtm_mom = moments; ctx->gtm_c = C; ctx->gtm_h = height; ctx->gtm_w = width;
     return ST3R_OK;
 }
 

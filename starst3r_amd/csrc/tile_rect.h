@@ -76,55 +76,27 @@ __device__ __forceinline__ uint64_t pack_rect(TileRect r) {
 // The fused path keeps one packed rectangle per (camera, Gaussian) pair and gathers it by pair id (emit kernel): half
 // the bytes per entry is half the cache footprint of that gather, so tile grids of up to 255 x 255 tiles (images up
 // to 4080 pixels a side: every BASELINE configuration) use a 32-bit form, `is32` = 1:
-//   plain   x0 | y0 << 8 | w << 16 | h << 24                         every tile of the rectangle
-// `is32` = 2 (opt-in, debug flag 4096; grids up to 255 x 127 so that h < 128): bit 31 tells two layouts apart, the plain
-// one above and
-//   masked  x0 | y0 << 8 | w << 16 | h << 18 | mask << 20 | 1 << 31  (w, h <= 3): bit dy * 3 + dx of the 9-bit mask says
-//           whether tile (x0 + dx, y0 + dy) is emitted.  Round 5: the rectangle is the bounding box of the ellipse
-//           {alpha >= 1/255}; on SYNTH-1M 49 % of the visible pairs have a 2 x 2 rectangle and the ellipse misses one
-//           of its corners often enough that 6.0 % of all (record, tile) pairs are dead weight for the sort, the
-//           emission and the staging of both blend kernels (they fail the alpha test on all 256 pixels).
-// The RECTANGLE keeps defining the slots of the backward's partial sums (slot = base + index of the tile inside the
-// rectangle; a tile that is not emitted leaves its slot unstamped and k_gather_vtile skips it), so the pair-order scan
-// still runs over the areas; only what is emitted, sorted and staged shrinks.
-__device__ __forceinline__ uint32_t pack_rect32(TileRect r, unsigned mask9 = 0u) {
+//   x0 | y0 << 8 | w << 16 | h << 24
+// (Round 5 also carried a 9-bit mask of the tiles the exact ellipse test keeps in rectangles of at most 3 x 3 tiles:
+// 6 % fewer records on SYNTH-1M, measured not faster -- tools/experiments/README.md; removed in round 6.)
+__device__ __forceinline__ uint32_t pack_rect32(TileRect r) {
     const uint32_t w = (uint32_t)(r.x1 - r.x0), h = (uint32_t)(r.y1 - r.y0);
     if (w == 0 || h == 0) return 0u;
-    if (mask9) return (uint32_t)r.x0 | ((uint32_t)r.y0 << 8) | (w << 16) | (h << 18) | (mask9 << 20) | 0x80000000u;
     return (uint32_t)r.x0 | ((uint32_t)r.y0 << 8) | (w << 16) | (h << 24);
 }
-__device__ __forceinline__ void rect_store(void* rects, int is32, int64_t i, TileRect r, unsigned mask9 = 0u) {
-    if (is32) reinterpret_cast<uint32_t*>(rects)[i] = pack_rect32(r, mask9);
+__device__ __forceinline__ void rect_store(void* rects, int is32, int64_t i, TileRect r) {
+    if (is32) reinterpret_cast<uint32_t*>(rects)[i] = pack_rect32(r);
     else reinterpret_cast<uint64_t*>(rects)[i] = pack_rect(r);
 }
-// 32-bit entry -> origin x0 | y0 << 16, width, height, tile mask (0: every tile of the rectangle); is32 = 2: the entry
-// may be a masked one
-__device__ __forceinline__ void rect32_decode(uint32_t r, int is32, uint32_t* org, uint32_t* w, uint32_t* h, uint32_t* mask) {
-    *org = (r & 0xFFu) | ((r & 0xFF00u) << 8);
-    if (is32 == 2 && (r & 0x80000000u)) { *w = (r >> 16) & 3u; *h = (r >> 18) & 3u; *mask = (r >> 20) & 0x1FFu; }
-    else { *w = (r >> 16) & 0xFFu; *h = r >> 24; *mask = 0u; }
-}
-// number of tiles a 32-bit entry emits
-__device__ __forceinline__ int rect32_count(uint32_t r, int is32) {
-    return (is32 == 2 && (r & 0x80000000u)) ? __popc((r >> 20) & 0x1FFu) : (int)((r >> 16) & 0xFFu) * (int)(r >> 24);
-}
-// entry i of either form: origin x0 | y0 << 16, width, height (is32 is uniform over the launch); *mask as above
-__device__ __forceinline__ void rect_load(const void* rects, int is32, int64_t i, uint32_t* org, uint32_t* w, uint32_t* h,
-                                          uint32_t* mask = nullptr) {
+// entry i of either form: origin x0 | y0 << 16, width, height (is32 is uniform over the launch)
+__device__ __forceinline__ void rect_load(const void* rects, int is32, int64_t i, uint32_t* org, uint32_t* w, uint32_t* h) {
     if (is32) {
-        uint32_t m;
-        rect32_decode(reinterpret_cast<const uint32_t*>(rects)[i], is32, org, w, h, &m);
-        if (mask) *mask = m;
+        const uint32_t r = reinterpret_cast<const uint32_t*>(rects)[i];
+        *org = (r & 0xFFu) | ((r & 0xFF00u) << 8); *w = (r >> 16) & 0xFFu; *h = r >> 24;
     } else {
         const uint64_t r = reinterpret_cast<const uint64_t*>(rects)[i];
         *org = (uint32_t)(r & 0xFFFFFFFFull); *w = (uint32_t)((r >> 32) & 0xFFFF); *h = (uint32_t)(r >> 48);
-        if (mask) *mask = 0u;
     }
-}
-// the k-th emitted tile of a masked entry (k < popcount): its index dy * 3 + dx
-__device__ __forceinline__ int mask9_nth(uint32_t mask, int k) {
-    for (int i = 0; i < k; ++i) mask &= mask - 1u;
-    return __ffs((int)mask) - 1;
 }
 
 // ---- exact culling: does the ellipse {sigma(p - mean) <= tau} reach a square of pixel centres? ----
@@ -164,31 +136,6 @@ __device__ __forceinline__ bool ellipse_hits_square(const EllipseTest& e, float 
     return hit;
 }
 
-// Which tiles of a rectangle of at most 3 x 3 tiles can the ellipse {alpha >= 1/255} reach?  Bit dy * 3 + dx.  The tile's
-// pixel centres 16 t + 0.5 ... 16 t + 15.5 are widened by 0.05 px on every side (the slack of tight_tile_rect, above the
-// 0.02 / 0.01 px of the blend kernels' own quadrant and cell tests): a tile dropped here fails those tests as well, and
-// the alpha test of the blend loop on all of its 256 pixels.  Returns 0 when every tile is reachable (no mask needed).
-__device__ __forceinline__ unsigned exact_tile_mask9(TileRect r, float x, float y, float opac, float ca, float cb, float cc) {
-#pragma clang fp contract(off)
-    const int w = r.x1 - r.x0, h = r.y1 - r.y0;
-    if (w <= 0 || h <= 0 || w > 3 || h > 3 || w * h == 1) return 0u;
-    EllipseTest e;
-    if (!ellipse_prepare(opac, ca, cb, cc, &e)) return 0u;
-    unsigned m = 0u, full = 0u;
-    for (int dy = 0; dy < h; ++dy) {
-        const float y0 = (float)(16 * (r.y0 + dy)) + 0.45f - y;
-        for (int dx = 0; dx < w; ++dx) {
-            const float x0 = (float)(16 * (r.x0 + dx)) + 0.45f - x;
-            const unsigned bit = 1u << (dy * 3 + dx);
-            full |= bit;
-            if (ellipse_hits_square(e, x0, x0 + 15.1f, y0, y0 + 15.1f)) m |= bit;
-        }
-    }
-    // (never drop a pair altogether here: the rectangle says the box reaches its tiles; an empty mask would be a rounding
-    // artefact of two different conservative tests)
-    return (m == full || m == 0u) ? 0u : m;
-}
-
 // ---- exact culling at cell granularity: which of the sixteen 4x4-pixel cells of a tile can the ellipse reach? ----
 // Bit cy * 4 + cx of the result is set when some pixel centre of cell (cx, cy) -- centres tx0 + 4 cx + 0.5 ... + 3.5,
 // rows alike -- may pass the alpha >= 1/255 test; a clear bit means all sixteen pixels fail it (same inflated tau as
@@ -219,17 +166,6 @@ __device__ __forceinline__ unsigned cell_mask16(float mx, float my, float opac, 
         const float e0 = fmaxf(ry + (float)(4 * cy), -ey), e1 = fminf(ry + (float)(4 * cy + 3), ey);
         // (for e0 > e1 the strip misses the ellipse and the result is discarded below)
         const float yu = __builtin_amdgcn_fmed3f(-dys, e0, e1), yl = __builtin_amdgcn_fmed3f(dys, e0, e1);
-#ifdef CELL_MASK_ROUND4   // the arithmetic of rounds 3 - 4 (same masks)
-        const float hu = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-det * yu, yu, t2A), 0.0f)), hA, 0.01f);
-        const float hl = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-det * yl, yl, t2A), 0.0f)), hA, 0.01f);
-        const float xhi = __builtin_fmaf(-bA, yu, hu), xlo = -__builtin_fmaf(bA, yl, hl);
-        // cells with  rx + 4 cx <= xhi  and  rx + 4 cx + 3 >= xlo
-        const float hi = fminf(floorf(__builtin_fmaf(xhi, 0.25f, kh)), 3.0f), lo = fmaxf(ceilf(__builtin_fmaf(xlo, 0.25f, kl)), 0.0f);
-        if (e0 <= e1 && lo <= hi) {
-            const int il = (int)lo, n = (int)hi - il + 1;
-            m |= (((1u << n) - 1u) << il) << (4 * cy);
-        }
-#else
         // Round 5 (issue classes, tools/probe/valu_issue.hip: min / max / floor / convert / shift are four-cycle instructions,
         // and one evaluation of this test costs the forward ~0.1 ms): |.| under the root instead of max(., 0) -- a slightly
         // negative radicand at the very tips of the ellipse becomes a slightly positive one, i.e. a superset --, floor and
@@ -247,7 +183,6 @@ __device__ __forceinline__ unsigned cell_mask16(float mx, float my, float opac, 
         unsigned bits;
         asm("v_bfm_b32 %0, %1, %2" : "=v"(bits) : "v"(max(n, 0)), "v"(il + 4 * cy));   // ((1 << n) - 1) << (il + 4 cy)
         m |= bits;
-#endif
     }
     return m;
 }

@@ -244,7 +244,16 @@ def _gt_on_device(scene, views):
     if getattr(scene, "_gt_dev", None) is None or scene._gt_dev[0] != key:
         imgs = [torch.as_tensor(np.asarray(scene.imgs[i]), dtype=torch.float32) for i in views]
         scene._gt_dev = (key, torch.stack(imgs).to(scene.device).contiguous())
+        scene._gt_mom = None
     return scene._gt_dev[1]
+
+
+def _gt_moments(scene, ctx, gt):
+    """SSIM's windowed moments of the ground truth, conv(gt) and conv(gt^2): the reference recomputes them every iteration
+    (torchmetrics, gs.py:129) although the images never change; here once per uploaded image set."""
+    if getattr(scene, "_gt_mom", None) is None or scene._gt_mom[0] is not gt:
+        scene._gt_mom = (gt, ops.gt_moments(ctx, gt))
+    return scene._gt_mom[1]
 
 
 def run_3dgs_optim(
@@ -321,11 +330,19 @@ def run_3dgs_optim(
 
     # A peer failure (ST3R_ERR_PEER: the step before failed on some rank, nobody applied it) ABORTS the run on every rank
     # alike -- all ranks get the code from the same call --; the exchange form is restored whatever ends the loop.
+    # our own strategy reads the parameters in step_post_backward only, and the SH rows on refinement steps only
+    # (relocation / growth copy whole rows); any OTHER strategy object sees up-to-date rows at every hook call
+    own_strategy = type(scene.strategy) is MCMCStrategy
+    ops.set_gt_moments(ctx, gt, _gt_moments(scene, ctx, gt))
     try:
         step = 0
         for _ in it_range:
             if enable_pruning:
+                if not own_strategy:
+                    sh_write_back()
                 scene.strategy.step_pre_backward(g, scene.optimizers, scene.strategy_state, step, None)
+                if not own_strategy:
+                    sh_c[0] = g["shN"].data[:, :4].contiguous()
             st.step += 1
             try:
                 one_iteration(step)
@@ -347,10 +364,7 @@ def run_3dgs_optim(
                     st.step += 1
                 one_iteration(step)
             if enable_pruning:
-                # our own strategy touches the SH rows on refinement steps only (relocation / growth copy whole rows); any
-                # other strategy object sees up-to-date parameters at every call
-                refine = getattr(scene.strategy, "is_refine_step", None)
-                touch = True if refine is None else bool(refine(step))
+                touch = bool(scene.strategy.is_refine_step(step)) if own_strategy else True
                 if touch:
                     sh_write_back()
                 scene.strategy.step_post_backward(g, scene.optimizers, scene.strategy_state, step, None, 1e-3)
@@ -365,6 +379,7 @@ def run_3dgs_optim(
                     raise
                 one_iteration(iters - 1)   # its update was skipped on the device: repeat it
     finally:
+        ops.set_gt_moments(ctx, None, None)
         if sh_c[0].shape[0] == g["shN"].shape[0]:
             sh_write_back()
         if restore_exchange is not None:   # (the moments stay complete on every rank: rs_ag goes on using its own piece)
@@ -453,18 +468,22 @@ def _run_3dgs_optim_sharded(scene, iters, ssim_fac, opac_fac, scale_fac, verbose
         from tqdm import trange
         it_range = trange(iters)
     strategy, state = scene.strategy, scene.strategy_state
-    for step in it_range:
-        tr.step(losses[step:step + 1])
-        if enable_pruning:   # MCMCStrategy.step_post_backward, shard-wise
-            seed, call = state.get("seed", 0), state.get("calls", 0)
-            state["calls"] = call + 1
-            with torch.no_grad():
-                if strategy.is_refine_step(step):
-                    unshard(tr, P, N, n, counts)
-                    strategy.refine(scene.gaussians, scene.optimizers, state, step, call)
-                    tr, P, N, n, lo, counts = shard()
-                ops.mcmc_noise(ctx, {k: P[k] for k in ("means", "quats", "scales", "opacities")},
-                               1e-3 * strategy.noise_lr, seed, call, row_offset=lo)
+    ops.set_gt_moments(ctx, gt, _gt_moments(scene, ctx, gt))
+    try:
+        for step in it_range:
+            tr.step(losses[step:step + 1])
+            if enable_pruning:   # MCMCStrategy.step_post_backward, shard-wise
+                seed, call = state.get("seed", 0), state.get("calls", 0)
+                state["calls"] = call + 1
+                with torch.no_grad():
+                    if strategy.is_refine_step(step):
+                        unshard(tr, P, N, n, counts)
+                        strategy.refine(scene.gaussians, scene.optimizers, state, step, call)
+                        tr, P, N, n, lo, counts = shard()
+                    ops.mcmc_noise(ctx, {k: P[k] for k in ("means", "quats", "scales", "opacities")},
+                                   1e-3 * strategy.noise_lr, seed, call, row_offset=lo)
+    finally:
+        ops.set_gt_moments(ctx, None, None)
     unshard(tr, P, N, n, counts)
     _dist.all_reduce_sum(losses)
     return losses[:iters].cpu().tolist()

@@ -221,6 +221,27 @@ def loss_l1_ssim(ctx, render, gt, w_l1, w_ssim, want_grad=True):
     return sums, v
 
 
+def gt_moments(ctx, gt):
+    """(conv(gt), conv(gt^2)) of SSIM's 11 x 11 window for the images gt [C,H,W,3]: [C,H,W,3,2], computed once per
+    training call (st3r_loss_gt_moments)."""
+    Cn, H, W = gt.shape[0], gt.shape[1], gt.shape[2]
+    mom = torch.empty((Cn, H, W, 3, 2), dtype=torch.float32, device=gt.device)
+    _lib.check(_lib.lib().st3r_loss_gt_moments(ctx.handle, _stream(), Cn, H, W, _p(gt), _p(mom)))
+    return mom
+
+
+def set_gt_moments(ctx, gt, moments):
+    """Register (gt, moments) with the ctx -- the loss kernels then read the moments instead of convolving gt -- or clear
+    the registration (gt = None).  The caller keeps both tensors alive and unchanged while registered."""
+    if gt is None or moments is None:
+        _lib.check(_lib.lib().st3r_ctx_set_gt_moments(ctx.handle, None, None, 0, 0, 0))
+        ctx._gtm_keep = None
+        return
+    assert gt.is_contiguous() and moments.is_contiguous() and moments.shape == (*gt.shape, 2)
+    _lib.check(_lib.lib().st3r_ctx_set_gt_moments(ctx.handle, _p(gt), _p(moments), gt.shape[0], gt.shape[1], gt.shape[2]))
+    ctx._gtm_keep = (gt, moments)
+
+
 def adam_step(ctx, params, grads, m, v, lr, b1, b2, eps, step):
     """params: dict with means, quats, scales, opacities, shN (updated in place)."""
     N = params["means"].shape[0]

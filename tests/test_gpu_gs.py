@@ -264,6 +264,86 @@ def test_l1_ssim_vs_oracle(ctx, shape):
         assert (err[big] / np.abs(vr[big])).max() <= 1e-5
 
 
+@pytest.mark.parametrize("shape", [(1, 30, 37), (3, 64, 96), (2, 75, 101), (1, 200, 333)])
+def test_gt_moments_change_no_bit_of_the_loss(ctx, shape):
+    """Round 6: conv(gt) and conv(gt^2) are computed once per training call (st3r_loss_gt_moments) and read by the fused loss
+    kernel instead of being convolved every iteration.  Same taps in the same order: the sums and the gradient image are the
+    same BITS with and without the registered moments -- for the whole image set and for a whole-view offset into it (view
+    shards / view chunks) -- and the moments equal a float64 convolution of the ground truth (starster/gs.py:129: torchmetrics
+    recomputes them every call)."""
+    from starst3r_amd import ops
+    Cn, H, W = shape
+    rng = np.random.default_rng(5)
+    x = dev(rng.uniform(0, 1, (Cn, H, W, 3)).astype(np.float32))
+    y_np = np.clip(x.cpu().numpy() + rng.normal(0, 0.1, (Cn, H, W, 3)), 0, 1).astype(np.float32)
+    y = dev(y_np)
+    s0, v0 = ops.loss_l1_ssim(ctx, x, y, 0.8, 0.2)
+    mom = ops.gt_moments(ctx, y)
+    ops.set_gt_moments(ctx, y, mom)
+    try:
+        s1, v1 = ops.loss_l1_ssim(ctx, x, y, 0.8, 0.2)
+        s1b, v1b = ops.loss_l1_ssim(ctx, x[Cn - 1:], y[Cn - 1:], 0.8, 0.2)      # the last view alone: an offset into gt
+        other = y.clone()                                                         # another buffer: moments not used, same result
+        s2, v2 = ops.loss_l1_ssim(ctx, x, other, 0.8, 0.2)
+    finally:
+        ops.set_gt_moments(ctx, None, None)
+    torch.cuda.synchronize()
+    for s_, v_ in ((s1, v1), (s2, v2)):
+        assert torch.equal(v_.view(torch.int32), v0.view(torch.int32))
+        # (the sums are double-precision atomics over the strips: order-dependent in the last bits only)
+        assert torch.allclose(s_, s0, rtol=1e-13, atol=0)
+    assert torch.equal(v1b.view(torch.int32), v0[Cn - 1:].view(torch.int32))
+    # the moments against a float64 separable convolution
+    g = np.exp(-0.5 * ((np.arange(11) - 5) / 1.5) ** 2); g /= g.sum()
+    M = mom.cpu().numpy().astype(np.float64)
+    yd = y_np.astype(np.float64)
+
+    def conv(a):
+        out = np.zeros((Cn, H - 10, W - 10, 3))
+        tmp = sum(g[k] * a[:, :, k:k + W - 10] for k in range(11))
+        out = sum(g[k] * tmp[:, k:k + H - 10] for k in range(11))
+        return out
+    assert np.abs(M[:, 5:H - 5, 5:W - 5, :, 0] - conv(yd)).max() < 2e-6
+    assert np.abs(M[:, 5:H - 5, 5:W - 5, :, 1] - conv(yd * yd)).max() < 2e-6
+    border = np.ones((H, W), bool); border[5:H - 5, 5:W - 5] = False
+    assert np.all(M[:, border] == 0.0)
+
+
+def test_gt_moments_change_no_bit_of_a_training_step():
+    """The same through st3r_gs_train_fwd_bwd, in one pass and with the views walked in two chunks (debug flag 32: the second
+    chunk's ground-truth pointer is a whole-view offset): gradients and loss bit for bit.  (A context of its own: the chunk
+    count sticks to a context.)"""
+    from starst3r_amd import ops
+    ctx = ops.Context("cuda:0")
+    g, w2c, Ks, W, H = make("medium")
+    N = g["means"].shape[0]
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    campos = ops.camera_positions(vm)
+    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
+    torch.manual_seed(5)
+    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
+    mom = ops.gt_moments(ctx, gt)
+    out = {}
+    try:
+        for flag in (0, 32):
+            for use in (False, True):
+                ops.set_debug(ctx, flag)
+                ops.set_gt_moments(ctx, gt if use else None, mom if use else None)
+                grads = torch.full((23 * N,), float("nan"), device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+                ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+                torch.cuda.synchronize()
+                out[(flag, use)] = (grads, float(loss[0]))
+    finally:
+        ops.set_debug(ctx, 0)
+        ops.set_gt_moments(ctx, None, None)
+    for flag in (0, 32):
+        (g0, l0), (g1, l1) = out[(flag, False)], out[(flag, True)]
+        assert bool(torch.isfinite(g1).all())
+        assert torch.equal(g0.view(torch.int32), g1.view(torch.int32)), flag
+        assert abs(l0 - l1) <= 1e-6 * abs(l0)
+
+
 def test_adam_vs_oracle_and_torch(ctx):
     from starst3r_amd import ops
     N = 333
@@ -385,106 +465,6 @@ def test_fused_train_gradients_equal_stage_path(ctx, name):
     expect = sum(0.8 * s[c, 0] / (H * W * 3) + 0.2 * (1 - s[c, 1] / ((H - 10) * (W - 10) * 3)) for c in range(Cn))
     expect += Cn * (0.01 * float(torch.sigmoid(P["opacities"]).mean()) + 0.01 * float(torch.exp(P["scales"]).mean()))
     assert abs(float(loss[0]) - expect) <= 1e-5 * abs(expect)
-
-
-@pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
-def test_masked_rectangles_drop_only_dead_records(ctx, name):
-    """Debug flag 4096 (round 5, opt-in: measured not faster): rectangles of at most 3 x 3 tiles carry the mask of the tiles
-    the exact ellipse test keeps; the emission writes fewer records, the backward's slots stay rectangle-indexed.  A
-    dropped (record, tile) pair fails the alpha test on all 256 pixels: images bit-identical, gradients bit-identical
-    (the same per-record sums in the same slots, the dropped slots were never stamped with anything but zeros)."""
-    from starst3r_amd import ops
-    g, w2c, Ks, W, H = make(name)
-    N = g["means"].shape[0]
-    P = {k: dev(v) for k, v in g.items()}
-    vm, K = dev(w2c), dev(Ks)
-    campos = ops.camera_positions(vm)
-    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
-    torch.manual_seed(5)
-    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
-    out = {}
-    try:
-        for flag in (0, 4096):
-            ops.set_debug(ctx, flag)
-            grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
-            st = ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
-            torch.cuda.synchronize()
-            img = ops.peek(ctx, 8, rgb.numel(), torch.float32).clone()
-            out[flag] = (st, grads, float(loss[0]), img)
-    finally:
-        ops.set_debug(ctx, 0)
-    (st0, g0, l0, i0), (st1, g1, l1, i1) = out[0], out[4096]
-    assert st1["n_isects_ref"] == st0["n_isects_ref"] and st1["n_visible"] == st0["n_visible"]
-    assert 0 <= st1["n_isects"] <= st0["n_isects"]
-    assert torch.equal(i0.view(torch.int32), i1.view(torch.int32)) and l0 == l1
-    # gradients: the per-(record, tile) sums are unchanged, but the contribution words of a forward batch group other
-    # records now (batches of 256 consecutive LIST entries), so the backward's rounds -- and with them the grouping of the
-    # float sums per record -- may differ: equal to rounding
-    scale = float(g0.abs().max())
-    assert float((g1 - g0).abs().max()) <= (2e-3 if name.startswith("fuzz") else 2e-5) * scale
-
-
-@pytest.mark.parametrize("name", ["small", "ragged", "medium", "many", "one"] + FUZZ[:4])
-def test_pair_sums_inside_the_projection_backward_are_bit_identical(ctx, name):
-    """Round 5: the fused training calls sum a pair's (record, tile) slots inside the projection backward
-    (gs_project_bwd.hip, GATHER) instead of in k_gather_vtile + a 48-byte record per pair (debug flag 16384 keeps the two
-    kernels): the same sums in the same order, so the 23 N gradients and the loss are the same bits."""
-    from starst3r_amd import ops
-    g, w2c, Ks, W, H = make(name)
-    N = g["means"].shape[0]
-    P = {k: dev(v) for k, v in g.items()}
-    vm, K = dev(w2c), dev(Ks)
-    campos = ops.camera_positions(vm)
-    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
-    torch.manual_seed(5)
-    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
-    out = []
-    try:
-        for flag in (16384, 0):
-            ops.set_debug(ctx, flag)
-            grads = torch.full((23 * N,), float("nan"), device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
-            ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
-            torch.cuda.synchronize()
-            out.append((grads, float(loss[0])))
-    finally:
-        ops.set_debug(ctx, 0)
-    (g0, l0), (g1, l1) = out
-    assert l0 == l1 and bool(torch.isfinite(g1).all())
-    assert torch.equal(g0.view(torch.int32), g1.view(torch.int32))
-
-
-@pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
-def test_experimental_cell_backward_agrees_with_the_quadrant_backward(ctx, name):
-    """Debug flag 8192 (round 5 experiment, measured 0.86 ms SLOWER: tools/experiments/README.md): the blend backward with a
-    cell-granular phase 1 (gs_blend_cells.hip: k_blend_bwd_cells).  Same forward, same slots; the per-record sums are grouped
-    by cell instead of by 4-pixel runs of a quadrant, so the gradients agree to rounding -- and twice in a row bit for bit
-    (no atomics)."""
-    from starst3r_amd import ops
-    g, w2c, Ks, W, H = make(name)
-    N = g["means"].shape[0]
-    P = {k: dev(v) for k, v in g.items()}
-    vm, K = dev(w2c), dev(Ks)
-    campos = ops.camera_positions(vm)
-    rgb, _, _ = ops.render(ctx, P, vm, K, campos, W, H)
-    torch.manual_seed(5)
-    gt = torch.clamp(rgb + 0.1 * torch.randn_like(rgb), 0, 1).contiguous()
-    out = []
-    try:
-        for flag in (0, 8192, 8192):
-            ops.set_debug(ctx, flag)
-            grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
-            ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
-            torch.cuda.synchronize()
-            out.append((grads, float(loss[0])))
-    finally:
-        ops.set_debug(ctx, 0)
-    (g0, l0), (g1, l1), (g2, l2) = out
-    assert l0 == l1 == l2
-    assert torch.equal(g1.view(torch.int32), g2.view(torch.int32))
-    scale = float(g0.abs().max())
-    print("cell-vs-quadrant", name, float((g1 - g0).abs().max()) / scale)
-    # the stress scenes' needle-shaped Gaussians sum terms far above the result (see the stage-path test above)
-    assert float((g1 - g0).abs().max()) <= (1e-2 if name.startswith("fuzz") else 2e-5) * scale
 
 
 @pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
