@@ -79,7 +79,9 @@ int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t byt
 int st3r_ctx_set_profiling(st3r_ctx* ctx, int enable);
 /* test hook. bit 0: the blend forward walks every staged record in every wave (no per-quadrant relevance test):
  * images must come out bit-identical, which is how the culling is validated at full size.
- * st3r_ctx_peek(which = 8 / 9): rgb [C,H,W,3] / alpha [C,H,W] of the last st3r_gs_train_fwd_bwd call.
+ * st3r_ctx_peek(which = 8 / 9): rgb [C,H,W,3] / alpha [C,H,W] of the last st3r_gs_train_fwd_bwd call; which = 10: the 16
+ * int32 control words of the fused steps ([8..10] = bias, sentinel key and pass count of the segmented level-1 sort).
+ * bit 2 (4): the training calls' level-1 sort on (camera | depth) keys in four passes instead of per-camera segments.
  * (the other bits: csrc/common.h, st3r_ctx::debug_flags) */
 int st3r_ctx_set_debug(st3r_ctx* ctx, int flags);
 /* Waits for the record count of the last asynchronous training step (st3r_gs_train_fwd_bwd / st3r_gs_train_step with

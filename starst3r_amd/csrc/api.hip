@@ -95,10 +95,10 @@ int st3r_arena_get2(st3r_ctx* ctx, int slot, size_t bytes, void** out, int* grow
 // which: 0 = sorted pair ids ("flatten ids", int32 [n_isects]), 1 = tile offsets (int32 [C*tiles]),
 //        2 = splat records (float [C*N*12]), 3 = inclusive tile scan in pair-id order (int32 [C*N])
 ST3R_EXPORT int st3r_ctx_peek(st3r_ctx* ctx, void* stream, int which, void* dst, int64_t bytes) {
-    ARG_CHECK(ctx && dst && bytes >= 0 && which >= 0 && which <= 9);
-    static const int slots[10] = {SLOT_VALS_B, SLOT_OFFSETS, SLOT_SPLATS, SLOT_CUM,
+    ARG_CHECK(ctx && dst && bytes >= 0 && which >= 0 && which <= 10);
+    static const int slots[11] = {SLOT_VALS_B, SLOT_OFFSETS, SLOT_SPLATS, SLOT_CUM,
                                   SLOT_MCMC_CUM, SLOT_MCMC_DEAD, SLOT_MCMC_SAMPLED, SLOT_MCMC_COUNT,
-                                  SLOT_RGB, SLOT_ALPHA};
+                                  SLOT_RGB, SLOT_ALPHA, SLOT_COUNTS};
     ARG_CHECK((size_t)bytes <= ctx->slot_bytes[slots[which]]);
     HIP_TRY(hipMemcpyAsync(dst, ctx->slot_ptr[slots[which]], (size_t)bytes, hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
@@ -187,7 +187,9 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
                       uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32,
-                      int reg_overwrite, double* zero_ptr, int zero_n);
+                      int reg_overwrite, double* zero_ptr, int zero_n, uint32_t* krange);
+int st3r_sort_depth_seg_impl(st3r_ctx* ctx, hipStream_t s, int64_t N, int C, uint32_t* keys_in, int32_t* vals_in,
+                             uint32_t* keys_out, int32_t* vals_out, const uint32_t* krange);
 int st3r_isect_emit_chain_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const int32_t* perm, const void* rects,
                                int rect32, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* vals, int64_t cap);
 int st3r_records_prepare_impl(hipStream_t s, int N, int C, const float* splats, int tile_size, int tile_w, int tile_h,
@@ -336,6 +338,13 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     // flag 64, whose backward reads the 64-bit form
     const int rect32 = (tile_w <= 255 && tile_h <= 255 && !(ctx->debug_flags & 64)) ? 1 : 0;
     GET(SLOT_RECTS, uint64_t, rect32 ? (n_pairs + 1) / 2 : n_pairs, rects);
+    int32_t* counts = nullptr;
+    { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
+    // Round 6: with the projection's own reduction at hand (training calls) the level-1 sort runs per camera SEGMENT on keys
+    // biased by the smallest depth code of the call -- three 8-bit passes instead of four whenever the scene's depth codes
+    // span less than 2^24 (decided on the device: counts[8..10] = bias, sentinel, passes); debug flag 4 keeps the
+    // (camera | depth) keys and their four passes
+    uint32_t* const krange = (key32 && reg_sums && !records_in && !(ctx->debug_flags & 4)) ? (uint32_t*)(counts + 8) : nullptr;
     st3r_prof_begin(ctx, s, STG_PROJECT);
     const uint32_t key_base = key32 ? near_bits : 0u;
     int rc = records_in
@@ -343,15 +352,16 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
                                              key_base, rects, rect32)
                  : st3r_project_impl(ctx, s, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos,
                                      W, H, tile, 0.3f, near_plane, far_plane, 0.0f, splats, nullptr, reg_sums, dkeys_a,
-                                     dvals_a, tight, key_base, rects, rect32, 1, loss_sums, 2 * C);
+                                     dvals_a, tight, key_base, rects, rect32, 1, loss_sums, 2 * C, krange);
     if (!rc && records_in && loss_sums) HIP_TRY(hipMemsetAsync(loss_sums, 0, sizeof(double) * 2 * (size_t)C, s));
     st3r_prof_end(ctx, s, STG_PROJECT);
     if (rc) return rc;
     st3r_prof_begin(ctx, s, STG_SORT_DEPTH);
     const int cam_bits = bit_length_u32((uint32_t)(C - 1));
-    rc = key32 ? st3r_sort_depth32_impl(ctx, s, n_sort, 29 + cam_bits, (uint32_t*)dkeys_a, dvals_a, (uint32_t*)dkeys_b,
-                                        perm)
-               : st3r_sort_depth_impl(ctx, s, n_sort, 32 + cam_bits, dkeys_a, dvals_a, dkeys_b, perm);
+    rc = krange ? st3r_sort_depth_seg_impl(ctx, s, N, C, (uint32_t*)dkeys_a, dvals_a, (uint32_t*)dkeys_b, perm, krange)
+         : key32 ? st3r_sort_depth32_impl(ctx, s, n_sort, 29 + cam_bits, (uint32_t*)dkeys_a, dvals_a, (uint32_t*)dkeys_b,
+                                          perm)
+                 : st3r_sort_depth_impl(ctx, s, n_sort, 32 + cam_bits, dkeys_a, dvals_a, dkeys_b, perm);
     st3r_prof_end(ctx, s, STG_SORT_DEPTH);
     if (rc) return rc;
     int64_t n_isects = 0;
@@ -372,8 +382,6 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     const int32_t* n_dev = nullptr;
     const int64_t sig = ((int64_t)N << 34) ^ ((int64_t)C << 26) ^ ((int64_t)W << 13) ^ (int64_t)H;
     const bool async = allow_async && ctx->isect_hint > 0 && ctx->hint_sig == sig;
-    int32_t* counts = nullptr;
-    { int rc_ = st3r_counts_buffer(ctx, s, &counts); if (rc_) return rc_; }
     int32_t* total_dev = nullptr;
     rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev,
                               async ? counts : nullptr);

@@ -72,6 +72,7 @@ enum ArenaSlot {
     SLOT_PSTAGE,
     SLOT_GSTAGE,
     SLOT_ALIGN_CTL,   // alignment: the chain cache of k_align_update
+    SLOT_KRANGE_PART, // projection: per-block smallest / largest level-1 key (gs_project.hip)
     SLOT_SCAN_CHAIN,  // single-pass scans (gs_isect.hip): ticket, totals, one status word per tile
     SLOT_COUNT
 };
@@ -106,7 +107,7 @@ struct st3r_ctx {
     int64_t* pinned;  // small pinned host buffer for read-backs
     // profiling: ring of (start, stop) events per stage; elapsed times are harvested lazily
     int debug_flags;  // st3r_ctx_set_debug: bit 0 = blend forward ignores the per-quadrant relevance test; 1: backward
-                      // recomputes the tile rectangles; 3: async capacity halved; 5: training calls start at 2 view chunks;
+                      // recomputes the tile rectangles; 2 (4): level-1 sort on (camera | depth) keys in four passes; 3: async capacity halved; 5: training calls start at 2 view chunks;
                       // 6: backward gathers rectangle and slot base separately; 7 (128): training forward on the quadrant
                       // kernel; 9 (512): st3r_gs_render on the cell-list kernel; 11 (2048): under a communicator
                       // st3r_gs_train_step behaves as if this rank's forward / backward had failed (comm.hip)

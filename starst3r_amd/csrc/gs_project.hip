@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
     float near_plane, float far_plane, float radius_clip, float4* __restrict__ splats,
     int32_t* __restrict__ tiles_per_gauss, double* __restrict__ reg_part,
     uint64_t* __restrict__ depth_keys, int32_t* __restrict__ depth_vals, int tight, uint32_t key_base,
-    void* __restrict__ rects, int rect32) {
+    void* __restrict__ rects, int rect32, uint32_t* __restrict__ krange_part) {
+    // krange_part != NULL (fused training calls, <= 8 views): the level-1 keys carry NO camera bits -- the sort treats every
+    // camera's N pairs as a segment of its own (radix_sort.hip) -- and the block's smallest / largest key of a visible pair
+    // is left for k_reg_reduce, which turns them into the bias and the pass count of that sort
     extern __shared__ float cam[];
     __shared__ float red[8];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         }
     }
     int n_vis = 0, n_ref = 0;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;   // level-1 keys of this thread's visible pairs
     for (int c = 0; active && c < C; ++c) {
         const float* o = cam + c * CAM_STRIDE;
         const float R00 = o[0], R01 = o[1], R02 = o[2], t0 = o[3];
@@ -189,13 +193,26 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
         if (rects) rect_store(rects, rect32, pid, tr);
         if (depth_keys) {  // (camera | depth bits) key of the two-level sort; culled pairs sort last
             const uint32_t dbits = valid ? (uint32_t)__float_as_int(z) : 0xFFFFFFFFu;
-            if (key_base)   // packed 32-bit key: camera (<= 8) | depth bits above those of the near plane (29 bits)
-                reinterpret_cast<uint32_t*>(depth_keys)[pid] = ((uint32_t)c << 29) | (valid ? dbits - key_base : 0x1FFFFFFFu);
-            else
+            if (key_base) {  // packed 32-bit key: camera (<= 8) | depth bits above those of the near plane (29 bits)
+                const uint32_t kk = valid ? dbits - key_base : 0x1FFFFFFFu;
+                reinterpret_cast<uint32_t*>(depth_keys)[pid] = (krange_part ? 0u : ((uint32_t)c << 29)) | kk;
+                if (valid) { kmin = min(kmin, kk); kmax = max(kmax, kk); }
+            } else
                 depth_keys[pid] = ((uint64_t)c << 32) | dbits;
             depth_vals[pid] = (int32_t)pid;
         }
         n_vis += valid ? 1 : 0;
+    }
+    if (krange_part) {
+        for (int off = 32; off > 0; off >>= 1) { kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, off)); kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, off)); }
+        __shared__ uint32_t redk[8];
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { redk[w] = kmin; redk[4 + w] = kmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            krange_part[2 * blockIdx.x + 0] = min(min(redk[0], redk[1]), min(redk[2], redk[3]));
+            krange_part[2 * blockIdx.x + 1] = max(max(redk[4], redk[5]), max(redk[6], redk[7]));
+        }
     }
     if (reg_part) {  // visible (camera, gaussian) pairs and reference tile intersections of this block
         for (int off = 32; off > 0; off >>= 1) { n_vis += __shfl_down(n_vis, off); n_ref += __shfl_down(n_ref, off); }
@@ -214,10 +231,37 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
 // same-address double atomics from the projection kernel used to cost more than the projection itself).  The fused
 // training calls also let this one small workgroup clear the loss kernel's accumulators (zero_ptr[0 .. zero_n)): two
 // memset launches less per step.
+// krange (with krange_part, the fused training calls): [0] = smallest level-1 key of a visible pair, [1] = the key the
+// culled pairs get after the bias (largest - smallest + 1: they sort last), [2] = the 8-bit passes the segmented level-1
+// sort needs for keys up to [1] -- three when the depth codes of the scene span less than 2^24 (SYNTH-1M: 2^23.3), else four.
 __global__ __launch_bounds__(256) void k_reg_reduce(int n_blocks, const double* __restrict__ reg_part,
                                                     double* __restrict__ reg_sums, int overwrite,
-                                                    double* __restrict__ zero_ptr, int zero_n) {
+                                                    double* __restrict__ zero_ptr, int zero_n,
+                                                    const uint32_t* __restrict__ krange_part,
+                                                    uint32_t* __restrict__ krange) {
     for (int i = threadIdx.x; i < zero_n; i += 256) zero_ptr[i] = 0.0;
+    if (krange_part) {
+        __shared__ uint32_t shk[2][256];
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int b = threadIdx.x; b < n_blocks; b += 256) { lo = min(lo, krange_part[2 * b]); hi = max(hi, krange_part[2 * b + 1]); }
+        shk[0][threadIdx.x] = lo; shk[1][threadIdx.x] = hi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) {
+                shk[0][threadIdx.x] = min(shk[0][threadIdx.x], shk[0][threadIdx.x + off]);
+                shk[1][threadIdx.x] = max(shk[1][threadIdx.x], shk[1][threadIdx.x + off]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            lo = shk[0][0]; hi = shk[1][0];
+            if (hi < lo) { lo = 0u; hi = 0u; }             // nothing visible
+            const uint32_t top = hi - lo + 1u;            // the culled pairs' key; < 2^29
+            krange[0] = lo; krange[1] = top;
+            krange[2] = top < (1u << 8) ? 1u : top < (1u << 16) ? 2u : top < (1u << 24) ? 3u : 4u;
+        }
+        __syncthreads();
+    }
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
     for (int b = threadIdx.x; b < n_blocks; b += 256)
@@ -239,7 +283,8 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
                       const float* campos, int width, int height, int tile_size, float eps2d, float near_plane,
                       float far_plane, float radius_clip, float* splats, int32_t* tiles_per_gauss, double* reg_sums,
                       uint64_t* depth_keys, int32_t* depth_vals, int tight, uint32_t key_base, void* rects, int rect32,
-                      int reg_overwrite, double* zero_ptr, int zero_n) {
+                      int reg_overwrite, double* zero_ptr, int zero_n, uint32_t* krange) {
+    // krange != NULL (needs reg_sums): segment keys + key range for the segmented level-1 sort (see k_reg_reduce)
     if (N == 0) {
         if (reg_sums && reg_overwrite) HIP_TRY(hipMemsetAsync(reg_sums, 0, sizeof(double) * 4, s));
         if (zero_ptr && zero_n > 0) HIP_TRY(hipMemsetAsync(zero_ptr, 0, sizeof(double) * (size_t)zero_n, s));
@@ -255,13 +300,20 @@ int st3r_project_impl(st3r_ctx* ctx, hipStream_t s, int N, int C, const float* m
         if (rc) return rc;
         reg_part = (double*)p;
     }
+    uint32_t* krange_part = nullptr;
+    if (krange && reg_sums) {
+        void* p;
+        int rc = st3r_arena_get(ctx, SLOT_KRANGE_PART, sizeof(uint32_t) * 2 * (size_t)grid.x, &p);
+        if (rc) return rc;
+        krange_part = (uint32_t*)p;
+    }
     hipLaunchKernelGGL(k_project_sh_fwd, grid, block, shmem, s, N, C, means, quats, scales, opacities, sh, sh_stride,
                        viewmats, Ks, campos, width, height, tile_size, tile_w, tile_h, eps2d, near_plane, far_plane,
                        radius_clip, (float4*)splats, tiles_per_gauss, reg_part, depth_keys, depth_vals, tight, key_base,
-                       rects, rect32);
+                       rects, rect32, krange_part);
     if (reg_sums)
         hipLaunchKernelGGL(k_reg_reduce, dim3(1), dim3(256), 0, s, (int)grid.x, reg_part, reg_sums, reg_overwrite, zero_ptr,
-                           zero_ptr ? zero_n : 0);
+                           zero_ptr ? zero_n : 0, (const uint32_t*)krange_part, krange);
     else if (zero_ptr && zero_n > 0)
         HIP_TRY(hipMemsetAsync(zero_ptr, 0, sizeof(double) * (size_t)zero_n, s));
     LAUNCH_CHECK();
@@ -278,5 +330,5 @@ ST3R_EXPORT int st3r_gs_project_sh(st3r_ctx* ctx, void* stream, int N, int C, co
     ARG_CHECK(means && quats && scales && opacities && sh && viewmats && Ks && campos && splats && tiles_per_gauss);
     return st3r_project_impl(ctx, (hipStream_t)stream, N, C, means, quats, scales, opacities, sh, sh_stride, viewmats, Ks,
                              campos, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, splats,
-                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0, 0u, nullptr, 0, 0, nullptr, 0);
+                             tiles_per_gauss, reg_sums, nullptr, nullptr, 0, 0u, nullptr, 0, 0, nullptr, 0, nullptr);
 }

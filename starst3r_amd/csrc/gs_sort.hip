@@ -26,6 +26,13 @@ int st3r_sort_depth32_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit,
     return st3r_radix_sort_u32(ctx, s, n, 0, end_bit, keys_in, vals_in, keys_out, vals_out);
 }
 
+// the same keys WITHOUT the camera bits, one segment of N pairs per camera, biased and sorted in as many 8-bit passes as the
+// depth range of the call needs (radix_sort.hip: SEG; krange from the projection's reduction)
+int st3r_sort_depth_seg_impl(st3r_ctx* ctx, hipStream_t s, int64_t N, int C, uint32_t* keys_in, int32_t* vals_in,
+                             uint32_t* keys_out, int32_t* vals_out, const uint32_t* krange) {
+    return st3r_radix_sort_u32_segments(ctx, s, N, C, keys_in, vals_in, keys_out, vals_out, krange);
+}
+
 // 32-bit (camera, tile) keys, stable: keeps the depth order established by the first level
 int st3r_sort_tile_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, uint32_t* keys_in, int32_t* vals_in,
                         uint32_t* keys_out, int32_t* vals_out, const int32_t* n_dev) {

@@ -111,14 +111,77 @@ __global__ __launch_bounds__(HIST_THREADS) void k_rs_hist(const K* __restrict__ 
     }
 }
 
-template <typename K, int THREADS, int IPT>
+// Segmented, biased variant of the histogram (level-1 sort of the fused training calls): segment g = blockIdx.y holds the
+// items [g seg_n, (g + 1) seg_n); a key is first mapped to key - krange[0] (the sentinel 0x1FFFFFFF of a culled pair to
+// krange[1]), and every segment gets its own histograms of the four digits.
+__device__ __forceinline__ uint32_t seg_key(uint32_t raw, uint32_t kmin, uint32_t ktop) {
+    return raw == 0x1FFFFFFFu ? ktop : raw - kmin;
+}
+__global__ __launch_bounds__(HIST_THREADS) void k_rs_hist_seg(const uint32_t* __restrict__ keys, int64_t seg_n,
+                                                              uint32_t* __restrict__ hist,
+                                                              const uint32_t* __restrict__ krange) {
+    __shared__ uint32_t sh[HIST_THREADS / 64][4 * RADIX];
+    const uint32_t kmin = krange[0], ktop = krange[1];
+    const int passes = (int)krange[2];
+    for (int i = threadIdx.x; i < (HIST_THREADS / 64) * 4 * RADIX; i += HIST_THREADS) (&sh[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t* mine = sh[threadIdx.x >> 6];
+    const uint32_t* kseg = keys + (int64_t)blockIdx.y * seg_n;
+    constexpr int CH = HIST_THREADS * HIST_ITEMS;
+    for (int64_t base = (int64_t)blockIdx.x * CH; base < seg_n; base += (int64_t)gridDim.x * CH) {
+        uint32_t k[HIST_ITEMS];
+#pragma unroll
+        for (int i = 0; i < HIST_ITEMS; ++i) {
+            const int64_t idx = base + i * HIST_THREADS + threadIdx.x;
+            k[i] = idx < seg_n ? kseg[idx] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < HIST_ITEMS; ++i) {
+            if (base + i * HIST_THREADS + threadIdx.x < seg_n) {
+                const uint32_t kk = seg_key(k[i], kmin, ktop);
+                for (int p = 0; p < passes; ++p) atomicAdd(&mine[p * RADIX + ((kk >> (RB * p)) & (RADIX - 1))], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < HIST_THREADS / 64; ++w) t += sh[w][i];
+        if (t) atomicAdd(&hist[blockIdx.y * (MAX_PASSES * RADIX) + i], t);
+    }
+}
+
+// SEG (level-1 sort of the fused training calls; K = uint32_t): the input is n_seg segments of seg_n items (one per camera),
+// each sorted on its own -- tile t serves segment t / tiles_per_seg, the chained scan restarts at a segment's first tile --,
+// the keys are biased on the way in (pass 0: seg_key), and the NUMBER of passes is read from device memory (krange[2], set
+// by the projection's reduction from the depth range it saw: three when the biased keys stay below 2^24, else four): launch
+// `ps` returns at once when ps >= passes, and source / destination of a pass follow from the pass count so that the last
+// pass that runs writes kout / vout (kin = the caller's input, ktmp / vtmp = scratch).
+template <typename K, int THREADS, int IPT, bool SEG = false>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, const int32_t* __restrict__ vin,
                                                      K* __restrict__ kout, int32_t* __restrict__ vout, int64_t n,
                                                      int shift, int bits, const uint32_t* __restrict__ hist_base,
                                                      u64* status, uint32_t* tile_counter,
-                                                     const int32_t* __restrict__ n_dev) {
+                                                     const int32_t* __restrict__ n_dev, int64_t seg_n = 0,
+                                                     int tiles_per_seg = 0, const uint32_t* __restrict__ krange = nullptr,
+                                                     int ps = 0, K* __restrict__ ktmp = nullptr,
+                                                     int32_t* __restrict__ vtmp = nullptr) {
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));   // count on the device, grid sized for the capacity `n`
     constexpr int TILE = THREADS * IPT, WAVES = THREADS / 64;
+    uint32_t kmin = 0, ktop = 0;
+    if constexpr (SEG) {
+        const int np = (int)krange[2];
+        if (ps >= np) return;                                   // (uniform over the launch)
+        const bool to_out = ((np - 1 - ps) & 1) == 0;           // the last pass that runs writes the caller's output
+        const K* src_k = ps == 0 ? kin : (to_out ? ktmp : kout);
+        const int32_t* src_v = ps == 0 ? vin : (to_out ? vtmp : vout);
+        K* dst_k = to_out ? kout : ktmp;
+        int32_t* dst_v = to_out ? vout : vtmp;
+        kin = src_k; vin = src_v; kout = dst_k; vout = dst_v;
+        kmin = krange[0]; ktop = krange[1];
+        shift = RB * ps; bits = RB;
+    }
     __shared__ K sbuf[TILE];
     __shared__ int32_t svals[TILE];   // values regroup together with the keys: one trip through LDS, one store phase
     __shared__ uint32_t whist[WAVES][RADIX];
@@ -134,9 +197,22 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     for (int i = tid; i < WAVES * RADIX; i += THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    if ((int64_t)tile * TILE >= n) return;   // (capacity launch) a ticket past the last tile: uniform over the workgroup
-    const int64_t tbase = (int64_t)tile * TILE;
-    const int tcount = (int)min((int64_t)TILE, n - tbase);
+    uint32_t first_tile = 0;      // first tile of this tile's chain (SEG: of its segment)
+    int64_t tbase, seg_base = 0;
+    int tcount;
+    if constexpr (SEG) {
+        const uint32_t sg = tile / (uint32_t)tiles_per_seg;
+        first_tile = sg * (uint32_t)tiles_per_seg;
+        seg_base = (int64_t)sg * seg_n;
+        const int64_t in_seg = (int64_t)(tile - first_tile) * TILE;
+        tbase = seg_base + in_seg;
+        tcount = (int)min((int64_t)TILE, seg_n - in_seg);
+        hist_base += (size_t)sg * (MAX_PASSES * RADIX);
+    } else {
+        if ((int64_t)tile * TILE >= n) return;   // (capacity launch) a ticket past the last tile: uniform over the workgroup
+        tbase = (int64_t)tile * TILE;
+        tcount = (int)min((int64_t)TILE, n - tbase);
+    }
     const uint32_t dmask = (1u << bits) - 1u;
     const int wbase = w * 64 * IPT + lane;
 
@@ -147,6 +223,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     for (int i = 0; i < IPT; ++i) {
         const int li = wbase + i * 64;
         key[i] = li < tcount ? kin[tbase + li] : K(0);
+        if constexpr (SEG) { if (ps == 0) key[i] = (K)seg_key((uint32_t)key[i], kmin, ktop); }
     }
     // this pass's global digit counts (the HIST_COPIES partial histograms of k_rs_hist; in flight while the keys are ranked).
     // Their exclusive scan -- the global base of every bin -- is taken by every workgroup for itself further down, next to
@@ -154,8 +231,11 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     // first pass: 4.6 us twice per step).
     uint32_t hv = 0;
     if (tid < RADIX) {
+        if constexpr (SEG) hv = hist_base[tid];   // (one histogram per segment)
+        else {
 #pragma unroll
-        for (int c = 0; c < HIST_COPIES; ++c) hv += hist_base[c * (MAX_PASSES * RADIX) + tid];
+            for (int c = 0; c < HIST_COPIES; ++c) hv += hist_base[c * (MAX_PASSES * RADIX) + tid];
+        }
     }
     if (vin) {   // in flight while the keys are ranked
 #pragma unroll
@@ -193,7 +273,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
             whist[ww][tid] = cnt;
             cnt += c;
         }
-        if (tile != 0)
+        if (tile != first_tile)
             __hip_atomic_store(status + (size_t)tile * RADIX + tid, FLAG_AGG | (u64)cnt, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         tcnt[tid] = cnt;
@@ -220,12 +300,12 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
         static_assert(LB == 4 || LB == 2, "the look-back group is a DPP quad or pair");
         const int d = tid / LB, j = tid % LB;
         u64 excl = 0;
-        if (tile != 0) {
+        if (tile != first_tile) {
             bool done = false;
             for (int64_t t0 = (int64_t)tile - 1; !done; t0 -= LB) {
                 const int64_t t = t0 - j;
                 u64 v = FLAG_INC;   // before the first tile: an inclusive prefix of zero
-                if (t >= 0) {
+                if (t >= (int64_t)first_tile) {
                     const u64* pt = status + (size_t)t * RADIX + d;
                     v = __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     unsigned spins = 0;
@@ -253,7 +333,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
         }
     }
     __syncthreads();
-    if (tid < RADIX) gofs[tid] = (long long)((u64)hexc + gexc[tid]) - (long long)lbase[tid];
+    if (tid < RADIX) gofs[tid] = (long long)((u64)hexc + gexc[tid]) - (long long)lbase[tid] + seg_base;
     __syncthreads();
 
     // regroup by digit in LDS, then leave in runs that are contiguous in the destination
@@ -336,7 +416,57 @@ int sort_pairs(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_b
     return ST3R_OK;
 }
 
+// n_seg segments of seg_n (key, value) pairs each, every segment sorted on its own by seg_key(key) (see k_rs_pass<.., SEG>);
+// krange (device): bias, sentinel key and pass count
+int sort_pairs_seg(st3r_ctx* ctx, hipStream_t s, int64_t seg_n, int n_seg, const uint32_t* keys_in, const int32_t* vals_in,
+                   uint32_t* keys_out, int32_t* vals_out, const uint32_t* krange) {
+    if (seg_n == 0 || n_seg == 0) return ST3R_OK;
+    typedef uint32_t K;
+    constexpr int PASSES = 4;   // launches; the passes that run: krange[2]
+    constexpr int TILE_L = THREADS_L * Traits<K>::IPT, TILE_S = THREADS_S * Traits<K>::IPT_S;
+    const int64_t n = seg_n * n_seg;
+    const bool small = (n + TILE_L - 1) / TILE_L < RS_SMALL_BELOW;
+    const int64_t TILE = small ? TILE_S : TILE_L;
+    const int tiles_per_seg = (int)((seg_n + TILE - 1) / TILE);
+    const int64_t ntiles = (int64_t)tiles_per_seg * n_seg;
+    const size_t hist_bytes = align256(sizeof(uint32_t) * ((size_t)n_seg * MAX_PASSES * RADIX + MAX_PASSES));
+    const size_t status_bytes = sizeof(u64) * (size_t)PASSES * (size_t)ntiles * RADIX;
+    const size_t meta_bytes = hist_bytes + align256(status_bytes);
+    const size_t tk_bytes = align256(sizeof(K) * (size_t)n), tv_bytes = align256(sizeof(int32_t) * (size_t)n);
+    void* p;
+    int rc = st3r_arena_get(ctx, SLOT_SORT_TMP, meta_bytes + tk_bytes + tv_bytes, &p);
+    if (rc) return rc;
+    char* base = (char*)p;
+    uint32_t* hist = (uint32_t*)base;
+    uint32_t* counters = hist + (size_t)n_seg * MAX_PASSES * RADIX;
+    u64* status = (u64*)(base + hist_bytes);
+    K* tk = (K*)(base + meta_bytes);
+    int32_t* tv = (int32_t*)(base + meta_bytes + tk_bytes);
+    HIP_TRY(hipMemsetAsync(base, 0, meta_bytes, s));
+    const int hist_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(1024 / n_seg, (seg_n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS)));
+    hipLaunchKernelGGL(k_rs_hist_seg, dim3(hist_blocks, n_seg), dim3(HIST_THREADS), 0, s, keys_in, seg_n, hist, krange);
+    for (int ps = 0; ps < PASSES; ++ps) {
+        if (small)
+            hipLaunchKernelGGL((k_rs_pass<K, THREADS_S, Traits<K>::IPT_S, true>), dim3((unsigned)ntiles), dim3(THREADS_S), 0, s,
+                               keys_in, vals_in, keys_out, vals_out, n, 0, RB, hist + ps * RADIX,
+                               status + (size_t)ps * ntiles * RADIX, counters + ps, (const int32_t*)nullptr, seg_n,
+                               tiles_per_seg, krange, ps, tk, tv);
+        else
+            hipLaunchKernelGGL((k_rs_pass<K, THREADS_L, Traits<K>::IPT, true>), dim3((unsigned)ntiles), dim3(THREADS_L), 0, s,
+                               keys_in, vals_in, keys_out, vals_out, n, 0, RB, hist + ps * RADIX,
+                               status + (size_t)ps * ntiles * RADIX, counters + ps, (const int32_t*)nullptr, seg_n,
+                               tiles_per_seg, krange, ps, tk, tv);
+    }
+    LAUNCH_CHECK();
+    return ST3R_OK;
+}
+
 }  // namespace
+
+int st3r_radix_sort_u32_segments(st3r_ctx* ctx, hipStream_t s, int64_t seg_n, int n_seg, const uint32_t* keys_in,
+                                 const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out, const uint32_t* krange) {
+    return sort_pairs_seg(ctx, s, seg_n, n_seg, keys_in, vals_in, keys_out, vals_out, krange);
+}
 
 int st3r_radix_sort_u32(st3r_ctx* ctx, hipStream_t s, int64_t n, int begin_bit, int end_bit, const uint32_t* keys_in,
                         const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out) {
