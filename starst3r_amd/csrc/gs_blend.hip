@@ -408,7 +408,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
         const uint64_t m_cur = m_next;
         if (hb > 0) m_next = wmask[hb - 1];
         if (bsz <= 0) continue;   // the tail of the last forward batch may be empty (uniform over the workgroup)
-        __syncthreads();
+        // (no barrier here -- round 6: the staging arrays are free once every wave is past the walk of the previous round,
+        // which the barrier in front of the flush established, and the staging wave is the one that flushed; the waves' own
+        // accumulator rows are next written after the barrier below.  Two workgroup barriers per round instead of three.)
         // ---- staging: one record per thread (threads 0..HB-1).  A record some wave contributed to also fixes its
         // output slot now, so that the flush below is loads-free:  u = cum_excl[pid] + index of this tile inside the
         // record's tile rectangle (same float ops as the emit kernel => same integers)

@@ -55,6 +55,27 @@ def test_one_view_of_synth_1m_against_the_c_oracle(synth_1m_view):
     assert np.abs(rgb.cpu().numpy()[~ok] - rgb_o[~ok]).max() <= 5e-3
 
 
+def test_training_record_list_of_one_view_of_synth_1m_is_the_oracle_list_minus_dead_pairs(synth_1m_view):
+    """The fused TRAINING path's record list at full size (the path the headline number times) against the C oracle's sorted
+    list: equal, order included, once the pairs the exact culling drops are removed; every dropped pair (a 300 000 sample of
+    them) fails the alpha test on all 256 pixels of its tile; tile offsets follow (tests/test_gpu_gs.py:
+    _kept_list_against_oracle)."""
+    from starst3r_amd import ops
+    from test_gpu_gs import _kept_list_against_oracle
+    N, W, H = 1_000_000, 1920, 1080
+    g, w2c, Ks, rgb_o, alpha_o, meta = synth_1m_view
+    ctx = ops.Context(DEV)
+    P = {k: _dev(v) for k, v in g.items()}
+    vm, K = _dev(w2c), _dev(Ks)
+    gt = _dev(np.clip(rgb_o, 0, 1))
+    grads = torch.empty(23 * N, device=DEV); loss = torch.zeros(1, device=DEV)
+    st = ops.train_fwd_bwd(ctx, P, vm, K, ops.camera_positions(vm), gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+    torch.cuda.synchronize()
+    assert st["n_isects_ref"] == meta["isect_ids"].size
+    n_ref, n_drop = _kept_list_against_oracle(ctx, g, w2c, Ks, W, H, meta, st["n_isects"], max_dropped=300_000)
+    assert n_ref - n_drop == st["n_isects"] and 0.2 * n_ref < n_drop < 0.5 * n_ref   # (SYNTH-1M: 35 % of the pairs are dead)
+
+
 def test_backward_of_one_view_of_synth_1m_against_the_c_oracle(synth_1m_view):
     """VERDICT r3 'What's weak' 1(i): backward parity against the C oracle stopped at 20 000 Gaussians.  Here: the same
     full-size view (1 M Gaussians, 1920x1080, ~3.4 M intersections, every covered pixel ~36 Gaussians deep) through

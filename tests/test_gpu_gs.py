@@ -130,6 +130,74 @@ def test_fused_two_level_sort_matches_reference_order(ctx, name):
     np.testing.assert_allclose(rgb.cpu().numpy()[ok], rgb_o[ok], rtol=1e-4, atol=1e-5)
 
 
+def _kept_list_against_oracle(ctx, g, w2c, Ks, W, H, meta, n_kept, max_dropped=2_000_000):
+    """The TRAINING path's record list (exact culling: a (record, tile) pair is kept only if the box of {alpha >= 1/255}
+    reaches the tile's pixel centres) against the oracle's sorted list (gsplat's 3-sigma squares):
+      * kept list == the oracle's list with the dropped (record, tile) pairs removed, ORDER INCLUDED (north_star: tile / sort
+        indices bit-exact);
+      * tile offsets == the run boundaries of that filtered list;
+      * every dropped pair fails the alpha test on all 256 pixels of its tile (float64 evaluation of the oracle's formula).
+    Returns (#oracle pairs, #dropped)."""
+    from starst3r_amd import ops
+    N, Cn = g["means"].shape[0], w2c.shape[0]
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    n_tiles = tw * th
+    kept_pid = ops.peek(ctx, 0, n_kept).cpu().numpy().astype(np.int64)
+    off = ops.peek(ctx, 1, Cn * n_tiles + 1).cpu().numpy().astype(np.int64)
+    assert off[-1] == n_kept and np.all(np.diff(off) >= 0)
+    kept_tile = np.repeat(np.arange(Cn * n_tiles, dtype=np.int64), np.diff(off))        # camera * tiles + tile
+    # the oracle's sorted list: key = cam << (32 + tile_bits) | tile << 32 | depth bits, value = PACKED index
+    tile_bits = int(n_tiles).bit_length()
+    keys = meta["isect_ids"].astype(np.int64)
+    o_tile = ((keys >> 32) & ((1 << tile_bits) - 1)) + (keys >> (32 + tile_bits)) * n_tiles
+    packed = meta["flatten_ids"].astype(np.int64)
+    o_pid = meta["camera_ids"].astype(np.int64)[packed] * N + meta["gaussian_ids"].astype(np.int64)[packed]
+    code = lambda tile, pid: tile * (N * Cn) + pid                                        # one integer per (tile, pair)
+    kept_code, o_code = code(kept_tile, kept_pid), code(o_tile, o_pid)
+    keep = np.isin(o_code, kept_code)
+    assert keep.sum() == n_kept, "a kept pair that the reference algorithm does not have"
+    assert np.array_equal(o_code[keep], kept_code), "the kept list is not the oracle's list minus the dropped pairs"
+    # dropped pairs: alpha < 1/255 on every pixel centre of the tile
+    d_tile, d_packed = o_tile[~keep], packed[~keep]
+    if d_tile.size > max_dropped:
+        sel = np.random.default_rng(0).choice(d_tile.size, max_dropped, replace=False)
+        d_tile, d_packed = d_tile[sel], d_packed[sel]
+    t = d_tile % n_tiles
+    px0 = (t % tw) * 16 + 0.5; py0 = (t // tw) * 16 + 0.5
+    m2 = meta["means2d"].astype(np.float64)[d_packed]; con = meta["conics"].astype(np.float64)[d_packed]
+    opac = meta["opacities"].astype(np.float64)[d_packed]
+    worst = 0.0
+    for s0 in range(0, d_tile.size, 50_000):
+        sl = slice(s0, s0 + 50_000)
+        dx = m2[sl, 0, None, None] - (px0[sl, None, None] + np.arange(16)[None, None, :])
+        dy = m2[sl, 1, None, None] - (py0[sl, None, None] + np.arange(16)[None, :, None])
+        sigma = 0.5 * (con[sl, 0, None, None] * dx * dx + con[sl, 2, None, None] * dy * dy) + con[sl, 1, None, None] * dx * dy
+        alpha = np.minimum(0.999, opac[sl, None, None] * np.exp(-sigma))
+        alpha[sigma < 0] = 0.0                                                            # gsplat skips sigma < 0
+        worst = max(worst, float(alpha.max()) if alpha.size else 0.0)
+    assert worst < 1.0 / 255.0, worst
+    return o_code.size, int((~keep).sum())
+
+
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "many"] + FUZZ)
+def test_fused_training_list_is_the_oracle_list_minus_dead_pairs(ctx, name):
+    """the timed (fused training) path's record list was only ever compared with the oracle indirectly (same
+    images, gradients close to the staged path's).  Directly: see _kept_list_against_oracle."""
+    from starst3r_amd import ops
+    g, w2c, Ks, W, H = make(name)
+    N, Cn = g["means"].shape[0], w2c.shape[0]
+    rgb_o, _, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H)
+    P = {k: dev(v) for k, v in g.items()}
+    vm, K = dev(w2c), dev(Ks)
+    gt = dev(np.clip(rgb_o, 0, 1))
+    grads = torch.empty(23 * N, device="cuda:0"); loss = torch.zeros(1, device="cuda:0")
+    st = ops.train_fwd_bwd(ctx, P, vm, K, ops.camera_positions(vm), gt, W, H, 0.2, 0.01, 0.01, grads, loss)
+    torch.cuda.synchronize()
+    assert st["n_isects_ref"] == meta["isect_ids"].size
+    n_ref, n_drop = _kept_list_against_oracle(ctx, g, w2c, Ks, W, H, meta, st["n_isects"])
+    assert n_ref - n_drop == st["n_isects"]
+
+
 @pytest.mark.parametrize("name", ["small", "ragged", "medium"] + FUZZ)
 def test_blend_forward(ctx, name):
     g, w2c, Ks, W, H = make(name)
