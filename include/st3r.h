@@ -388,8 +388,17 @@ int st3r_mcmc_noise_rows(st3r_ctx* ctx, void* stream, int n, int64_t row_offset,
  *                            bit-identical by construction), runs Adam on the piece, and READS the other pieces of
  *                            the updated parameters from their owners; two device-side barriers per step over the
  *                            exported flags (bounded: a peer that never arrives is a failed step, not a hang), the
- *                            step's status word travels with them.  Moments as under RS_AG.  st3r_comm_destroy is
- *                            COLLECTIVE once this form has been used (nobody may unmap a buffer a peer still reads).
+ *                            step's status word travels with BOTH of them.  A barrier that times out is FATAL for the
+ *                            communicator: the rank that saw it skips what follows the barrier, every later training
+ *                            call on it returns ST3R_ERR_PEER without exchanging anything (the peers then time out in
+ *                            their next barrier and end the same way), and the replicas may differ by that one step --
+ *                            tear the communicator down and restore the parameters.  The flags live in uncached
+ *                            device memory exported over HIP IPC; where that cannot be had the form is refused
+ *                            (ST3R_ERR_HIP from the first step).  EXPERIMENTAL: exercised between processes that share
+ *                            one device only (tests/test_gpu_multi.py), never yet across two devices.  Moments as under
+ *                            RS_AG.  st3r_comm_destroy is COLLECTIVE once this form has been used (nobody may unmap a
+ *                            buffer a peer still reads; the wait for the peers is bounded by ST3R_XBAR_TIMEOUT_MS --
+ *                            past it the window is leaked instead of unmapped).
  * A communicator starts with the form the environment variable ST3R_EXCHANGE names (allreduce | ranges | rs_ag | direct; read once,
  * when the communicator is created or attached; never written by the library), else with the all-reduce.  All ranks must
  * use the same form.

@@ -49,6 +49,9 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <thread>
+
 #include "common.h"
 
 namespace {
@@ -172,7 +175,7 @@ ST3R_EXPORT int st3r_comm_destroy(st3r_ctx* ctx) {
     RcclApi* api = rccl_api();
     if (ctx->xwin) xwin_destroy(ctx, api);   // (collective: see st3r.h)
     if (api && ctx->comm_owned) (void)api->comm_destroy((ncclComm_t)ctx->comm);
-    ctx->comm = nullptr; ctx->comm_owned = 0; ctx->comm_size = 0; ctx->comm_rank = 0;
+    ctx->comm = nullptr; ctx->comm_owned = 0; ctx->comm_size = 0; ctx->comm_rank = 0; ctx->comm_broken = 0;
     ctx->peer_pending = 0;   // nobody is left to repeat a failed step with: a later single-process call must not report it
     return ST3R_OK;
 }
@@ -248,7 +251,18 @@ int st3r_peer_status_settle(st3r_ctx* ctx) {
     if (!ctx->peer_pending) return ST3R_OK;
     HIP_TRY(hipEventSynchronize(ctx->peer_event));
     ctx->peer_pending = 0;
-    if (((volatile int32_t*)(ctx->pinned + PEER_PINNED))[0] != 0) {
+    const int32_t word = ((volatile int32_t*)(ctx->pinned + PEER_PINNED))[0];
+    if (word & 2) {
+        // a device-side barrier of the direct form gave up on a peer: the ranks are no longer in lockstep (this rank may
+        // have applied a step a peer did not, or hold parameter pieces the peer never delivered) -- nothing further is
+        // exchanged over this communicator
+        ctx->comm_broken = 1;
+        st3r_set_error("direct exchange: a peer did not arrive at a device-side barrier within the time-out "
+                       "(ST3R_XBAR_TIMEOUT_MS): the ranks are out of lockstep and the replicas may differ by one step -- "
+                       "this communicator is finished (st3r_comm_destroy, restore the parameters, attach a new one)");
+        return ST3R_ERR_PEER;
+    }
+    if (word != 0) {
         st3r_set_error("the previous training step failed on a rank of the communicator: no rank applied its "
                        "update (replicas are unchanged and identical; every rank gets this code and repeats the step) "
                        "-- see the failing rank's own error");
@@ -289,13 +303,29 @@ static void xwin_destroy(st3r_ctx* ctx, RcclApi* api) {
     ctx->xwin = nullptr;
     (void)hipDeviceSynchronize();
     int32_t* word = nullptr;
+    bool peers_done = true;
     if (api && x->w > 1 && hipMalloc((void**)&word, sizeof(int32_t)) == hipSuccess) {
         (void)hipMemset(word, 0, sizeof(int32_t));
         (void)api->all_reduce(word, word, 1, ncclInt32, ncclMax, (ncclComm_t)ctx->comm, nullptr);
-        (void)hipStreamSynchronize(nullptr);
-        (void)hipFree(word);
+        // bounded: a peer that crashed or tears down in another order must not hang this rank's destructor
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, nullptr) == hipSuccess) {
+            const char* te = getenv("ST3R_XBAR_TIMEOUT_MS");
+            const double limit_s = (te ? atof(te) : 20000.0) * 1e-3;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (hipEventQuery(ev) == hipErrorNotReady) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) { peers_done = false; break; }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        } else {
+            (void)hipStreamSynchronize(nullptr);
+        }
+        if (ev && peers_done) (void)hipEventDestroy(ev);
+        if (peers_done) (void)hipFree(word);
     }
-    xwin_free_local(x);
+    // peers that did not answer may still be reading this rank's buffers: the window is then LEAKED rather than unmapped
+    // under them (the process is on its way out or the communicator is broken anyway)
+    if (peers_done) xwin_free_local(x);
 }
 
 // (Re)builds the window for `total` floats per buffer.  COLLECTIVE: all ranks call it in the same step (they hold the
@@ -323,13 +353,17 @@ static int xwin_ensure(st3r_ctx* ctx, RcclApi* api, hipStream_t s, int64_t total
     } while (0)
     XW_TRY(hipMalloc((void**)&x->grad, sizeof(float) * x->cap));
     XW_TRY(hipMalloc((void**)&x->param, sizeof(float) * x->cap));
-    // the flags are written by peers while this rank's kernel polls them: uncached (fine-grained) memory where the
-    // runtime exports it, ordinary device memory + system-scope atomics otherwise
+    // The flags are written by peers while this rank's kernel polls them: they MUST live in uncached (fine-grained) memory
+    // that the runtime can export.  Ordinary device memory is cached in this device's L2 as non-coherent lines, a
+    // system-scope load is not guaranteed to miss there, and a poll could spin on a stale line until the time-out: where
+    // such memory cannot be had or exported the form is refused -- the caller stays on an RCCL form.
     x->flag_uncached = 1;
     if (hipExtMallocWithFlags((void**)&x->flag, sizeof(unsigned long long) * XW_MAX_RANKS, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
-        x->flag_uncached = 0;
-        XW_TRY(hipMalloc((void**)&x->flag, sizeof(unsigned long long) * XW_MAX_RANKS));
+        st3r_set_error("direct exchange: no uncached device memory for the barrier flags (hipExtMallocWithFlags "
+                       "hipDeviceMallocUncached failed): use ST3R_EXCHANGE=allreduce | ranges | rs_ag");
+        xwin_free_local(x);
+        return ST3R_ERR_HIP;
     }
     XW_TRY(hipMemset(x->flag, 0, sizeof(unsigned long long) * XW_MAX_RANKS));
     XHandles mine;
@@ -337,12 +371,12 @@ static int xwin_ensure(st3r_ctx* ctx, RcclApi* api, hipStream_t s, int64_t total
     if (x->w > 1) {
         XW_TRY(hipIpcGetMemHandle(&mine.h[0], x->grad));
         XW_TRY(hipIpcGetMemHandle(&mine.h[1], x->param));
-        if (hipIpcGetMemHandle(&mine.h[2], x->flag) != hipSuccess && x->flag_uncached) {   // not exportable: plain memory
+        if (hipIpcGetMemHandle(&mine.h[2], x->flag) != hipSuccess) {
             (void)hipGetLastError();
-            (void)hipFree(x->flag); x->flag = nullptr; x->flag_uncached = 0;
-            XW_TRY(hipMalloc((void**)&x->flag, sizeof(unsigned long long) * XW_MAX_RANKS));
-            XW_TRY(hipMemset(x->flag, 0, sizeof(unsigned long long) * XW_MAX_RANKS));
-            XW_TRY(hipIpcGetMemHandle(&mine.h[2], x->flag));
+            st3r_set_error("direct exchange: the uncached barrier flags cannot be exported over HIP IPC on this system: "
+                           "use ST3R_EXCHANGE=allreduce | ranges | rs_ag");
+            xwin_free_local(x);
+            return ST3R_ERR_HIP;
         }
     }
     x->peer[0][x->r] = x->grad; x->peer[1][x->r] = x->param; x->peer[2][x->r] = x->flag;
@@ -350,7 +384,8 @@ static int xwin_ensure(st3r_ctx* ctx, RcclApi* api, hipStream_t s, int64_t total
         static_assert(sizeof(XHandles) % 4 == 0, "handles travel as int32 words");
         char* hb = nullptr;
         XW_TRY(hipMalloc((void**)&hb, sizeof(XHandles) * x->w));
-        XW_TRY(hipMemcpy(hb + sizeof(XHandles) * x->r, &mine, sizeof(XHandles), hipMemcpyHostToDevice));
+#define XW_TRY_HB(expr) do { hipError_t _e2 = (expr); if (_e2 != hipSuccess) { (void)hipFree(hb); XW_TRY(_e2); } } while (0)
+        XW_TRY_HB(hipMemcpy(hb + sizeof(XHandles) * x->r, &mine, sizeof(XHandles), hipMemcpyHostToDevice));
         ncclResult_t nr = api->all_gather(hb + sizeof(XHandles) * x->r, hb, sizeof(XHandles) / 4, ncclInt32,
                                           (ncclComm_t)ctx->comm, s);
         if (nr != ncclSuccess) {
@@ -359,8 +394,9 @@ static int xwin_ensure(st3r_ctx* ctx, RcclApi* api, hipStream_t s, int64_t total
             return ST3R_ERR_HIP;
         }
         std::vector<XHandles> all(x->w);
-        XW_TRY(hipMemcpyAsync(all.data(), hb, sizeof(XHandles) * x->w, hipMemcpyDeviceToHost, s));
-        XW_TRY(hipStreamSynchronize(s));
+        XW_TRY_HB(hipMemcpyAsync(all.data(), hb, sizeof(XHandles) * x->w, hipMemcpyDeviceToHost, s));
+        XW_TRY_HB(hipStreamSynchronize(s));
+#undef XW_TRY_HB
         (void)hipFree(hb);
         for (int p = 0; p < x->w; ++p) {
             if (p == x->r) continue;
@@ -382,7 +418,7 @@ static int xwin_ensure(st3r_ctx* ctx, RcclApi* api, hipStream_t s, int64_t total
 // status_out (first barrier of a step only): the OR over the ranks -- the same word the other forms max-all-reduce.
 __global__ __launch_bounds__(XW_MAX_RANKS) void k_xbar(unsigned long long* const* __restrict__ flag_tab, int w, int r,
                                                        unsigned long long gen, int my_fail, long long timeout_ticks,
-                                                       int32_t* __restrict__ status_out) {
+                                                       int32_t* __restrict__ status_out, int accumulate) {
     __shared__ int s_any;
     const int p = threadIdx.x;
     if (p == 0) s_any = my_fail ? 1 : 0;
@@ -400,7 +436,9 @@ __global__ __launch_bounds__(XW_MAX_RANKS) void k_xbar(unsigned long long* const
         if (v & 3ull) atomicOr(&s_any, (int)(v & 3ull));
     }
     __syncthreads();
-    if (p == 0 && status_out) *status_out = s_any;
+    // (second barrier of a step: ORed into the step's word, so that what follows it -- the parameter pieces read from the
+    // peers -- and the host's read-back see a time-out of THIS barrier as well)
+    if (p == 0 && status_out) *status_out = accumulate ? (*status_out | s_any) : s_any;
     __threadfence_system();
 }
 
@@ -454,6 +492,11 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     int rc = st3r_peer_status_settle(ctx);   // did the previous step fail somewhere else?
     if (rc) return rc;
+    if (ctx->comm_broken) {
+        st3r_set_error("this communicator lost lockstep in an earlier step (a device-side barrier timed out): no further "
+                       "step is exchanged over it");
+        return ST3R_ERR_PEER;
+    }
     const int mode = ctx->exchange;
     int32_t* counts = nullptr;
     // (failures from here to the collectives below are failures of the machinery the protocol itself needs: they are
@@ -509,7 +552,7 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
     if (xw) {   // direct form: the first barrier of the step carries the status word
         ++xw->gen;
         hipLaunchKernelGGL(k_xbar, dim3(1), dim3(XW_MAX_RANKS), 0, s, (unsigned long long* const*)(xw->dev_tab + 2 * XW_MAX_RANKS),
-                           xw->w, xw->r, xw->gen, rc_local ? 1 : 0, xw->timeout_ticks, counts + PEER_WORD);
+                           xw->w, xw->r, xw->gen, rc_local ? 1 : 0, xw->timeout_ticks, counts + PEER_WORD, 0);
         SOFT_HIP(hipGetLastError());
     } else {
         SOFT_HIP(hipMemsetAsync(counts + PEER_WORD, rc_local ? 1 : 0, sizeof(int32_t), s));
@@ -600,8 +643,12 @@ ST3R_EXPORT int st3r_gs_train_step(st3r_ctx* ctx, void* stream, int N, int C, fl
         st3r_prof_end(ctx, s, STG_ADAM);
         ++xw->gen;
         hipLaunchKernelGGL(k_xbar, dim3(1), dim3(XW_MAX_RANKS), 0, s, (unsigned long long* const*)(xw->dev_tab + 2 * XW_MAX_RANKS),
-                           w, r, xw->gen, rc_local ? 1 : 0, xw->timeout_ticks, (int32_t*)nullptr);
+                           w, r, xw->gen, rc_local ? 1 : 0, xw->timeout_ticks, counts + PEER_WORD, 1);
         SOFT_HIP(hipGetLastError());
+        // the word once more for the host, now with the second barrier in it (the event's last record is what the next
+        // call waits for)
+        SOFT_HIP(hipMemcpyAsync((int32_t*)(ctx->pinned + PEER_PINNED), counts + PEER_WORD, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SOFT_HIP(hipEventRecord(ctx->peer_event, s));
         if (!rc)
             rc = st3r_params_from_peers_impl(s, N, means, quats, scales, opacities, sh, sh_stride,
                                              (const float* const*)(xw->dev_tab + XW_MAX_RANKS), r, q, tail0, status);

@@ -127,6 +127,7 @@ struct st3r_ctx {
     void* comm;     // ncclComm_t of the view-sharded job (NULL: single replica)
     int comm_owned, comm_rank, comm_size;
     int exchange;   // ST3R_EXCHANGE_*: the form the gradient exchange of st3r_gs_train_step takes (comm.hip)
+    int comm_broken;         // a device-side barrier of the direct form timed out: the ranks lost lockstep (comm.hip)
     int peer_pending;        // the status word of the last exchanged step is still to be looked at (comm.hip)
     hipEvent_t peer_event;
     // range-wise exchange (comm.hip): the projection backward runs once per Gaussian range and leaves an event per

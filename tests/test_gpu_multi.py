@@ -175,6 +175,59 @@ def test_exchanged_step_equals_single_gpu_step(tmp_path, exchange):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def _real_pair_worker(rank, world, port, steps):
+    """Two ranks on two DIFFERENT devices (RCCL, real HIP-IPC peer mappings): `steps` training steps under the plain
+    all-reduce and under the `direct` form (own reduce-scatter / all-gather over the peers' exported buffers) from the same
+    start.  With two ranks both forms add the same two floats per element (a + b = b + a), so the parameters must agree BIT
+    FOR BIT -- between the forms and between the ranks.  A `direct` form that reads stale peer data, loses a barrier or
+    maps the wrong buffer shows here as a difference, not as a slow step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device(f"cuda:{rank}")
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from starst3r_amd import dist as sdist, ops
+    ctx = ops.get_context(dev)
+    g, w2c, Ks, V = _scene(world)
+    gt = _gt(ctx, g, w2c, Ks, dev)
+    views = sdist.shard_views(V, rank, world)
+    vm, K = torch.from_numpy(w2c).to(dev)[views].contiguous(), torch.from_numpy(Ks).to(dev)[views].contiguous()
+    campos, gtv = ops.camera_positions(vm), gt[views].contiguous()
+    assert sdist.attach_native_comm(ctx) == (rank, world)
+    res = {}
+    for form in ("allreduce", "direct", "allreduce"):          # (the third run: the window's tear-down left nothing behind)
+        ops.set_exchange(ctx, form)
+        P = {k: torch.from_numpy(g[k]).to(dev) for k in ("means", "quats", "scales", "opacities", "shN")}
+        grads = torch.empty(23 * N, device=dev); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+        loss = torch.zeros(steps, device=dev)
+        for it in range(steps):
+            ops.train_step(ctx, P, vm, K, campos, gtv, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1,
+                           loss[it:it + 1])
+        ops.settle(ctx)
+        torch.cuda.synchronize()
+        for name, t in P.items():
+            ref = t.detach().clone()
+            torch.distributed.broadcast(ref, src=0)
+            assert torch.equal(ref, t), (form, name, rank)                         # replicas identical
+            if form in res:
+                assert torch.equal(res[form][name], t), (form, name, "repeat")
+        res.setdefault(form, {k: t.clone() for k, t in P.items()})
+        res[form + "_loss"] = loss.clone()
+    for name in res["allreduce"]:
+        assert torch.equal(res["allreduce"][name].view(torch.int32), res["direct"][name].view(torch.int32)), (name, rank)
+    assert torch.equal(res["allreduce_loss"], res["direct_loss"])
+    ops.set_exchange(ctx, "allreduce")
+    sdist.detach_native_comm(ctx)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(N_GPUS < 2, reason="needs two real devices (the round-end 8-GPU node): RCCL + HIP IPC across devices")
+def test_direct_exchange_on_two_real_devices_equals_the_allreduce_bit_for_bit():
+    """skipped on a one-GPU box, runs unmodified where torch.cuda.device_count() >= 2."""
+    mp.spawn(_real_pair_worker, args=(2, _free_port(), 3), nprocs=2, join=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def _scene_worker(rank, world, port, out, iters):
     _init(rank, world, port)
     from starst3r_amd import dist as sdist, ops
