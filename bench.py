@@ -416,6 +416,52 @@ def scaling_model(ctx, ops, g_np, w2c_np, Ks_np, N, V, W, H, device):
     return out
 
 
+def config1_bench(ctx, ops, device, steps=60, warm=15):
+    """BASELINE.json configs[1]'s training regime on one GPU -- 200 k Gaussians, 8 views of 512 x 384 (the size the
+    reference's own main.py:80-81 runs) --, labelled, NOT the headline: the same single C call per iteration, ground-truth
+    moments registered once like run_3dgs_optim does."""
+    from st3r_synth import synth
+    N, V, W, H = 200_000, 8, 512, 384
+    g_np, w2c_np, Ks_np = synth.make_scene(N, V, W, H)
+    P = {k: torch.tensor(v, device=device) for k, v in g_np.items()}
+    P["shN"] = P["shN"][:, :4].contiguous()
+    w2c, Ks = torch.tensor(w2c_np, device=device), torch.tensor(Ks_np, device=device)
+    campos = ops.camera_positions(w2c)
+    gt = make_gt_images(ctx, ops, g_np, w2c, Ks, W, H, device)
+    mom = ops.gt_moments(ctx, gt)
+    ops.set_gt_moments(ctx, gt, mom)
+    grads = torch.empty(23 * N, device=device); m = torch.zeros_like(grads); v = torch.zeros_like(grads)
+    loss = torch.zeros(warm + steps, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st0 = None
+    try:
+        for it in range(warm + steps):
+            if it == warm:
+                e0.record()
+            st = ops.train_step(ctx, P, w2c, Ks, campos, gt, W, H, 0.2, 0.01, 0.01, grads, m, v, 1e-3, 0.9, 0.999, 1e-8, it + 1,
+                                loss[it:it + 1], want_stats=(it == 0))
+            st0 = st0 or st
+        e1.record(); torch.cuda.synchronize()
+        ops.settle(ctx)
+    finally:
+        ops.set_gt_moments(ctx, None, None)
+    ms = e0.elapsed_time(e1) / steps
+    L = loss.cpu().numpy()
+    return {"workload": f"BASELINE configs[1] regime: {N} gaussians, {V} views {W}x{H}, train only (labelled secondary "
+                        "measurement, not the headline)", "ms_per_step": ms, "iters_per_sec": 1e3 / ms, "steps": steps,
+            "warmup": warm, "n_isects_kept_first_step": (st0 or {}).get("n_isects"), "loss_first": float(L[0]),
+            "loss_last": float(L[-1]), "seconds_for_7000_iterations_at_this_rate": 7.0 * ms}
+
+
+def replica_checksum(P):
+    """one int64 over the BITS of every parameter tensor: equal on every rank <=> the replicas are (all but certainly) identical"""
+    tot = torch.zeros((), dtype=torch.int64, device=next(iter(P.values())).device)
+    for k in sorted(P):
+        b = P[k].contiguous().view(torch.int32).to(torch.int64)
+        tot = tot + (b * (torch.arange(b.numel(), device=b.device, dtype=torch.int64).reshape(b.shape) % 1021 + 1)).sum()
+    return tot
+
+
 def matching_bench(device, with_cpu=True):
     """Path A: seeded nearest-neighbour query of fast_reciprocal_NNs (starster/reconstruct.py:97) at the
     reference's size: 3072 seeds against the 512x384 descriptors (D = 24) of the other image -- the only dense
@@ -673,6 +719,23 @@ def main():
             t = torch.tensor([e0.elapsed_time(e1) / reps], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             exch_ms = float(t.item())
+    # N > 1 self-diagnosis: how many ranks the library's communicator really has, and whether the
+    # replicas are still identical after the timed steps (a wrong exchange shows as a difference, not as a slow step)
+    n_ranks_seen, replicas_identical = 1, None
+    if mode != "gaussian-sharded":
+        from starst3r_amd import _lib as _l
+        import ctypes
+        ws, rk = ctypes.c_int(0), ctypes.c_int(0)
+        _l.check(_l.lib().st3r_comm_world(ctx.handle, ctypes.byref(ws), ctypes.byref(rk)))
+        n_ranks_seen = int(ws.value)
+        if dist is not None:
+            mine = replica_checksum(P).reshape(1)
+            allc = [torch.zeros_like(mine) for _ in range(world)]
+            if EMULATED:
+                allc = [a.cpu() for a in allc]; dist.all_gather(allc, mine.cpu())
+            else:
+                dist.all_gather(allc, mine)
+            replicas_identical = all(int(a.item()) == int(allc[0].item()) for a in allc)
     if mode == "gaussian-sharded":   # counts of the own Gaussians over all views ~ those of the own views over all Gaussians
         stats["n_visible"] = int(trainer.reg[2].item()); stats["n_isects_ref"] = int(trainer.reg[3].item())
     if world > 1:
@@ -789,7 +852,28 @@ def main():
         out["roofline"]["backward_stages_frac"] = out["roofline"]["backward_stages_combined"]["frac"]
         if drift and "steps_180_200" in drift:   # SURVEY 8(d)'s >= 200-step regime next to the driver's 20-step headline
             out["value_steps_180_200"] = 1e3 / drift["steps_180_200"]
-        out["roofline"]["valu_issue"] = valu_issue(per_stage, N, args.views, W, H, world)
+        vi = valu_issue(per_stage, N, args.views, W, H, world)
+        out["roofline"]["valu_issue"] = vi
+        # the bound the blend kernels actually hit, as flat scalars: fraction of the 2-cycle VALU issue
+        # rate at the 2.4 GHz the guide quotes (None until profiles/pmc_traffic.json belongs to these kernel sources)
+        for st_ in ("blend_fwd", "blend_bwd"):
+            out["roofline"][f"valu_issue_frac_{st_}"] = (vi or {}).get(st_, {}).get("frac_at_2_cycles")
+        # DESIGN.md section 7, "floor": the VALU slots this formulation cannot avoid (forward: 22 per (record, wave) trip of
+        # the cell lists; backward: 28 per trip + 60 per four records) x the trips SYNTH-1M takes x 2 cycles at the 2.1 GHz
+        # the kernels hold = 0.48 + 1.10 ms, plus the 1.75 ms every other stage takes today = 3.3 - 3.4 ms: the 3.33 ms of
+        # 300 it/s are not reachable by scheduling these loops better, only by evaluating fewer (record, pixel) pairs
+        out["roofline"]["blend_formulation_floor_ms"] = {"blend_fwd": 0.48, "blend_bwd": 1.10,
+                                                          "all_other_stages_today": sum(v_ for k_, v_ in per_stage.items() if k_ not in ("blend_fwd", "blend_bwd"))}
+        out["roofline"]["target_reachable_with_this_formulation"] = False
+        # flat N > 1 diagnostics
+        out["n_ranks_seen"] = n_ranks_seen
+        out["replicas_identical_after_timed_steps"] = replicas_identical
+        out["exchange_ms_isolated"] = exch_ms
+        out["compute_only_ms_per_step"] = (ms_per_step - exch_ms) if exch_ms is not None else ms_per_step
+        if world == 1 and not FREEZE and not args.train_only and mode != "gaussian-sharded":
+            ops.set_gt_moments(ctx, None, None)
+            out["config_1"] = config1_bench(ctx, ops, device)
+            out["config_1_iters_per_sec"] = out["config_1"]["iters_per_sec"]
         if world == 1 and not FREEZE and not args.no_scaling_model and mode != "gaussian-sharded":
             out["scaling_model"] = scaling_model(ctx, ops, g_np, w2c_np, Ks_np, N, args.views, W, H, device)
         if not args.no_cpu_baseline and world == 1:
@@ -851,6 +935,13 @@ def main():
                 t = torch.tensor([e0.elapsed_time(e1) / 5], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 forms_ms[form] = float(t.item())
+                # the replicas after this form's six steps: identical or the form is WRONG on this node
+                mine = replica_checksum(P).reshape(1)
+                lo, hi = mine.clone(), mine.clone()
+                if EMULATED:
+                    lo, hi = lo.cpu(), hi.cpu()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                forms_ms[form + "_replicas_identical"] = bool(int(lo.item()) == int(hi.item()))
             except Exception as e:  # noqa: BLE001 -- a form that fails on this node is a finding, not a crash of the bench
                 forms_ms[form] = f"failed on rank {rank}: {e}"[:200]
                 break
