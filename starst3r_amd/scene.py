@@ -13,7 +13,9 @@ from .reconstruct import reconstruct_scene
 
 
 class Scene:
-    """Starst3r scene. Contains Mast3r and 3DGS reconstructions, and helper methods."""
+    """State of one reconstruction: the input photographs, the poses / intrinsics / dense points the alignment produced for
+    them, and -- after init_3dgs -- the Gaussians with their optimisers.  Mirrors starster/scene.py:19-77 attribute for
+    attribute (the boundary users program against); every method hands the work to reconstruct.py or gs.py."""
 
     def __init__(self, cache_dir: Optional[str] = None, device="cuda"):
         self.device = device
@@ -35,13 +37,13 @@ class Scene:
 
     @property
     def dense_pts_flat(self):
-        """Dense points concatenated from all cameras."""
+        """One [sum_i n_i, 3] tensor: the per-view point sets of `dense_pts` stacked in view order (scene.py:79-83)."""
         assert self.dense_pts, "No dense points available."
         return torch.cat(self.dense_pts, dim=0)
 
     @property
     def dense_cols_flat(self):
-        """Dense colors concatenated from all cameras."""
+        """The colours that go with `dense_pts_flat`, same order (scene.py:85-89)."""
         assert self.dense_cols, "No dense colors available."
         return torch.cat(self.dense_cols, dim=0)
 
@@ -56,26 +58,20 @@ class Scene:
         return self._w2c_cache[2]
 
     def add_images(self, model, imgs, conf_thres=1.5):
-        """Add GT images to the scene. Solve camera pose and update dense points (scene.py:97-155).
-        Every call re-solves ALL images and replaces poses/points; the previous optimisation result is
-        the warm start."""
+        """Append photographs (each [H, W, 3]) and solve the WHOLE set again: matching, alignment (warm-started from the
+        previous call's parameters) and dense points, keeping per view the points whose confidence exceeds `conf_thres`.
+        Poses, intrinsics and points of earlier views are replaced, not extended (scene.py:97-155); the
+        pair cache under `cache_dir` is keyed by the stand-in file names "0.png", "1.png", ... like the reference's."""
         self.raw_imgs.extend(imgs)
-        filelist = [f"{i}.png" for i in range(len(self.raw_imgs))]
-        scene, optim_params = reconstruct_scene(model, self.raw_imgs, filelist, self.device,
-                                                optim_params=self.optim_params, tmpdir=self.cache_dir)
-        self.optim_params = optim_params
-        curr_len = len(self.imgs)
-        self.imgs.extend(scene.imgs[curr_len:])
-        self.c2w = scene.cam2w
-        self.intrinsics = scene.intrinsics
-        pts, _, confs = scene.get_dense_pts3d(clean_depth=True)
-        self.dense_pts = []
-        self.dense_cols = []
-        for i in range(len(scene.imgs)):
-            mask = (confs[i] > conf_thres).reshape(-1).cpu()
-            colors = torch.as_tensor(scene.imgs[i]).reshape(-1, 3)
-            self.dense_pts.append(pts[i].cpu()[mask])
-            self.dense_cols.append(colors[mask])
+        names = [f"{i}.png" for i in range(len(self.raw_imgs))]
+        result, self.optim_params = reconstruct_scene(model, self.raw_imgs, names, self.device,
+                                                      optim_params=self.optim_params, tmpdir=self.cache_dir)
+        self.imgs.extend(result.imgs[len(self.imgs):])
+        self.c2w, self.intrinsics = result.cam2w, result.intrinsics
+        pts, _, confs = result.get_dense_pts3d(clean_depth=True)
+        keep = [(confs[i] > conf_thres).reshape(-1).cpu() for i in range(len(result.imgs))]
+        self.dense_pts = [pts[i].cpu()[k] for i, k in enumerate(keep)]
+        self.dense_cols = [torch.as_tensor(result.imgs[i]).reshape(-1, 3)[k] for i, k in enumerate(keep)]
 
     def init_3dgs(self, init_scale=3e-3, lr=1e-3):
         _gs.init_3dgs(self, init_scale, lr)
