@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-scaling-model", action="store_true",
                     help="skip the single-GPU model of the 1 -> 8 GPU curve (scaling_model: this rank's step at 8 / 4 / 2 / 1 "
                          "views + the one-rank exchange), ~1 s")
+    ap.add_argument("--no-config1", action="store_true",
+                    help="skip the labelled secondary measurement at BASELINE configs[1]'s size (profiling runs: its 75 steps of "
+                         "a smaller workload would enter the per-kernel means)")
     ap.add_argument("--train-only", action="store_true",
                     help="skip the alignment / matching / condensation benches behind the headline (profiling runs)")
     ap.add_argument("--multi-gpu", choices=("replicated", "gaussian-sharded"), default="replicated",
@@ -755,6 +758,14 @@ def main():
         keybits = 32 + (tw * th).bit_length() + C_local.bit_length()           # gsplat's single key (reference)
         key1_bytes = 4 if C_local <= 8 else 8                                   # level-1 (camera | depth) key
         key1_bits = (29 if C_local <= 8 else 32) + max(C_local - 1, 0).bit_length()
+        # round 6: <= 8 views sort per camera segment on depth codes biased by the smallest one of the call, in as many 8-bit
+        # passes as that range needs -- decided on the device (control word 10 of the fused steps); the bytes are those of
+        # the passes that RAN
+        level1_passes_run = None
+        if C_local <= 8 and mode != "gaussian-sharded":
+            level1_passes_run = int(ops.peek(ctx, 10, 16)[10].item())
+            if 1 <= level1_passes_run <= 4:
+                key1_bits = 8 * level1_passes_run
         key2_bits = max(C_local * tw * th - 1, 1).bit_length()                  # level-2 (camera, tile) key
         ab = algorithmic_bytes(N, C_local, V, I_kept, P_px, C_local * tw * th, key1_bits, key1_bytes, key2_bits)
         ab_ref = algorithmic_bytes_reference(N, V, I, P_px, C_local * tw * th, keybits)
@@ -787,6 +798,7 @@ def main():
                                       "N > 1 path, not a measurement"} if EMULATED else {}),
                 "n_visible_pairs": V, "n_isects_reference_algorithm": I, "n_isects_kept_after_exact_culling": I_kept,
                 "sort_key_bits": {"reference_single_key": keybits, "level1": key1_bits, "level2": key2_bits},
+                "level1_sort_passes_run": level1_passes_run,
                 "mean_tiles_per_visible_gaussian": (I_kept / V) if V else 0.0,
                 "mean_records_per_tile": I_kept / (C_local * tw * th),
                 # loss of the first step and of the LAST TIMED step (step warmup + steps), the step psnr_db_after is taken
@@ -870,7 +882,7 @@ def main():
         out["replicas_identical_after_timed_steps"] = replicas_identical
         out["exchange_ms_isolated"] = exch_ms
         out["compute_only_ms_per_step"] = (ms_per_step - exch_ms) if exch_ms is not None else ms_per_step
-        if world == 1 and not FREEZE and not args.train_only and mode != "gaussian-sharded":
+        if world == 1 and not FREEZE and not args.train_only and not args.no_config1 and mode != "gaussian-sharded":
             ops.set_gt_moments(ctx, None, None)
             out["config_1"] = config1_bench(ctx, ops, device)
             out["config_1_iters_per_sec"] = out["config_1"]["iters_per_sec"]

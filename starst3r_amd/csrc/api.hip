@@ -175,7 +175,7 @@ ST3R_EXPORT int st3r_ctx_get_stage_ms(st3r_ctx* ctx, double* ms_out, int64_t* co
 // ---- internal stage launchers (other translation units) ----
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
                          int64_t* n_isects_host, const void* pack_rects, int rect32, uint64_t* pack_out,
-                         int32_t** total_dev_out, int32_t* total_copy);
+                         int32_t** total_dev_out, int32_t* total_copy, int32_t* total_host);
 int st3r_isect_emit_impl(hipStream_t s, int N, int C, const float* splats, const int32_t* cum, int tile_size,
                          int tile_w, int tile_h, int64_t* isect_ids, int32_t* flatten_ids);
 int st3r_sort_impl(st3r_ctx* ctx, hipStream_t s, int64_t n, int end_bit, int64_t* keys_in, int32_t* vals_in,
@@ -384,11 +384,11 @@ static int rasterize_front(st3r_ctx* ctx, hipStream_t s, int N, int C, const flo
     const bool async = allow_async && ctx->isect_hint > 0 && ctx->hint_sig == sig;
     int32_t* total_dev = nullptr;
     rc = st3r_isect_scan_impl(ctx, s, n_pairs, nullptr, cum, nullptr, rects, rect32, rectbase, &total_dev,
-                              async ? counts : nullptr);
+                              async ? counts : nullptr, async ? (int32_t*)(ctx->pinned + 8) : nullptr);
     st3r_prof_end(ctx, s, STG_SCAN);
     if (rc) return rc;
     if (async) {
-        HIP_TRY(hipMemcpyAsync((int32_t*)(ctx->pinned + 8), total_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        // (the scan's last workgroup has stored the count into the pinned word itself)
         if (!ctx->count_event) HIP_TRY(hipEventCreateWithFlags(&ctx->count_event, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ctx->count_event, s));
         n_isects = ctx->isect_hint + ctx->isect_hint / 4 + 1024;   // capacity, not the count

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const int32_t* in
                                                                uint64_t* __restrict__ pack_out, u64* status,
                                                                uint32_t* ticket, uint32_t gen,
                                                                int32_t* __restrict__ total_out,
-                                                               int32_t* __restrict__ total_copy) {
+                                                               int32_t* __restrict__ total_copy,
+                                                               int32_t* __restrict__ total_host) {
     __shared__ int tile[SCAN_PAD(SCAN_TILE) + 1];
     __shared__ uint32_t s_tile;
     if (threadIdx.x == 0) {
@@ -161,6 +162,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const int32_t* in
         const u64 all = excl + tot;                     // -- the callers turn a negative count into an error -- instead of
         total_out[0] = all > 2147483647ull ? -1 : (int32_t)all;   // wrapping silently)
         if (total_copy) total_copy[0] = total_out[0];   // (the ctx's count word of an asynchronous step: no copy launch)
+        // and straight into the ctx's pinned host word (round 6: the 4-byte hipMemcpyAsync that used to carry it cost a blit
+        // launch and ~20 us of drained GPU around it, every step); the host reads it behind the event recorded after this
+        // kernel, never earlier
+        if (total_host) __hip_atomic_store(total_host, total_out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const int tile_excl = (int)(uint32_t)excl;
     int run = tile_excl + inc - s;
@@ -207,14 +212,15 @@ static int chain_ctl(st3r_ctx* ctx, hipStream_t s, int64_t nwords, ChainCtl* c) 
 // out = inclusive scan of in (counts) or of the areas of the packed rectangles `rects`; the grand total is left in
 // device memory (*total_dev)
 int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, const void* rects, int rect32, int32_t* out,
-                            int64_t n, int32_t** total_dev, uint64_t* pack_out = nullptr, int32_t* total_copy = nullptr) {
+                            int64_t n, int32_t** total_dev, uint64_t* pack_out = nullptr, int32_t* total_copy = nullptr,
+                            int32_t* total_host = nullptr) {
     const int ntiles = ceil_div(n, SCAN_TILE);
     ChainCtl c;
     int rc = chain_ctl(ctx, s, ntiles, &c);
     if (rc) return rc;
 #define SCAN_LAUNCH(R, P)                                                                                                \
     hipLaunchKernelGGL((k_scan_chained<R, P>), dim3(ntiles), dim3(SCAN_THREADS), 0, s, in, rects, rect32, n, out, pack_out, \
-                       c.status, c.tickets, c.gen, c.total, total_copy)
+                       c.status, c.tickets, c.gen, c.total, total_copy, total_host)
     if (rects && pack_out) SCAN_LAUNCH(true, true);
     else if (rects) SCAN_LAUNCH(true, false);
     else SCAN_LAUNCH(false, false);
@@ -228,11 +234,11 @@ int st3r_scan_inclusive_i32(st3r_ctx* ctx, hipStream_t s, const int32_t* in, con
 // path; pack_out then also receives slot base | rectangle per pair when it is not NULL).
 int st3r_isect_scan_impl(st3r_ctx* ctx, hipStream_t s, int64_t n_pairs, const int32_t* tiles, int32_t* cum,
                          int64_t* n_isects_host, const void* pack_rects, int rect32, uint64_t* pack_out,
-                         int32_t** total_dev_out, int32_t* total_copy) {
+                         int32_t** total_dev_out, int32_t* total_copy, int32_t* total_host) {
     if (n_pairs == 0) { if (n_isects_host) *n_isects_host = 0; return ST3R_OK; }
     int32_t* total_dev = nullptr;
     int rc = st3r_scan_inclusive_i32(ctx, s, tiles, tiles ? nullptr : pack_rects, rect32, cum, n_pairs, &total_dev,
-                                     tiles ? nullptr : pack_out, total_copy);
+                                     tiles ? nullptr : pack_out, total_copy, total_host);
     if (rc) return rc;
     if (total_dev_out) *total_dev_out = total_dev;
     if (n_isects_host) {
@@ -248,7 +254,7 @@ ST3R_EXPORT int st3r_gs_isect_scan(st3r_ctx* ctx, void* stream, int64_t n_pairs,
                                    int32_t* cum_tiles, int64_t* n_isects_host) {
     ARG_CHECK(ctx && n_pairs >= 0 && tiles_per_gauss && cum_tiles && n_isects_host);
     return st3r_isect_scan_impl(ctx, (hipStream_t)stream, n_pairs, tiles_per_gauss, cum_tiles, n_isects_host, nullptr,
-                                0, nullptr, nullptr, nullptr);
+                                0, nullptr, nullptr, nullptr, nullptr);
 }
 
 __global__ __launch_bounds__(256) void k_isect_emit(int N, int64_t n_pairs, const float4* __restrict__ splats,

@@ -10,11 +10,11 @@ TAG=${1:-r4a}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-drift --no-scaling-model"
+CMD="python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-drift --no-scaling-model --no-config1"
 $CMD > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
-SHORT="python $ROOT/bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-drift --no-scaling-model"
+SHORT="python $ROOT/bench.py --gpus 1 --steps 6 --warmup 2 --no-cpu-baseline --no-drift --no-scaling-model --no-config1"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/pmc_$C -- $SHORT > $OUT/pmc_$C.log 2>&1
 done

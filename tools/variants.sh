@@ -16,7 +16,7 @@ else
   cp starst3r_amd/libst3r_hip.so /tmp/orig.so
   for f in build_variants/v*.so; do
     cp $f starst3r_amd/libst3r_hip.so
-    python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-drift --no-scaling-model "$@" 2>/dev/null | tail -1 | python -c "
+    python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-drift --no-scaling-model --no-config1 "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); s = d['roofline']['stage_ms']
 print('== [$(cat ${f%.so}.txt)]', round(d['ms_per_step'], 3), 'ms', {k: round(v, 3) for k, v in s.items()})"
