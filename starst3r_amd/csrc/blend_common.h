@@ -9,9 +9,15 @@
 
 // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  Tiles are handed out in groups of G consecutive
 // tiles per XCD, the groups round-robin over the XCDs: neighbouring tiles (which share Gaussians) meet in one L2.
-// With C a multiple of 8 a group is a whole camera (one camera per XCD); otherwise a group is one tile row, so
-// that the dense image centre and the sparse borders are spread over all XCDs (a single view cut into 8
-// contiguous bands left the XCDs of the borders idle: blend bwd 0.65 -> see DESIGN.md).
+// A group is one TILE ROW (XCD_GROUP), whatever the number of views: every XCD then gets every eighth row of every camera --
+// the dense image centre and the sparse borders are spread over all XCDs.  Rounds 2-5 gave a whole camera to an XCD when the
+// views were a multiple of 8; measured in round 6 (alternating same-box A/B, frozen SYNTH-1M scene): rows instead of
+// cameras -0.035 +- 0.006 ms on the blend backward (the cameras' record counts differ by a few per cent and the kernel
+// ends with its slowest XCD), two rows per group equal, half rows +0.03, quarter rows +1.6 ms (vertical stripes: the XCDs
+// that own the centre columns do most of the work), 17 rows +0.16.
+#ifndef XCD_GROUP
+#define XCD_GROUP(C, n_tiles, tile_w) (tile_w)
+#endif
 __device__ __forceinline__ int xcd_remap(int bid, int total, int G) {
     const int n_full = (total / (8 * G)) * (8 * G);
     if (bid >= n_full) return bid;

@@ -138,7 +138,7 @@ struct CellTile {
 __device__ __forceinline__ CellTile cell_tile(int C, int W, int H, int tile_w, int tile_h, const int32_t* __restrict__ offsets) {
     CellTile g;
     const int n_tiles = tile_w * tile_h, total = C * n_tiles;
-    g.lb = xcd_remap(blockIdx.x, total, (C & 7) == 0 ? (C >> 3) * n_tiles : tile_w);
+    g.lb = xcd_remap(blockIdx.x, total, XCD_GROUP(C, n_tiles, tile_w));
     g.cam = g.lb / n_tiles;
     const int tile = g.lb - g.cam * n_tiles;
     const int ty = tile / tile_w, tx = tile - ty * tile_w;

@@ -541,6 +541,11 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
     const int per_band = ceil_div(W, strip) * C;
     // (measured, tools/experiments/ssim_bands.sh: ~1000 workgroups, strips of at least 64 rows -- 8 views: 5 bands, 1 view: 17)
     int bands = std::max(1, std::min(ceil_div(SSIM_TARGET_WGS, per_band), std::max(1, H / 64)));
+    const float2* gtm = v_render ? gt_moments_for(ctx, gt, C, H, W) : nullptr;
+    // k_ssim_fused<true> (80 VGPRs) keeps THREE workgroups per CU: as many row bands as still fit the 768 resident slots in
+    // one round (round 6, 8 x 1080p: 3 bands = 720 workgroups 0.404 ms, 6 bands 0.403, 4 bands 0.411, the 5 bands of the
+    // rule above 0.453, 8 bands 0.437, 10 bands 0.416: what matters is how the workgroups fill whole rounds of the chip)
+    if (gtm) bands = std::max(1, std::min(768 / std::max(per_band, 1), std::max(1, H / 64)));
     if (const char* e = getenv("ST3R_SSIM_BANDS")) bands = std::max(1, atoi(e));   // tuning hook (tools/experiments/ssim_bands.sh)
     const int LH = ceil_div(H, bands);
     dim3 grid(ceil_div(W, strip), ceil_div(H, LH), C);
@@ -553,7 +558,6 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
     const double cnt = (Hi > 0 && Wi > 0) ? (double)Hi * Wi * 3 : 0.0;
     const float k_l1 = (float)((double)w_l1 / ((double)H * W * 3));
     const float k_ss = cnt > 0 ? (float)(-(double)w_ssim / cnt) : 0.f;
-    const float2* gtm = gt_moments_for(ctx, gt, C, H, W);
     if (gtm)
         hipLaunchKernelGGL(k_ssim_fused<true>, grid, dim3(FT2), 0, s, LH, H, W, render, gt, gtm, win, k_l1, k_ss, sums, v_render);
     else
