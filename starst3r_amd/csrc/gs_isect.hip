@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
                                                       int64_t cap) {
     __shared__ int s_end[EP];         // inclusive scan of the workgroup's tile counts
     __shared__ uint32_t s_org[EP];    // x0 | y0 << 16
-    __shared__ uint32_t s_w[EP];      // rectangle width
+    __shared__ uint16_t s_w[EP];      // rectangle width (< 2^16 in both packed forms; 22.6 KB of LDS in all: seven workgroups per CU)
     __shared__ int32_t s_pid[EP];
     __shared__ uint16_t s_own[ECH];   // owner (pair index + 1) of every output of the current emission chunk
     __shared__ unsigned s_wmax[4];
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_isect_emit_d(int N, int C, int bpc, con
             pid = perm[first + e];
             rect_load(rects_d, rect32, first + e, &org, &rw, &rh);
         }
-        s_pid[e] = pid; s_org[e] = org; s_w[e] = rw;
+        s_pid[e] = pid; s_org[e] = org; s_w[e] = (uint16_t)rw;
         cnt[j] = (int)(rw * rh);
     }
     // scan in pair order: EPT block scans of 256 consecutive pairs, the carry in a register
