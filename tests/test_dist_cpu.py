@@ -320,6 +320,10 @@ def _mock_ops(monkey_ops, g_keys=("means", "quats", "scales", "opacities", "shN"
     monkey_ops.train_step = train_step
     monkey_ops.get_context = lambda device: type("Ctx", (), {"native_comm": False, "device": "cpu"})()
     monkey_ops.settle = lambda ctx: None     # the stand-in steps are synchronous: nothing is ever in flight
+    # (round 6: the loop registers SSIM's ground-truth moments with the ctx once per call -- C calls like the others; the
+    # oracle stand-in of the step convolves the ground truth itself)
+    monkey_ops.gt_moments = lambda ctx, gt: None
+    monkey_ops.set_gt_moments = lambda ctx, gt, mom: None
     return calls
 
 
