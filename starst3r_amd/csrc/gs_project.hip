@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_project_sh_fwd(
                 if (valid) { kmin = min(kmin, kk); kmax = max(kmax, kk); }
             } else
                 depth_keys[pid] = ((uint64_t)c << 32) | dbits;
-            depth_vals[pid] = (int32_t)pid;
+            if (!krange_part) depth_vals[pid] = (int32_t)pid;   // (the segmented sort's first pass numbers the pairs itself)
         }
         n_vis += valid ? 1 : 0;
     }

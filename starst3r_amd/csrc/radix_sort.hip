@@ -170,8 +170,10 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));   // count on the device, grid sized for the capacity `n`
     constexpr int TILE = THREADS * IPT, WAVES = THREADS / 64;
     uint32_t kmin = 0, ktop = 0;
+    bool last_seg_pass = false;
     if constexpr (SEG) {
         const int np = (int)krange[2];
+        last_seg_pass = ps == np - 1;
         if (ps >= np) return;                                   // (uniform over the launch)
         const bool to_out = ((np - 1 - ps) & 1) == 0;           // the last pass that runs writes the caller's output
         const K* src_k = ps == 0 ? kin : (to_out ? ktmp : kout);
@@ -237,7 +239,13 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
             for (int c = 0; c < HIST_COPIES; ++c) hv += hist_base[c * (MAX_PASSES * RADIX) + tid];
         }
     }
-    if (vin) {   // in flight while the keys are ranked
+    // SEG, pass 0: the values ARE the item indices (pair ids) -- nothing is read, and the projection does not write them
+    const bool iota_vals = SEG && ps == 0;
+    const bool has_vals = SEG || vin != nullptr;
+    if (iota_vals) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) val[i] = (int32_t)(tbase + wbase + i * 64);
+    } else if (vin) {   // in flight while the keys are ranked
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const int li = wbase + i * 64;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
             const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
             const uint32_t pos = lbase[d] + wh[d] + rank[i];
             sbuf[pos] = key[i];
-            if (vin) svals[pos] = val[i];
+            if (has_vals) svals[pos] = val[i];
         }
     }
     __syncthreads();
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const K* __restrict__ kin, 
             const K k = sbuf[p];
             const uint32_t d = (uint32_t)(k >> shift) & dmask;
             const long long o = gofs[d] + p;
-            kout[o] = k;
-            if (vin) vout[o] = svals[p];
+            if (!(SEG && last_seg_pass)) kout[o] = k;   // (nobody reads the level-1 keys once the pairs are in order)
+            if (has_vals) vout[o] = svals[p];
         }
     }
 }
