@@ -699,6 +699,26 @@ def main():
         for a, b in ((100, 120), (180, 200)):
             if a in ev and b in ev:
                 drift[f"steps_{a}_{b}"] = ev[a].elapsed_time(ev[b]) / (b - a)
+    # What the once-per-call ground-truth moments are worth per step, measured: blocks of 5 more steps alternately WITH the
+    # registered moments (as in the timed region, as in gs.run_3dgs_optim) and WITHOUT (every step convolves the ground truth
+    # itself, like torchmetrics inside the reference's compute_loss) -- so that the line also carries the rate a reader gets
+    # who counts the moments as per-iteration work
+    gtm_delta_ms = None
+    if gtm_ms is not None and world == 1 and not FREEZE and mode != "gaussian-sharded":
+        it_x = max(losses.numel() - 2, 1)   # (not the first / last index: those ask for statistics, i.e. the synchronous path)
+        acc = {True: 0.0, False: 0.0}
+        for blk in range(6):
+            use = blk % 2 == 0
+            ops.set_gt_moments(ctx, gt if use else None, gt_mom if use else None)
+            step(it_x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                step(it_x)
+            e1.record(); torch.cuda.synchronize()
+            acc[use] += e0.elapsed_time(e1) / 5
+        ops.set_gt_moments(ctx, gt, gt_mom)
+        gtm_delta_ms = (acc[False] - acc[True]) / 3
     # per-rank view of the same timed region, and the exchange on its own (N > 1)
     my_ms = marks[0].elapsed_time(marks[-1]) / args.steps
     per_rank_ms, exch_ms = [my_ms], None
@@ -811,6 +831,11 @@ def main():
                 # SSIM's ground-truth moments: computed once per training call outside the timed steps (None: every step
                 # convolves the ground truth itself)
                 "gt_moments_once_per_call_ms": gtm_ms,
+                # measured after the timed region (alternating blocks of steps with / without the registered moments): what a
+                # step costs more when it convolves the ground truth itself, and the headline rate with that added back
+                "gt_moments_recompute_cost_ms_per_step": gtm_delta_ms,
+                "iters_per_sec_if_gt_moments_were_recomputed_every_step":
+                    (1e3 / (ms_per_step + gtm_delta_ms)) if gtm_delta_ms is not None else None,
                 **({"iters_per_sec_steps_180_200": 1e3 / drift["steps_180_200"],
                     "ms_per_step_steps_180_200": drift["steps_180_200"]} if drift and "steps_180_200" in drift else {}),
             },
