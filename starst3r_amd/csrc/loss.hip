@@ -545,7 +545,9 @@ int st3r_loss_impl(st3r_ctx* ctx, hipStream_t s, int C, int H, int W, const floa
     // k_ssim_fused<true> (80 VGPRs) keeps THREE workgroups per CU: as many row bands as still fit the 768 resident slots in
     // one round (round 6, 8 x 1080p: 3 bands = 720 workgroups 0.404 ms, 6 bands 0.403, 4 bands 0.411, the 5 bands of the
     // rule above 0.453, 8 bands 0.437, 10 bands 0.416: what matters is how the workgroups fill whole rounds of the chip)
-    if (gtm) bands = std::max(1, std::min(768 / std::max(per_band, 1), std::max(1, H / 64)));
+    // (the same for the kernel that convolves the ground truth itself -- 94 VGPRs, two workgroups per CU, 512 slots: 8 x 1080p
+    // with 2 bands 0.436 ms, 3 bands 0.49, 4 bands 0.45, 5 bands 0.47, 6 bands 0.46)
+    if (v_render) bands = std::max(1, std::min((gtm ? 768 : 512) / std::max(per_band, 1), std::max(1, H / 64)));
     if (const char* e = getenv("ST3R_SSIM_BANDS")) bands = std::max(1, atoi(e));   // tuning hook (tools/experiments/ssim_bands.sh)
     const int LH = ceil_div(H, bands);
     dim3 grid(ceil_div(W, strip), ceil_div(H, LH), C);
