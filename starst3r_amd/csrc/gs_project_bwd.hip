@@ -17,6 +17,9 @@
 #include "blend_common.h"
 
 #define CAM_STRIDE 32
+#ifndef GATHER_WIDE_ABOVE
+#define GATHER_WIDE_ABOVE 6   // slots per pair (wave average) above which the slot gather deals its additions by item
+#endif
 #define SH_C0 0.2820947917738781f
 #define SH_C1 0.48860251190292f
 
@@ -31,7 +34,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     unsigned vt_cap) {
     extern __shared__ float cam[];
     constexpr int ROW = ACC_VALS;   // odd stride: rows of neighbouring slots fall into different banks
-    __shared__ float sVal[GATHER ? 256 * ROW : 1];
+    __shared__ float sVal[GATHER ? 256 * ROW : 1];    // per wave: the current chunk of 64 slots, nine values each
+    __shared__ float sAcc[GATHER ? 256 * ROW : 1];    // per wave: the running sums of its 64 pairs
+    __shared__ int sStart[GATHER ? 4 * 65 : 1];       // per wave: first slot of each of its pairs (+ the end of the last)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float* o = cam + c * CAM_STRIDE;
         const float* V = viewmats + 16 * c;
@@ -106,8 +111,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             // flight), then lane = pair adds the rows of its own slots in slot order.  No workgroup barrier: the four waves of
             // a workgroup walk their ranges independently (with 256-slot chunks behind __syncthreads the kernel took 0.31 ms
             // at four waves per SIMD; the sums and their order are the same).
-            const int lane = threadIdx.x & 63;
-            float* wval = sVal + (threadIdx.x >> 6) * (64 * ROW);
+            // How the rows of a chunk are added depends on how many slots a pair has (decided per wave and camera, uniform):
+            //   narrow (<= 6 slots per pair on average: SYNTH-1M has 3.3)   lane = pair adds the nine values of its own rows,
+            //            sums in registers -- a chunk of 64 slots meets ~20 pairs, four or five rows each;
+            //   wide   (round 6; the configs[1] example after a few hundred iterations: 25 slots per pair)   the additions are
+            //            dealt by (pair, value) ITEM: the pairs that meet the chunk times the nine values are spread over the
+            //            lanes, each item adds its rows in slot order onto the pair's running sum in LDS.  With lane = pair
+            //            such a scene left 3 of 64 lanes working through up to 64 rows of nine values each: the projection
+            //            backward took 7.05 of a 13.7 ms iteration, 3.9 ms in this form.
+            // Either way a pair's rows are added in slot order starting from zero: the same sums, bit for bit.
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            float* wval = sVal + wv * (64 * ROW);
             // (a thread past g_end sits on the last pair: its range is the empty one BEHIND that pair, so that lane 63 still
             // closes the wave's range)
             const int my_end = cum[pid];
@@ -115,8 +129,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const int s0 = __builtin_amdgcn_readfirstlane(my_start);
             const int s1 = __builtin_amdgcn_readlane(my_end, 63);
             float acc[ACC_VALS];
-#pragma unroll
-            for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] = 0.f;
             float2 q0, q1, q2, q3, q4;
             auto fetch = [&](int u) {
                 q0 = q1 = q2 = q3 = q4 = make_float2(0.f, 0.f);   // stamp 0 = never written
@@ -125,22 +137,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                     q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; q4 = src[4];
                 }
             };
-            if (s1 > s0) fetch(s0 + lane);
-            for (int base = s0; base < s1; base += 64) {
+            auto rows_to_lds = [&]() {
                 const bool live = __float_as_int(q4.y) == stamp;
                 float* row = wval + lane * ROW;
                 row[0] = live ? q0.x : 0.f; row[1] = live ? q0.y : 0.f; row[2] = live ? q1.x : 0.f;
                 row[3] = live ? q1.y : 0.f; row[4] = live ? q2.x : 0.f; row[5] = live ? q2.y : 0.f;
                 row[6] = live ? q3.x : 0.f; row[7] = live ? q3.y : 0.f; row[8] = live ? q4.x : 0.f;
-                wave_lds_sync();
-                fetch(base + 64 + lane);
-                const int lo = max(my_start, base) - base, hi = min(my_end, base + 64) - base;
-                for (int r = lo; r < hi; ++r) {
-                    const float* src = wval + r * ROW;
+            };
+            if (s1 > s0) fetch(s0 + lane);
+            if (s1 - s0 <= 64 * GATHER_WIDE_ABOVE) {
 #pragma unroll
-                    for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] += src[k2];
+                for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] = 0.f;
+                for (int base = s0; base < s1; base += 64) {
+                    rows_to_lds();
+                    wave_lds_sync();
+                    fetch(base + 64 + lane);
+                    const int lo = max(my_start, base) - base, hi = min(my_end, base + 64) - base;
+                    for (int r = lo; r < hi; ++r) {
+                        const float* src = wval + r * ROW;
+#pragma unroll
+                        for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] += src[k2];
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
+            } else {
+                float* wacc = sAcc + wv * (64 * ROW);
+                int* wst = sStart + wv * 65;
+                wst[lane] = my_start;
+                if (lane == 63) wst[64] = my_end;
+#pragma unroll
+                for (int k2 = 0; k2 < ACC_VALS; ++k2) wacc[lane * ROW + k2] = 0.f;
+                for (int base = s0; base < s1; base += 64) {
+                    rows_to_lds();
+                    wave_lds_sync();
+                    fetch(base + 64 + lane);
+                    // the pairs whose ranges meet this chunk are consecutive lanes pa .. pb (empty ranges in between add nothing)
+                    const uint64_t pm = __builtin_amdgcn_ballot_w64(my_end > my_start && my_start < base + 64 && my_end > base);
+                    if (pm) {
+                        const int pa = __builtin_ctzll(pm), pb = 63 - __builtin_clzll(pm);
+                        const int items = (pb - pa + 1) * ROW;
+                        for (int it = lane; it < items; it += 64) {
+                            const int q = (it * 7282) >> 16;          // it / 9 for it < 576
+                            const int k2 = it - q * ROW, pp = pa + q;
+                            const int lo = max(wst[pp], base) - base, hi = min(wst[pp + 1], base + 64) - base;
+                            if (hi > lo) {
+                                float sum = wacc[pp * ROW + k2];
+                                const float* src = wval + k2;
+                                int r = lo;
+                                for (; r + 4 <= hi; r += 4) {   // (four reads in flight, the additions in slot order)
+                                    const float a0 = src[r * ROW], a1 = src[(r + 1) * ROW], a2 = src[(r + 2) * ROW], a3 = src[(r + 3) * ROW];
+                                    sum += a0; sum += a1; sum += a2; sum += a3;
+                                }
+                                for (; r < hi; ++r) sum += src[r * ROW];
+                                wacc[pp * ROW + k2] = sum;
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] = wacc[lane * ROW + k2];
+                wave_lds_sync();   // (the next camera zeroes the rows)
             }
             g0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
             g1 = make_float4(acc[4], acc[5], acc[6], acc[7]);

@@ -34,6 +34,9 @@ SCENES = {
     "medium": (20000, 4, 320, 240, 5, 0.004, 0.03),
     "one": (1, 1, 48, 32, 1, 0.05, 0.06),
     "many": (800, 9, 64, 48, 3, 0.01, 0.08),          # > 8 views: 64-bit level-1 keys, row-interleaved XCD map
+    # large Gaussians, ~25 tiles per visible pair (the regime of the configs[1] example after a few hundred iterations): the
+    # projection backward's slot gather takes its item-parallel form (gs_project_bwd.hip, round 6)
+    "wide": (2500, 3, 320, 240, 13, 0.08, 0.25),
 }
 
 
@@ -179,7 +182,7 @@ def _kept_list_against_oracle(ctx, g, w2c, Ks, W, H, meta, n_kept, max_dropped=2
     return o_code.size, int((~keep).sum())
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "many"] + FUZZ)
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "many", "wide"] + FUZZ)
 def test_fused_training_list_is_the_oracle_list_minus_dead_pairs(ctx, name):
     """the timed (fused training) path's record list was only ever compared with the oracle indirectly (same
     images, gradients close to the staged path's).  Directly: see _kept_list_against_oracle."""
@@ -498,7 +501,7 @@ def test_fused_step_on_edge_cases(ctx):
     assert bool(torch.isfinite(grads2).all())
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
+@pytest.mark.parametrize("name", ["small", "medium", "many", "wide"] + FUZZ)
 def test_fused_train_gradients_equal_stage_path(ctx, name):
     """The fused train step culls (record, tile) pairs whose alpha >= 1/255 box misses the tile and sorts in
     two levels; its gradients must equal the reference-exact stage path's (the dropped pairs fail the alpha
@@ -521,6 +524,8 @@ def test_fused_train_gradients_equal_stage_path(ctx, name):
     st = ops.train_fwd_bwd(ctx, P, vm, K, campos, gt, W, H, 0.2, 0.01, 0.01, grads, loss)
     torch.cuda.synchronize()
     assert st["n_isects_ref"] == info["isect_ids"].numel() and st["n_isects"] <= st["n_isects_ref"]
+    if name == "wide":
+        assert st["n_isects"] > 6 * st["n_visible"]       # (the slot gather's wide form: more than six slots per pair)
     # the culled render is the un-culled render, bit for bit ...
     for which, full in ((8, rgb), (9, alpha)):
         got = ops.peek(ctx, which, full.numel(), torch.float32)
