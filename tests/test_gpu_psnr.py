@@ -74,7 +74,7 @@ def train_hip(g, w2c, Ks, gt, W, H, iters):
     return {k: t.cpu().numpy() for k, t in P.items()}, losses.cpu().numpy().tolist()
 
 
-@pytest.mark.parametrize("seed,N,V,W,H,iters", [(4, 300, 3, 64, 48, 120), (9, 500, 2, 80, 64, 80)])
+@pytest.mark.parametrize("seed,N,V,W,H,iters", [(4, 300, 3, 64, 48, 60), (9, 500, 2, 80, 64, 40)])
 def test_psnr_parity_hip_vs_fp64_autograd(seed, N, V, W, H, iters):
     g, w2c, Ks, gt = _scene(seed, N, V, W, H)
     ref, loss_ref = train_ref_fp64(g, w2c, Ks, gt, W, H, iters)
