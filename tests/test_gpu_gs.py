@@ -78,7 +78,7 @@ def run_hip(ctx, g, w2c, Ks, W, H):
     return P, rgb, alpha, info
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one"] + FUZZ)
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "wide"] + FUZZ)
 def test_projection_tiles_sort_offsets_bit_exact(ctx, name):
     g, w2c, Ks, W, H = make(name)
     _, _, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks, W, H)
@@ -109,7 +109,7 @@ def test_radius_constant_kat(ctx):
     assert info["isect_ids"].numel() == 1
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "many"] + FUZZ)
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "many", "wide"] + FUZZ)
 def test_fused_two_level_sort_matches_reference_order(ctx, name):
     """The fused render/train path sorts in two levels ((camera|depth) then a stable (camera,tile)
     pass); its sorted pair ids and tile offsets must equal the oracle's single 64-bit-key sort."""
@@ -201,7 +201,7 @@ def test_fused_training_list_is_the_oracle_list_minus_dead_pairs(ctx, name):
     assert n_ref - n_drop == st["n_isects"]
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "medium"] + FUZZ)
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "wide"] + FUZZ)
 def test_blend_forward(ctx, name):
     g, w2c, Ks, W, H = make(name)
     rgb_o, alpha_o, meta = go.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["shN"], w2c, Ks,
@@ -215,8 +215,10 @@ def test_blend_forward(ctx, name):
     # determined to 1e-4 in float32 far from the mean: more pixels are excluded there, see gso_blend_fwd).  The
     # excluded fraction is a property of the scene and of the oracle alone (CPU, deterministic), so it is pinned per
     # scene instead of bounded by one loose number: 9 of the 12 stress scenes keep > 90 % of their pixels
-    assert ok.mean() >= (FUZZ_CHECKED[name] - 2e-3 if name.startswith("fuzz") else 0.999), (name, ok.mean())
-    if name.startswith("fuzz"):
+    # ("wide": ~100 large Gaussians deep per pixel, i.e. ~100 decisions per pixel that can sit near a threshold: 0.9974)
+    floor = FUZZ_CHECKED[name] - 2e-3 if name.startswith("fuzz") else (0.997 if name == "wide" else 0.999)
+    assert ok.mean() >= floor, (name, ok.mean())
+    if name.startswith("fuzz") or name == "wide":
         # the excluded pixels are not left unchecked: whichever way their borderline decisions fall, the image stays
         # within about one 1/255 step of the oracle's
         bad = ~ok
@@ -231,7 +233,7 @@ def test_blend_forward(ctx, name):
     assert alpha_o.max() > 0.3
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "medium"] + FUZZ)
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "wide"] + FUZZ)
 def test_backward_vs_oracle(ctx, name):
     from starst3r_amd import ops
     g, w2c, Ks, W, H = make(name)
@@ -259,7 +261,9 @@ def test_backward_vs_oracle(ctx, name):
     dist = {}
     maxerr = {}
     # measured (round 3): regular scenes median <= 7e-7, p99 <= 4e-5; stress scenes median <= 4e-5, p99 <= 5e-3
-    MED_BOUND, P99_BOUND = (1e-4, 1e-2) if name.startswith("fuzz") else (2e-6, 1e-4)
+    # ("wide": a record's gradient is a float32 sum over ~25 tiles x up to 256 pixels, grouped differently in kernel and oracle:
+    # median 1e-6 like the regular scenes, p99 1.1e-4)
+    MED_BOUND, P99_BOUND = (1e-4, 1e-2) if name.startswith("fuzz") else ((2e-6, 3e-4) if name == "wide" else (2e-6, 1e-4))
 
     # bounds against the tensor's maximum, set from the measured errors (round 4: regular scenes <= 1.5e-5 per pair and
     # <= 1.0e-5 per parameter, stress scenes <= 6.7e-5 and <= 1.0e-3 -- the needle-shaped Gaussians' quaternion chain rule);
@@ -540,7 +544,7 @@ def test_fused_train_gradients_equal_stage_path(ctx, name):
     assert abs(float(loss[0]) - expect) <= 1e-5 * abs(expect)
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "many"] + FUZZ)
+@pytest.mark.parametrize("name", ["small", "medium", "many", "wide"] + FUZZ)
 def test_cell_list_forward_equals_quadrant_forward(ctx, name):
     """The fused training path blends with 4x4-cell lists (gs_blend_cells.hip: four records per trip, one per 16-lane row,
     exec-masked tests); st3r_gs_render takes the same kernel under debug flag 512.  Same records per pixel in the same
@@ -562,7 +566,7 @@ def test_cell_list_forward_equals_quadrant_forward(ctx, name):
         assert torch.equal(a1.view(torch.int32), a0.view(torch.int32)), flags
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one"] + FUZZ[:6])
+@pytest.mark.parametrize("name", ["small", "ragged", "medium", "one", "wide"] + FUZZ[:6])
 def test_segmented_level1_sort_changes_no_bit(ctx, name):
     """Round 6: the training calls sort the pairs of every camera as a segment of its own, on depth codes biased by the
     smallest one of the call, in as many 8-bit passes as that range needs (three at SYNTH-1M instead of four; decided on the
