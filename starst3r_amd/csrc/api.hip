@@ -294,7 +294,7 @@ int st3r_counts_buffer(st3r_ctx* ctx, hipStream_t s, int32_t** out) {
 struct RasterOut {
     float* splats; int32_t* offsets; int32_t* flat; int32_t* cum; const uint64_t* rects; uint64_t* rectbase;
     // n_isects: the slot count (sum of the rectangle areas) = capacity of everything indexed by record or slot;
-    // n_records: the records actually emitted (masked rectangles, tile_rect.h), -1 while the count stays on the device
+    // n_records: the records emitted (= n_isects on the synchronous path), -1 while the count stays on the device
     int64_t n_isects, n_records, n_isects_ref, n_visible; int tile_w, tile_h;
 };
 

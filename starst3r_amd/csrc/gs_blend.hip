@@ -4,8 +4,7 @@
 //
 // Mapping.  One workgroup = one 16x16 tile = 4 wave64; wave w owns the 8x8 quadrant
 // (w&1, w>>1).  Workgroups are remapped so that each XCD (private 4 MiB L2) walks groups of
-// consecutive (camera, tile) ids: a whole camera per XCD when the views are a multiple of 8,
-// tile rows round-robin over the XCDs otherwise (see xcd_remap).
+// consecutive (camera, tile) ids: one tile row per group, the rows round-robin over the XCDs (see xcd_remap, XCD_GROUP).
 //
 // Staging + wavefront compaction.  The tile's depth-sorted list is staged through LDS in
 // batches of 256 splat records (one record per thread, 3 x 16-byte loads).  The staging
