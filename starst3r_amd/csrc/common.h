@@ -72,6 +72,7 @@ enum ArenaSlot {
     SLOT_PSTAGE,
     SLOT_GSTAGE,
     SLOT_ALIGN_CTL,   // alignment: the chain cache of k_align_update
+    SLOT_PAIR_TOUCH,  // blend backward -> projection backward: per-pair stamp "some slot of this pair was written" (gs_blend.hip)
     SLOT_KRANGE_PART, // projection: per-block smallest / largest level-1 key (gs_project.hip)
     SLOT_SCAN_CHAIN,  // single-pass scans (gs_isect.hip): ticket, totals, one status word per tile
     SLOT_COUNT
@@ -98,7 +99,9 @@ enum Stage {
 #define ST3R_SPLIT_VIEWS 1000   // internal: more than 2^31 tile intersections, the caller may retry with fewer views
 
 // the backward's stamped (record, tile) slots, handed to the kernel that sums them per pair (gs_blend.hip -> gs_project_bwd.hip)
-struct st3r_vtile_ref { const int32_t* cum; const float* vtile; int stamp; unsigned vt_cap; };
+// touch (may be NULL): per pair the stamp of the last backward call in which some (record, tile) of the pair contributed --
+// written by k_blend_bwd for scenes of many slots per pair, so that the gather can skip the slots of pairs nobody touched
+struct st3r_vtile_ref { const int32_t* cum; const float* vtile; int stamp; unsigned vt_cap; const uint32_t* touch; };
 
 struct st3r_ctx {
     int device;

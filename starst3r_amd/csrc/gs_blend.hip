@@ -333,7 +333,9 @@ __device__ __forceinline__ void bwd_phase2(const float2* __restrict__ pr, unsign
     wave_lds_sync();
 }
 
-template <bool HAS_VA>  // v_alpha is NULL in the train step (the reference's loss ignores render_alpha, gs.py:126)
+// TOUCH: `rects` is not a rectangle array but the per-pair touch stamps (uint32 [C*N]; only with `rectbase`, which leaves
+// `rects` unused): a variant of its own, because the kernel sits at its 80-SGPR / 64-VGPR limits and SYNTH-1M never takes it
+template <bool HAS_VA, bool TOUCH = false>  // v_alpha is NULL in the train step (the reference's loss ignores render_alpha, gs.py:126)
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k_blend_bwd(int C, int W, int H, int tile_w, int tile_h,
                                                    const float4* __restrict__ splats,
                                                    const int32_t* __restrict__ offsets,
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
                                                    const uint64_t* __restrict__ rects,
                                                    const uint64_t* __restrict__ rectbase, int tight,
                                                    float* __restrict__ vtile, int stamp, unsigned vt_cap) {
+
     // staged records, same q-form as the forward's but as three arrays (measured: the forward is faster with one
     // 48-byte record per staged index, this kernel with the split layout)
     __shared__ float4 sA[HB];   // x y opacity qa
@@ -447,6 +450,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8))) void k
             const uint64_t cw = __builtin_amdgcn_ballot_w64(hard);
             if (t == 0) sClampW = cw;
             if (my_cb && rectbase) {   // fused path: slot base and rectangle in one gathered word
+                // (scenes of many slots per pair: the pair is marked as touched by this backward call -- the gather skips
+                // the slot ranges of pairs nobody marked; a benign race, every writer stores the same stamp)
+                if (TOUCH) reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(rects))[my_id] = (uint32_t)stamp;
                 const uint64_t r = rectbase[my_id];
                 const int x0 = (int)(r & 0x3FF), y0 = (int)((r >> 10) & 0x3FF), rw = (int)((r >> 20) & 0x3FF);
                 my_u = (int)(r >> 32) + ((g.ty0 >> 4) - y0) * rw + ((g.tx0 >> 4) - x0);
@@ -627,7 +633,7 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
                         const int32_t* cum, const uint64_t* rects, const uint64_t* rectbase, int tight, int64_t n_pairs,
                         float* v_splats, bool end_in_offsets, st3r_vtile_ref* defer) {
     // defer != NULL: the caller's next kernel sums the slots per pair itself (gs_project_bwd.hip); v_splats is not written
-    if (defer) *defer = st3r_vtile_ref{cum, nullptr, 0, 0u};
+    if (defer) *defer = st3r_vtile_ref{cum, nullptr, 0, 0u, nullptr};
     if (n_isects == 0) {
         if (!defer) HIP_TRY(hipMemsetAsync(v_splats, 0, sizeof(float) * ST3R_SPLAT_STRIDE * (size_t)n_pairs, s));
         return ST3R_OK;   // (defer: every pair's slot range is empty -- `cum` is all zeros -- and vt_cap = 0 guards the rest)
@@ -642,9 +648,25 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * VT_STRIDE * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
     float* vtile = (float*)p;
-    if (grown || ctx->bwd_stamp >= 2147483000) {
+    // Per-pair "touched" stamps, only where they pay: a scene with many slots per pair (large Gaussians; more than four on
+    // average) AND a gather that follows in the projection backward.  There most slots belong to pairs that never contribute
+    // (behind the saturation depth of their tiles): the configs[1] example reads 6.4 GB of slots per step of which ~15 % were
+    // written.  SYNTH-1M (3.3 slots per pair) does not take this path: one more scattered store per staged record for nothing.
+    uint32_t* touch = nullptr;
+    int grown_t = 0;
+    if (defer && rectbase && !v_alpha && n_isects > 4 * n_pairs) {
+        void* pt;
+        rc = st3r_arena_get2(ctx, SLOT_PAIR_TOUCH, sizeof(uint32_t) * (size_t)n_pairs, &pt, &grown_t);
+        if (rc) return rc;
+        touch = (uint32_t*)pt;
+    }
+    if (grown || ctx->bwd_stamp >= 2147483000) {   // (the stamps restart: both stamp stores are cleared together)
         HIP_TRY(hipMemsetAsync(p, 0, ctx->slot_bytes[SLOT_VTILE], s));
+        if (ctx->slot_ptr[SLOT_PAIR_TOUCH])
+            HIP_TRY(hipMemsetAsync(ctx->slot_ptr[SLOT_PAIR_TOUCH], 0, ctx->slot_bytes[SLOT_PAIR_TOUCH], s));
         ctx->bwd_stamp = 0;
+    } else if (grown_t) {   // (a fresh touch array: zeros are older than every stamp in use)
+        HIP_TRY(hipMemsetAsync(touch, 0, ctx->slot_bytes[SLOT_PAIR_TOUCH], s));
     }
     const int stamp = ++ctx->bwd_stamp;
     const int total = C * tile_w * tile_h;
@@ -653,12 +675,17 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
         hipLaunchKernelGGL(k_blend_bwd<true>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
                            v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp, vt_cap);
+    else if (touch)
+        hipLaunchKernelGGL((k_blend_bwd<false, true>), dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
+                           (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
+                           v_alpha, cmask, words, tile_nb, cum, reinterpret_cast<const uint64_t*>(touch), rectbase, tight, vtile,
+                           stamp, vt_cap);
     else
         hipLaunchKernelGGL(k_blend_bwd<false>, dim3(total), dim3(BLK), 0, s, C, W, H, tile_w, tile_h,
                            (const float4*)splats, offsets, flat, end_in_offsets ? -1 : (int)n_isects, alpha, last_ids, v_rgb,
                            v_alpha, cmask, words, tile_nb, cum, rects, rectbase, tight, vtile, stamp, vt_cap);
     LAUNCH_CHECK();
-    if (defer) { *defer = st3r_vtile_ref{cum, vtile, stamp, vt_cap}; return ST3R_OK; }
+    if (defer) { *defer = st3r_vtile_ref{cum, vtile, stamp, vt_cap, touch}; return ST3R_OK; }
     hipLaunchKernelGGL(k_gather_vtile, dim3(ceil_div(n_pairs, 256)), dim3(256), 0, s, n_pairs, cum, vtile, stamp, vt_cap,
                        (float4*)v_splats);
     LAUNCH_CHECK();

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const float* __restrict__ campos, int W, int H, float eps2d, const float4* __restrict__ splats,
     const float4* __restrict__ v_splats, float reg_o_k, float reg_s_k, float* __restrict__ grads, int accumulate,
     int g_begin, int g_end, int range_major, const int32_t* __restrict__ cum, const float* __restrict__ vtile, int stamp,
-    unsigned vt_cap) {
+    unsigned vt_cap, const uint32_t* __restrict__ touch) {
     extern __shared__ float cam[];
     constexpr int ROW = ACC_VALS;   // odd stride: rows of neighbouring slots fall into different banks
     __shared__ float sVal[GATHER ? 256 * ROW : 1];    // per wave: the current chunk of 64 slots, nine values each
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 row[3] = live ? q1.y : 0.f; row[4] = live ? q2.x : 0.f; row[5] = live ? q2.y : 0.f;
                 row[6] = live ? q3.x : 0.f; row[7] = live ? q3.y : 0.f; row[8] = live ? q4.x : 0.f;
             };
-            if (s1 > s0) fetch(s0 + lane);
             if (s1 - s0 <= 64 * GATHER_WIDE_ABOVE) {
+                if (s1 > s0) fetch(s0 + lane);
 #pragma unroll
                 for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] = 0.f;
                 for (int base = s0; base < s1; base += 64) {
@@ -167,13 +167,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 if (lane == 63) wst[64] = my_end;
 #pragma unroll
                 for (int k2 = 0; k2 < ACC_VALS; ++k2) wacc[lane * ROW + k2] = 0.f;
+                // pairs some (record, tile) of which contributed in this backward call (k_blend_bwd marks them when the scene
+                // has many slots per pair; without the marks every pair counts): a chunk of slots that meets none of them
+                // holds no stamped slot -- it is neither fetched nor added
+                const uint64_t tmask = touch ? __builtin_amdgcn_ballot_w64(valid && touch[pid] == (uint32_t)stamp) : ~0ull;
+                auto meets = [&](int b) {
+                    return __builtin_amdgcn_ballot_w64(my_end > my_start && my_start < b + 64 && my_end > b);
+                };
+                uint64_t pm_next = meets(s0);
+                bool have = false;      // the registers hold the rows of the chunk about to be processed
+                if (pm_next & tmask) { fetch(s0 + lane); have = true; }
                 for (int base = s0; base < s1; base += 64) {
-                    rows_to_lds();
-                    wave_lds_sync();
-                    fetch(base + 64 + lane);
-                    // the pairs whose ranges meet this chunk are consecutive lanes pa .. pb (empty ranges in between add nothing)
-                    const uint64_t pm = __builtin_amdgcn_ballot_w64(my_end > my_start && my_start < base + 64 && my_end > base);
-                    if (pm) {
+                    const uint64_t pm = pm_next & tmask;
+                    const bool cur = have;
+                    if (cur) { rows_to_lds(); wave_lds_sync(); }
+                    pm_next = base + 64 < s1 ? meets(base + 64) : 0ull;
+                    have = (pm_next & tmask) != 0;
+                    if (have) fetch(base + 64 + lane);
+                    if (cur) {
                         const int pa = __builtin_ctzll(pm), pb = 63 - __builtin_clzll(pm);
                         const int items = (pb - pa + 1) * ROW;
                         for (int it = lane; it < items; it += 64) {
@@ -192,9 +203,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                                 wacc[pp * ROW + k2] = sum;
                             }
                         }
+                        wave_lds_sync();
                     }
-                    wave_lds_sync();
                 }
+                wave_lds_sync();   // (the zeroed sums of a range without any touched chunk are visible to their lanes)
 #pragma unroll
                 for (int k2 = 0; k2 < ACC_VALS; ++k2) acc[k2] = wacc[lane * ROW + k2];
                 wave_lds_sync();   // (the next camera zeroes the rows)
@@ -392,12 +404,12 @@ int st3r_project_sh_bwd_impl(hipStream_t s, int N, int C, const float* means, co
         hipLaunchKernelGGL(k_project_sh_bwd<true>, dim3(ceil_div(g_end - g_begin, 256)), dim3(256), shmem, s, N, C, means,
                            quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d,
                            (const float4*)splats, (const float4*)nullptr, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin,
-                           g_end, range_major ? 1 : 0, slots->cum, slots->vtile, slots->stamp, slots->vt_cap);
+                           g_end, range_major ? 1 : 0, slots->cum, slots->vtile, slots->stamp, slots->vt_cap, slots->touch);
     else
         hipLaunchKernelGGL(k_project_sh_bwd<false>, dim3(ceil_div(g_end - g_begin, 256)), dim3(256), shmem, s, N, C, means,
                            quats, scales, opacities, sh, sh_stride, viewmats, Ks, campos, width, height, eps2d,
                            (const float4*)splats, (const float4*)v_splats, reg_o_k, reg_s_k, grads, accumulate ? 1 : 0, g_begin,
-                           g_end, range_major ? 1 : 0, (const int32_t*)nullptr, (const float*)nullptr, 0, 0u);
+                           g_end, range_major ? 1 : 0, (const int32_t*)nullptr, (const float*)nullptr, 0, 0u, (const uint32_t*)nullptr);
     LAUNCH_CHECK();
     return ST3R_OK;
 }
