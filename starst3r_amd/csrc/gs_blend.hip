@@ -648,13 +648,14 @@ int st3r_blend_bwd_impl(st3r_ctx* ctx, hipStream_t s, int C, int W, int H, int t
     rc = st3r_arena_get2(ctx, SLOT_VTILE, sizeof(float) * VT_STRIDE * (size_t)n_isects, &p, &grown);
     if (rc) return rc;
     float* vtile = (float*)p;
-    // Per-pair "touched" stamps, only where they pay: a scene with many slots per pair (large Gaussians; more than four on
-    // average) AND a gather that follows in the projection backward.  There most slots belong to pairs that never contribute
+    // Per-pair "touched" stamps, only where they pay: a scene with many slots per pair (large Gaussians; more than eight
+    // per pair SLOT of the call -- the gather's item-parallel form, which is the one that skips, starts at six per visible pair
+    // of a wave, and SYNTH-1M late in training reaches five) AND a gather that follows in the projection backward.  There most slots belong to pairs that never contribute
     // (behind the saturation depth of their tiles): the configs[1] example reads 6.4 GB of slots per step of which ~15 % were
     // written.  SYNTH-1M (3.3 slots per pair) does not take this path: one more scattered store per staged record for nothing.
     uint32_t* touch = nullptr;
     int grown_t = 0;
-    if (defer && rectbase && !v_alpha && n_isects > 4 * n_pairs) {
+    if (defer && rectbase && !v_alpha && n_isects > 8 * n_pairs) {
         void* pt;
         rc = st3r_arena_get2(ctx, SLOT_PAIR_TOUCH, sizeof(uint32_t) * (size_t)n_pairs, &pt, &grown_t);
         if (rc) return rc;
